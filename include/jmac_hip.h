@@ -1,0 +1,212 @@
+/*
+ * jmac_hip.h -- C ABI of libjmac_hip.so: the MI355X (gfx950) implementation of JMAC's relation-aware
+ * GNN layer and triple / entity-pair scoring hot path.
+ *
+ * The reference (vinhsuhi/JMAC) is pure Python/PyTorch and has no FFI of its own; the seams this
+ * library replaces are the Python call sites cited on every entry point below (paths relative to the
+ * reference tree).  INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous row-major data unless the name starts with h_;
+ *  - the caller owns every buffer; the library never allocates device memory.  Scratch space is
+ *    passed in (`ws`, `ws_bytes`); its size comes from the matching *_workspace_bytes() function;
+ *  - row tables carry a leading dimension in ELEMENTS (ld*): rows must be 16-byte aligned
+ *    (ld % 4 == 0, base 16-B aligned) and d % 4 == 0, d <= 512 (the Python host pads d);
+ *  - indices on the device side are int32 (edge / node / relation ids), sizes are int64;
+ *    the reference's int64 edge lists are converted by jmac_csr_build;
+ *  - every function takes the stream to launch on (pass torch.cuda.current_stream().cuda_stream),
+ *    is asynchronous, never synchronises, and is hipGraph-capturable;
+ *  - return value: 0 = ok, negative = JMAC_E* argument error, positive = hipError_t;
+ *  - no global state; re-entrant; one host thread per device.
+ */
+#ifndef JMAC_HIP_H_
+#define JMAC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* jmac_stream_t; /* hipStream_t */
+
+#define JMAC_OK 0
+#define JMAC_EINVAL (-1)    /* bad argument (null pointer, negative size)            */
+#define JMAC_EDIM (-2)      /* unsupported d (d % 4 != 0 or d > 512) or ld           */
+#define JMAC_EWORKSPACE (-3) /* workspace too small                                   */
+#define JMAC_ERANGE (-4)    /* size exceeds int32 indexing                           */
+
+/* A schedule item: one wavefront's unit of work = a run of at most `chunk` consecutive entries of one
+ * segment (segment = destination node, source node or relation type).  pslot < 0: the item covers its
+ * whole segment and finalises it; pslot >= 0: partial result slot, merged by the combine pass. */
+typedef struct { int32_t seg, beg, end, pslot; } jmac_item_t;
+/* A segment that was split over several items. */
+typedef struct { int32_t seg, pslot0, nchunks, pad; } jmac_split_t;
+
+const char* jmac_strerror(int rc);
+int jmac_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Graph ingest (replaces: compute_norm's scatter_add degree, src/jmac_model.py:99-109; the implicit
+ * COO edge lists of train.py:116-135 and src/utils.py:112-149).
+ * --------------------------------------------------------------------------------------------- */
+
+/* Bytes of scratch needed by jmac_csr_build / jmac_group_build for E entries and S segments. */
+size_t jmac_graph_workspace_bytes(int64_t E, int64_t S);
+
+/* COO (edge_index [2,E] int64: row 0 = aggregation destination, row 1 = message source;
+ * edge_type [E] int64) -> CSR by destination with a STABLE order inside each row.
+ *   rowptr [N+1], col [E] (source of each CSR slot), etype [E], perm [E] (original edge id). */
+int jmac_csr_build(const int64_t* edge_index, const int64_t* edge_type, int64_t E, int64_t N,
+                   int32_t* rowptr, int32_t* col, int32_t* etype, int32_t* perm,
+                   void* ws, size_t ws_bytes, jmac_stream_t stream);
+
+/* Generic stable grouping of E int32 keys in [0,S): ptr [S+1], order [E] (positions sorted by key).
+ * Used for the by-source (CSC) and by-relation views of the CSR slots needed by the backward. */
+int jmac_group_build(const int32_t* keys, int64_t E, int64_t S, int32_t* ptr, int32_t* order,
+                     void* ws, size_t ws_bytes, jmac_stream_t stream);
+
+/* Upper bounds for the arrays jmac_items_build fills. */
+int64_t jmac_items_max(int64_t S, int64_t E, int32_t chunk);      /* items                  */
+int64_t jmac_splits_max(int64_t E, int32_t chunk);                /* split segments         */
+int64_t jmac_parts_max(int64_t E, int32_t chunk);                 /* partial slots          */
+
+/* Cut segments (ptr [S+1]) into items of at most `chunk` entries.
+ *   items [jmac_items_max], splits [jmac_splits_max], counts [4] = {n_items, n_splits, n_parts, 0}
+ *   (device ints: kernels read the counts, the host never has to). */
+int jmac_items_build(const int32_t* ptr, int64_t S, int32_t chunk, jmac_item_t* items,
+                     jmac_split_t* splits, int32_t* counts, void* ws, size_t ws_bytes,
+                     jmac_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Relation-aware attention aggregation (replaces: MessagePassing.propagate + message + scatter_,
+ * modules/helper/message_passing.py:4-29,55-90 and src/jmac_model.py:56-89; the self-loop
+ * propagate of src/jmac_model.py:44-45,50; the (nb+self)/2 of :52), in the factorised form
+ *     h_e = P[i] + Q[j] - Rq[t]        s_e = a . LeakyReLU(h_e)      alpha = softmax over in(i)
+ *     out[i] = out_scale * ( sqrt(deg_i) * sum_e alpha_e (Z[j] - Rz[t])  +  [Z[i] - Rz[loop]] )
+ * for edges e = (i <- j, type t).  Tables: P [N,d] (ldp); QZ [N,2d] = Q|Z per node (ldqz);
+ * RR [nr+1,2d] = Rq|Rz per relation (ldrr); a_att [d].  loop_rel < 0 drops the bracketed self term.
+ * seg_max/seg_den [N] receive the per-destination softmax max / denominator for the backward.
+ * --------------------------------------------------------------------------------------------- */
+size_t jmac_rel_attn_fwd_workspace_bytes(int64_t n_parts_max, int64_t d);
+
+int jmac_rel_attn_aggregate_fwd_f32(
+    const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR, int64_t ldrr,
+    const float* a_att, const int32_t* rowptr, const int32_t* col, const int32_t* etype,
+    const jmac_item_t* items, const jmac_split_t* splits, const int32_t* counts,
+    int64_t n_items_max, int64_t n_splits_max, int64_t n_parts_max, int64_t N, int64_t d,
+    float slope, int32_t loop_rel, float out_scale, float* out, int64_t ldo, float* seg_max,
+    float* seg_den,
+    void* ws, size_t ws_bytes, jmac_stream_t stream);
+
+/* Backward of the op above (replaces autograd through the same reference lines).
+ *   G [N,d] (ldg) = dL/dout;  outputs: dP [N,d] (lddp), dQZ [N,2d] (lddqz), dRR [nr+1,2d] (lddrr),
+ *   da [d].  All outputs are fully written (no pre-zeroing needed).
+ * mode 0 ("atomic"): one pass by destination, float atomics into dQZ / dRR.
+ * mode 1 ("deterministic", default): pass A by destination writes per-edge records, pass B by source
+ *   and pass C by relation sum them with plain stores: bitwise reproducible, no atomics.
+ *   Needs the by-source view (sptr [N+1], sorder [E], sitems ...) and the by-relation view
+ *   (tptr [nrel+1], torder [E], titems ...) of the CSR slots, built with jmac_group_build +
+ *   jmac_items_build. dst_of_slot [E] = destination node of each CSR slot. */
+size_t jmac_rel_attn_bwd_workspace_bytes(int64_t N, int64_t E, int64_t nrel, int64_t d,
+                                         int64_t n_parts_max_dst, int64_t n_parts_max_src,
+                                         int64_t n_parts_max_rel, int32_t mode);
+
+typedef struct {
+    const int32_t* ptr;          /* [S+1]                         */
+    const int32_t* order;        /* [E] CSR slot per entry, or NULL for the CSR itself */
+    const jmac_item_t* items;
+    const jmac_split_t* splits;
+    const int32_t* counts;       /* device {n_items,n_splits,n_parts,0} */
+    int64_t n_items_max, n_splits_max, n_parts_max;
+} jmac_view_t;
+
+int jmac_rel_attn_aggregate_bwd_f32(
+    const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR, int64_t ldrr,
+    const float* a_att, const int32_t* col, const int32_t* etype, const int32_t* dst_of_slot,
+    const jmac_view_t* by_dst, const jmac_view_t* by_src, const jmac_view_t* by_rel,
+    int64_t N, int64_t E, int64_t nrel, int64_t d, float slope, int32_t loop_rel, float out_scale,
+    const float* out, int64_t ldo, const float* seg_max, const float* seg_den,
+    const float* G, int64_t ldg,
+    float* dP, int64_t lddp, float* dQZ, int64_t lddqz, float* dRR, int64_t lddrr, float* da,
+    int32_t mode, void* ws, size_t ws_bytes, jmac_stream_t stream);
+
+/* BatchNorm1d (batch statistics or running statistics) + tanh on [N,d]
+ * (replaces: self.layer_act(self.bn(.)), src/jmac_model.py:52).
+ * training != 0: mean/var are computed over the N rows (biased var), written to save_mean /
+ * save_invstd [d], and running_mean/var (may be NULL) are updated with `momentum` (unbiased var). */
+size_t jmac_bn_tanh_workspace_bytes(int64_t N, int64_t d);
+int jmac_bn_tanh_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, const float* weight,
+                         const float* bias, float* running_mean, float* running_var,
+                         int32_t training, float momentum, float eps, float* y, int64_t ldy,
+                         float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                         jmac_stream_t stream);
+int jmac_bn_tanh_bwd_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy,
+                         int64_t ldgy, int64_t N, int64_t d, const float* weight,
+                         const float* save_mean, const float* save_invstd, int32_t training,
+                         float* gx, int64_t ldgx, float* gweight, float* gbias, void* ws,
+                         size_t ws_bytes, jmac_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Completion scoring (replaces: torch.cdist(er, all_kg_emb, p=1), src/jmac_model.py:312; the
+ * filter/sort/np.where ranking loop of src/validate.py:50-64).
+ * --------------------------------------------------------------------------------------------- */
+/* out[b,n] (+)= sum_k |er[b,k] - table[n,k]|;  accumulate != 0 adds to out (layer loop of :302). */
+int jmac_l1_score_f32(const float* er, int64_t lder, const float* table, int64_t ldt, int64_t B,
+                      int64_t N, int64_t d, float* out, int64_t ldout, int32_t accumulate,
+                      jmac_stream_t stream);
+
+/* rank[b] = 1 + #{n : score[b,n] < score[b,gold] or (== and n < gold[b])}, where entries listed in
+ * the filter CSR (filt_ptr [B+1], filt_idx) other than the gold are skipped.  `score` is a DISTANCE
+ * (the reference's predictions = -dist, sorted descending).  filt_ptr may be NULL (raw ranking). */
+int jmac_filtered_rank_f32(const float* score, int64_t lds, const int32_t* gold,
+                           const int32_t* filt_ptr, const int32_t* filt_idx, int64_t B, int64_t N,
+                           int32_t* rank, jmac_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Alignment scoring (replaces: get_neg's mm + topk, modules/utils/util.py:52-53; the mm / softmax /
+ * entropy of compute_alignment_quality, train.py:239-248).
+ * --------------------------------------------------------------------------------------------- */
+/* C[m,n] = sum_k A[m,k] * B[n,k]  (fp32-in / fp32-accumulate MFMA: exact fp32 products). */
+int jmac_sim_matrix_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
+                        int64_t N, int64_t d, float* C, int64_t ldc, jmac_stream_t stream);
+
+size_t jmac_sim_topk_workspace_bytes(int64_t L, int64_t N);
+/* Per row of A: the k largest similarities against all rows of B, descending, ties -> lower index
+ * first.  val [L,k] (may be NULL), idx [L,k] int32. */
+int jmac_sim_topk_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t L, int64_t N,
+                      int64_t d, int32_t k, float* val, int32_t* idx, void* ws, size_t ws_bytes,
+                      jmac_stream_t stream);
+
+/* Row top-k of an existing score matrix (same ordering rule). */
+int jmac_row_topk_f32(const float* S, int64_t lds, int64_t L, int64_t N, int32_t k, float* val,
+                      int32_t* idx, jmac_stream_t stream);
+
+size_t jmac_softmax_entropy_workspace_bytes(int64_t n1, int64_t n2);
+/* S = A B^T (n1 x n2); ent_rows[i] = H(softmax_j(scale*S[i,:])), ent_cols[j] = H(softmax_i(scale*S[:,j])). */
+int jmac_softmax_entropy_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t n1,
+                             int64_t n2, int64_t d, float scale, float* ent_rows, float* ent_cols,
+                             void* ws, size_t ws_bytes, jmac_stream_t stream);
+
+/* Row softmax of scale*S with rows in `row_mask` and columns in `col_mask` (uint8, 1 = keep) left as
+ * is and every other entry replaced by `fill` first (train.py:252-257: fill = -1). In place allowed. */
+int jmac_masked_row_softmax_f32(const float* S, int64_t lds, int64_t n1, int64_t n2,
+                                const uint8_t* row_mask, const uint8_t* col_mask, float fill,
+                                float scale, float* out, int64_t ldo, jmac_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * torch_scatter-compatible primitives (replace the third-party calls at src/jmac_model.py:105 and
+ * modules/helper/message_passing.py:24,28) so the UNMODIFIED reference layer can run on this library.
+ * index need not be sorted.  out must be pre-zeroed by the caller for scatter_sum.
+ * --------------------------------------------------------------------------------------------- */
+int jmac_scatter_sum_f32(const float* src, const int64_t* index, int64_t E, int64_t d, int64_t N,
+                         float* out, jmac_stream_t stream);
+size_t jmac_scatter_softmax_workspace_bytes(int64_t N, int64_t d);
+int jmac_scatter_softmax_f32(const float* src, const int64_t* index, int64_t E, int64_t d, int64_t N,
+                             float* out, void* ws, size_t ws_bytes, jmac_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JMAC_HIP_H_ */

@@ -1,0 +1,744 @@
+// aggregate.hip -- relation-aware attention aggregation for gfx950 (forward + backward).
+//
+// Replaces, in the factorised form of DESIGN.md, the reference's per-edge message / attention /
+// scatter_softmax / scatter-sum chain (modules/helper/message_passing.py:4-29,55-90;
+// src/jmac_model.py:56-89), the self-loop propagate (src/jmac_model.py:44-45,50) and the (nb+self)/2
+// of src/jmac_model.py:52.
+//
+// Execution model (CDNA4): one 64-lane wavefront per schedule item (a run of <= chunk edges of one
+// destination).  A node's [Q|Z] row (2d floats) is covered by NCH float4 "chunks" per lane, chunk
+// c = lane + 64k: chunks c < d/4 are the attention half (h-role), the rest the message half (v-role).
+// Every gather is a contiguous 8d-byte row read with 16 B per lane; U edges are kept in flight per
+// wave; logits are reduced across the wave with DPP + permlane swaps; the softmax is online (running
+// max / denominator), so each edge row is read exactly once.  The relation table [Rq|Rz] stays
+// L2-resident.  HBM-bound by design: see DESIGN.md for the byte model.
+#include "common.h"
+
+using namespace jmac;
+
+namespace {
+
+constexpr int kBlock = 256;            // 4 waves
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kPersistBlocks = 2048;   // 256 CUs x 8
+
+struct FwdArgs {
+    const float *P, *QZ, *RR, *a_att;
+    int64_t ldp, ldqz, ldrr, ldo;
+    const int32_t *rowptr, *col, *etype;
+    const jmac_item_t* items;
+    const jmac_split_t* splits;
+    const int32_t* counts;
+    int32_t N, D4, loop_rel;
+    float slope, out_scale;
+    float *out, *seg_max, *seg_den;
+    float *part_acc, *part_ml;
+};
+
+template <int NCH>
+struct Lanes {
+    int coff[NCH];     // float offset of this lane's chunk inside a [Q|Z] row
+    bool valid[NCH];
+    bool is_h[NCH];
+    __device__ __forceinline__ void init(int lane, int D4) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            int c = lane + 64 * k;
+            valid[k] = c < 2 * D4;
+            is_h[k] = c < D4;
+            coff[k] = c * 4;
+        }
+    }
+};
+
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 fma4(float4 a, float s, float4 c) {
+    return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
+}
+__device__ __forceinline__ float4 leaky4(float4 h, float slope) {
+    return make_float4(leaky(h.x, slope), leaky(h.y, slope), leaky(h.z, slope), leaky(h.w, slope));
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int NCH, int U>
+__global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    const int n_items = a.counts[0];
+    Lanes<NCH> L;
+    L.init(lane, a.D4);
+    const int voff = 4 * a.D4;
+    float4 av[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) av[k] = (L.valid[k] && L.is_h[k]) ? ld4(a.a_att + L.coff[k]) : f4zero();
+
+    for (int it = blockIdx.x * kWavesPerBlock + wave; it < n_items; it += nwaves) {
+        const jmac_item_t item = a.items[it];
+        const int i = item.seg;
+        float4 pv[NCH], acc[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            pv[k] = (L.valid[k] && L.is_h[k]) ? ld4(a.P + (int64_t)i * a.ldp + L.coff[k]) : f4zero();
+            acc[k] = f4zero();
+        }
+        float m = -INFINITY, l = 0.f;
+        for (int e0 = item.beg; e0 < item.end; e0 += 64) {
+            const int nb = min(64, item.end - e0);
+            int my_col = 0, my_typ = 0;
+            if (lane < nb) {
+                my_col = a.col[e0 + lane];
+                my_typ = a.etype[e0 + lane];
+            }
+            for (int u0 = 0; u0 < nb; u0 += U) {
+                float4 df[U][NCH];
+                float s[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool ev = (u0 + u) < nb;   // wave-uniform
+                    if (ev) {
+                        const int j = bcast_i(my_col, u0 + u);
+                        const int t = bcast_i(my_typ, u0 + u);
+                        const float* qrow = a.QZ + (int64_t)j * a.ldqz;
+                        const float* rrow = a.RR + (int64_t)t * a.ldrr;
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k)
+                            df[u][k] = L.valid[k] ? sub4(ld4(qrow + L.coff[k]), ld4(rrow + L.coff[k])) : f4zero();
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) df[u][k] = f4zero();
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float part = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) part += dot4(av[k], leaky4(add4(pv[k], df[u][k]), a.slope));
+                    s[u] = wave_sum(part);
+                    if (!((u0 + u) < nb)) s[u] = -INFINITY;
+                }
+                float gmax = s[0];
+#pragma unroll
+                for (int u = 1; u < U; ++u) gmax = fmaxf(gmax, s[u]);
+                const float mn = fmaxf(m, gmax);
+                const float sc = expf(m - mn);
+                float w[U], wsum = 0.f;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    w[u] = expf(s[u] - mn);
+                    wsum += w[u];
+                }
+                l = l * sc + wsum;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    float4 r = mul4(acc[k], sc);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) r = fma4(df[u][k], w[u], r);
+                    acc[k] = r;
+                }
+                m = mn;
+            }
+        }
+        if (item.pslot < 0) {
+            const int deg = item.end - item.beg;
+            const float scale = l > 0.f ? sqrtf((float)deg) / l : 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                if (L.valid[k] && !L.is_h[k]) {
+                    float4 o = mul4(acc[k], scale);
+                    if (a.loop_rel >= 0) {
+                        float4 z = ld4(a.QZ + (int64_t)i * a.ldqz + L.coff[k]);
+                        float4 rz = ld4(a.RR + (int64_t)a.loop_rel * a.ldrr + L.coff[k]);
+                        o = add4(o, sub4(z, rz));
+                    }
+                    st4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff), mul4(o, a.out_scale));
+                }
+            }
+            if (lane == 0) {
+                a.seg_max[i] = m;
+                a.seg_den[i] = l;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if (L.valid[k] && !L.is_h[k]) st4(a.part_acc + (int64_t)item.pslot * voff + (L.coff[k] - voff), acc[k]);
+            if (lane == 0) {
+                a.part_ml[2 * item.pslot] = m;
+                a.part_ml[2 * item.pslot + 1] = l;
+            }
+        }
+    }
+}
+
+// merges the partial (max, denominator, accumulator) triples of destinations that were split
+template <int NCH>
+__global__ __launch_bounds__(kBlock) void rel_attn_fwd_combine_kernel(FwdArgs a) {
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    const int n_splits = a.counts[1];
+    Lanes<NCH> L;
+    L.init(lane, a.D4);
+    const int voff = 4 * a.D4;
+    for (int sp = blockIdx.x * kWavesPerBlock + wave; sp < n_splits; sp += nwaves) {
+        const jmac_split_t s = a.splits[sp];
+        const int i = s.seg;
+        float M = -INFINITY;
+        for (int c = 0; c < s.nchunks; ++c) M = fmaxf(M, a.part_ml[2 * (s.pslot0 + c)]);
+        float lsum = 0.f;
+        float4 acc[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) acc[k] = f4zero();
+        for (int c = 0; c < s.nchunks; ++c) {
+            const int ps = s.pslot0 + c;
+            const float f = expf(a.part_ml[2 * ps] - M);
+            lsum += a.part_ml[2 * ps + 1] * f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if (L.valid[k] && !L.is_h[k]) acc[k] = fma4(ld4(a.part_acc + (int64_t)ps * voff + (L.coff[k] - voff)), f, acc[k]);
+        }
+        const int deg = a.rowptr[i + 1] - a.rowptr[i];
+        const float scale = lsum > 0.f ? sqrtf((float)deg) / lsum : 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (L.valid[k] && !L.is_h[k]) {
+                float4 o = mul4(acc[k], scale);
+                if (a.loop_rel >= 0) {
+                    float4 z = ld4(a.QZ + (int64_t)i * a.ldqz + L.coff[k]);
+                    float4 rz = ld4(a.RR + (int64_t)a.loop_rel * a.ldrr + L.coff[k]);
+                    o = add4(o, sub4(z, rz));
+                }
+                st4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff), mul4(o, a.out_scale));
+            }
+        }
+        if (lane == 0) {
+            a.seg_max[i] = M;
+            a.seg_den[i] = lsum;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs {
+    const float *P, *QZ, *RR, *a_att, *out, *seg_max, *seg_den, *G;
+    int64_t ldp, ldqz, ldrr, ldo, ldg, lddp, lddqz, lddrr;
+    const int32_t *rowptr, *col, *etype, *dst_of_slot;
+    const jmac_item_t* items;
+    const jmac_split_t* splits;
+    const int32_t* counts;
+    const int32_t* order;     // pass B / C: CSR slot of each entry
+    int32_t N, D4, loop_rel, nrel;
+    float slope, out_scale;
+    float *dP, *dQZ, *dRR;
+    float* da_part;           // [gridDim.x, d]
+    float* part;              // partial rows of split segments
+    float2* wds;              // [E] (w_e, ds_e)
+    unsigned char* bits;      // [E, 64] sign bits of h_e: lane's byte = nibble per h-role chunk
+    float sign;               // pass B: +1, pass C: -1
+    int32_t add_self;         // pass B: add g_j to the Z half
+};
+
+// Pass A: by destination.  MODE 0: float atomics into dQZ / dRR.  MODE 1: per-edge records.
+template <int NCH, int U, int MODE>
+__global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
+    constexpr int NCH_H = (NCH + 1) / 2;
+    __shared__ float4 red[kWavesPerBlock][NCH_H][64];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    const int n_items = a.counts[0];
+    Lanes<NCH> L;
+    L.init(lane, a.D4);
+    const int voff = 4 * a.D4;
+    const float kappa = a.out_scale;
+    float4 av[NCH];
+    float4 da[NCH_H];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) av[k] = (L.valid[k] && L.is_h[k]) ? ld4(a.a_att + L.coff[k]) : f4zero();
+#pragma unroll
+    for (int k = 0; k < NCH_H; ++k) da[k] = f4zero();
+
+    for (int it = blockIdx.x * kWavesPerBlock + wave; it < n_items; it += nwaves) {
+        const jmac_item_t item = a.items[it];
+        const int i = item.seg;
+        float4 pv[NCH], gv[NCH], accP[NCH_H];
+        float tpart = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            pv[k] = (L.valid[k] && L.is_h[k]) ? ld4(a.P + (int64_t)i * a.ldp + L.coff[k]) : f4zero();
+            gv[k] = f4zero();
+            if (L.valid[k] && !L.is_h[k]) {
+                gv[k] = mul4(ld4(a.G + (int64_t)i * a.ldg + (L.coff[k] - voff)), kappa);
+                // nb_i = out/kappa - (Z[i] - Rz[loop])
+                float4 nbv = mul4(ld4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff)), 1.f / kappa);
+                if (a.loop_rel >= 0) {
+                    float4 z = ld4(a.QZ + (int64_t)i * a.ldqz + L.coff[k]);
+                    float4 rz = ld4(a.RR + (int64_t)a.loop_rel * a.ldrr + L.coff[k]);
+                    nbv = sub4(nbv, sub4(z, rz));
+                }
+                tpart += dot4(gv[k], nbv);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NCH_H; ++k) accP[k] = f4zero();
+        const float t_i = wave_sum(tpart);
+        const float m_i = a.seg_max[i];
+        const float l_i = a.seg_den[i];
+        const float inv_l = l_i > 0.f ? 1.f / l_i : 0.f;
+        const float c_i = sqrtf((float)(a.rowptr[i + 1] - a.rowptr[i]));
+
+        for (int e0 = item.beg; e0 < item.end; e0 += 64) {
+            const int nb = min(64, item.end - e0);
+            int my_col = 0, my_typ = 0;
+            if (lane < nb) {
+                my_col = a.col[e0 + lane];
+                my_typ = a.etype[e0 + lane];
+            }
+            float my_w = 0.f, my_ds = 0.f;
+            for (int u0 = 0; u0 < nb; u0 += U) {
+                float4 df[U][NCH];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool ev = (u0 + u) < nb;
+                    if (ev) {
+                        const int j = bcast_i(my_col, u0 + u);
+                        const int t = bcast_i(my_typ, u0 + u);
+                        const float* qrow = a.QZ + (int64_t)j * a.ldqz;
+                        const float* rrow = a.RR + (int64_t)t * a.ldrr;
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k)
+                            df[u][k] = L.valid[k] ? sub4(ld4(qrow + L.coff[k]), ld4(rrow + L.coff[k])) : f4zero();
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) df[u][k] = f4zero();
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!((u0 + u) < nb)) continue;   // wave-uniform
+                    float4 hv[NCH_H];
+                    float spart = 0.f, upart = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) {
+                        if (k < NCH_H) {
+                            hv[k] = add4(pv[k], df[u][k]);
+                            spart += dot4(av[k], leaky4(hv[k], a.slope));
+                        }
+                        upart += dot4(gv[k], df[u][k]);   // gv is zero on h-role chunks
+                    }
+                    const float s = wave_sum(spart);
+                    const float uu = wave_sum(upart);
+                    const float alpha = expf(s - m_i) * inv_l;
+                    const float w = c_i * alpha;
+                    const float ds = w * uu - alpha * t_i;
+                    if (lane == u0 + u) {
+                        my_w = w;
+                        my_ds = ds;
+                    }
+                    unsigned mybits = 0u;
+                    float4 dh[NCH_H];
+#pragma unroll
+                    for (int k = 0; k < NCH_H; ++k) {
+                        const float4 h = hv[k];
+                        const float4 g = make_float4(h.x > 0.f ? 1.f : a.slope, h.y > 0.f ? 1.f : a.slope,
+                                                     h.z > 0.f ? 1.f : a.slope, h.w > 0.f ? 1.f : a.slope);
+                        dh[k] = make_float4(ds * av[k].x * g.x, ds * av[k].y * g.y, ds * av[k].z * g.z, ds * av[k].w * g.w);
+                        accP[k] = add4(accP[k], dh[k]);
+                        da[k] = fma4(leaky4(h, a.slope), ds, da[k]);
+                        if (MODE == 1)
+                            mybits |= ((h.x > 0.f ? 1u : 0u) | (h.y > 0.f ? 2u : 0u) | (h.z > 0.f ? 4u : 0u) |
+                                       (h.w > 0.f ? 8u : 0u)) << (4 * k);
+                    }
+                    if (MODE == 1) {
+                        a.bits[(int64_t)(e0 + u0 + u) * 64 + lane] = (unsigned char)mybits;
+                    } else {
+                        const int j = bcast_i(my_col, u0 + u);
+                        const int t = bcast_i(my_typ, u0 + u);
+                        float* qd = a.dQZ + (int64_t)j * a.lddqz;
+                        float* rd = a.dRR + (int64_t)t * a.lddrr;
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) {
+                            if (!L.valid[k]) continue;
+                            float4 v = mul4(gv[k], w);
+                            if (k < NCH_H) v = L.is_h[k] ? dh[k] : v;
+                            atomicAdd(qd + L.coff[k] + 0, v.x);
+                            atomicAdd(qd + L.coff[k] + 1, v.y);
+                            atomicAdd(qd + L.coff[k] + 2, v.z);
+                            atomicAdd(qd + L.coff[k] + 3, v.w);
+                            atomicAdd(rd + L.coff[k] + 0, -v.x);
+                            atomicAdd(rd + L.coff[k] + 1, -v.y);
+                            atomicAdd(rd + L.coff[k] + 2, -v.z);
+                            atomicAdd(rd + L.coff[k] + 3, -v.w);
+                        }
+                    }
+                }
+            }
+            if (MODE == 1 && lane < nb) a.wds[e0 + lane] = make_float2(my_w, my_ds);
+        }
+        // dP row (h-role chunks)
+        float* prow = item.pslot < 0 ? a.dP + (int64_t)i * a.lddp : a.part + (int64_t)item.pslot * voff;
+#pragma unroll
+        for (int k = 0; k < NCH_H; ++k)
+            if (L.valid[k] && L.is_h[k]) st4(prow + L.coff[k], accP[k]);
+    }
+    // block-level reduction of the a_att gradient, one partial row per block
+#pragma unroll
+    for (int k = 0; k < NCH_H; ++k) red[wave][k][lane] = da[k];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < NCH_H; ++k) {
+            if (L.valid[k] && L.is_h[k]) {
+                float4 s = red[0][k][lane];
+#pragma unroll
+                for (int w = 1; w < kWavesPerBlock; ++w) s = add4(s, red[w][k][lane]);
+                st4(a.da_part + (int64_t)blockIdx.x * voff + L.coff[k], s);
+            }
+        }
+    }
+}
+
+// Pass B (by source, sign=+1) and pass C (by relation, sign=-1): sum the per-edge records.
+//   row[h-half] = sign * sum_e ds_e * a (.) lrelu'(h_e)         (sign bits from pass A)
+//   row[v-half] = sign * sum_e w_e * g_{dst(e)}  (+ g_j for the fused self loop in pass B)
+template <int NCH, int U>
+__global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs a, float* __restrict__ outp, int64_t ldout) {
+    constexpr int NCH_H = (NCH + 1) / 2;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    const int n_items = a.counts[0];
+    Lanes<NCH> L;
+    L.init(lane, a.D4);
+    const int voff = 4 * a.D4;
+    const float kappa = a.out_scale;
+    float4 av[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) av[k] = (L.valid[k] && L.is_h[k]) ? ld4(a.a_att + L.coff[k]) : f4zero();
+
+    for (int it = blockIdx.x * kWavesPerBlock + wave; it < n_items; it += nwaves) {
+        const jmac_item_t item = a.items[it];
+        const int seg = item.seg;
+        float4 acc[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) acc[k] = f4zero();
+        for (int x0 = item.beg; x0 < item.end; x0 += 64) {
+            const int nb = min(64, item.end - x0);
+            int my_slot = 0, my_dst = 0;
+            float2 my_wd = make_float2(0.f, 0.f);
+            if (lane < nb) {
+                my_slot = a.order[x0 + lane];
+                my_dst = a.dst_of_slot[my_slot];
+                my_wd = a.wds[my_slot];
+            }
+            for (int u0 = 0; u0 < nb; u0 += U) {
+                float4 gq[U][NCH];
+                unsigned bw[U];
+                float w[U], ds[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool ev = (u0 + u) < nb;
+                    w[u] = 0.f;
+                    ds[u] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) gq[u][k] = f4zero();
+                    bw[u] = 0u;
+                    if (ev) {
+                        const int slot = bcast_i(my_slot, u0 + u);
+                        const int i = bcast_i(my_dst, u0 + u);
+                        w[u] = bcast_f(my_wd.x, u0 + u);
+                        ds[u] = bcast_f(my_wd.y, u0 + u);
+                        const float* grow = a.G + (int64_t)i * a.ldg;
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k)
+                            if (L.valid[k] && !L.is_h[k]) gq[u][k] = ld4(grow + (L.coff[k] - voff));
+                        bw[u] = a.bits[(int64_t)slot * 64 + lane];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float wk = w[u] * kappa;
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) {
+                        if (k < NCH_H && L.is_h[k]) {
+                            const unsigned nib = bw[u] >> (4 * k);
+                            const float g0 = (nib & 1u) ? 1.f : a.slope;
+                            const float g1 = (nib & 2u) ? 1.f : a.slope;
+                            const float g2 = (nib & 4u) ? 1.f : a.slope;
+                            const float g3 = (nib & 8u) ? 1.f : a.slope;
+                            acc[k].x = fmaf(ds[u] * av[k].x, g0, acc[k].x);
+                            acc[k].y = fmaf(ds[u] * av[k].y, g1, acc[k].y);
+                            acc[k].z = fmaf(ds[u] * av[k].z, g2, acc[k].z);
+                            acc[k].w = fmaf(ds[u] * av[k].w, g3, acc[k].w);
+                        } else {
+                            acc[k] = fma4(gq[u][k], wk, acc[k]);
+                        }
+                    }
+                }
+            }
+        }
+        const bool direct = item.pslot < 0;
+        // the fused self loop contributes g_j to dZ[j]; it is added once, by the finalising item or
+        // (for split segments) by the combine pass.
+        float* row = direct ? outp + (int64_t)seg * ldout : a.part + (int64_t)item.pslot * (2 * voff);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (!L.valid[k]) continue;
+            float4 v = mul4(acc[k], a.sign);
+            if (direct && a.add_self && !L.is_h[k])
+                v = fma4(ld4(a.G + (int64_t)seg * a.ldg + (L.coff[k] - voff)), kappa, v);
+            st4(row + L.coff[k], v);
+        }
+    }
+}
+
+// plain sum of the partial rows of split segments (width = 4*W4 floats); optional self term (pass B)
+__global__ __launch_bounds__(kBlock) void sum_parts_kernel(const jmac_split_t* __restrict__ splits,
+                                                           const int32_t* __restrict__ counts,
+                                                           const float* __restrict__ part, int W4, float sign,
+                                                           float* __restrict__ outp, int64_t ldout,
+                                                           const float* __restrict__ G, int64_t ldg, int D4, float kappa,
+                                                           int add_self) {
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    const int n_splits = counts[1];
+    for (int sp = blockIdx.x * kWavesPerBlock + wave; sp < n_splits; sp += nwaves) {
+        const jmac_split_t s = splits[sp];
+        for (int c4 = lane; c4 < W4; c4 += 64) {
+            float4 acc = f4zero();
+            for (int c = 0; c < s.nchunks; ++c) acc = add4(acc, ld4(part + ((int64_t)(s.pslot0 + c) * W4 + c4) * 4));
+            acc = mul4(acc, sign);
+            if (add_self && c4 >= D4) acc = fma4(ld4(G + (int64_t)s.seg * ldg + (c4 - D4) * 4), kappa, acc);
+            st4(outp + (int64_t)s.seg * ldout + c4 * 4, acc);
+        }
+    }
+}
+
+// column sums of a [R, 4*W4] matrix in two deterministic steps: per-block partials, then one block.
+__global__ __launch_bounds__(kBlock) void colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int64_t R,
+                                                                int W4, float* __restrict__ partial) {
+    // thread t owns float4 column c4 = t % W4s ... simple strided layout: each thread loops rows
+    const int tid = threadIdx.x;
+    for (int c4 = tid; c4 < W4; c4 += kBlock) {
+        float4 acc = f4zero();
+        for (int64_t r = blockIdx.x; r < R; r += gridDim.x) acc = add4(acc, ld4(X + r * ldx + c4 * 4));
+        st4(partial + ((int64_t)blockIdx.x * W4 + c4) * 4, acc);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void colsum_final_kernel(const float* __restrict__ partial, int nparts, int W4,
+                                                              float scale, float* __restrict__ outp) {
+    const int tid = blockIdx.x * kBlock + threadIdx.x;
+    if (tid < W4) {
+        float4 acc = f4zero();
+        for (int p = 0; p < nparts; ++p) acc = add4(acc, ld4(partial + ((int64_t)p * W4 + tid) * 4));
+        st4(outp + tid * 4, mul4(acc, scale));
+    }
+}
+
+// atomic mode: dQZ starts at [0 | kappa*G[i]] (the fused self loop's dZ term) or at zero
+__global__ void init_dqz_kernel(float* __restrict__ dQZ, int64_t lddqz, int64_t N, int64_t d, const float* __restrict__ G,
+                                int64_t ldg, float kappa, int add_self) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N * 2 * d) {
+        int64_t r = i / (2 * d), c = i % (2 * d);
+        dQZ[r * lddqz + c] = (add_self && c >= d) ? kappa * G[r * ldg + (c - d)] : 0.f;
+    }
+}
+
+__global__ void fill_rows_kernel(float* __restrict__ p, int64_t rows, int64_t width, int64_t ld, float v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * width) p[(i / width) * ld + (i % width)] = v;
+}
+
+inline int check_dims(int64_t d, int64_t ld0, int64_t ld1, int64_t ld2) {
+    if (d <= 0 || d % 4 != 0 || d > 512) return JMAC_EDIM;
+    if (ld0 % 4 || ld1 % 4 || ld2 % 4) return JMAC_EDIM;
+    return 0;
+}
+
+inline unsigned persist_grid(int64_t n_items_max) {
+    int64_t need = (n_items_max + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (need < 1) need = 1;
+    return (unsigned)(need < kPersistBlocks ? need : kPersistBlocks);
+}
+
+#define JMAC_DISPATCH_NCH(nch, ...)                       \
+    switch (nch) {                                        \
+        case 1: { constexpr int NCH = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int NCH = 2; __VA_ARGS__; } break; \
+        case 3: { constexpr int NCH = 3; __VA_ARGS__; } break; \
+        default: { constexpr int NCH = 4; __VA_ARGS__; } break; \
+    }
+
+}  // namespace
+
+extern "C" {
+
+size_t jmac_rel_attn_fwd_workspace_bytes(int64_t n_parts_max, int64_t d) {
+    if (n_parts_max < 0) n_parts_max = 0;
+    return align_up((size_t)n_parts_max * 8) + align_up((size_t)n_parts_max * d * 4) + 256;
+}
+
+int jmac_rel_attn_aggregate_fwd_f32(const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR,
+                                    int64_t ldrr, const float* a_att, const int32_t* rowptr, const int32_t* col,
+                                    const int32_t* etype, const jmac_item_t* items, const jmac_split_t* splits,
+                                    const int32_t* counts, int64_t n_items_max, int64_t n_splits_max,
+                                    int64_t n_parts_max, int64_t N, int64_t d, float slope, int32_t loop_rel, float out_scale, float* out, int64_t ldo,
+                                    float* seg_max, float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    if (N < 0 || n_items_max < 0 || n_splits_max < 0) return JMAC_EINVAL;
+    if (N == 0) return JMAC_OK;
+    if (!P || !QZ || !RR || !a_att || !rowptr || !items || !counts || !out || !seg_max || !seg_den) return JMAC_EINVAL;
+    if (int rc = check_dims(d, ldp, ldqz, ldrr)) return rc;
+    if (ldo % 4) return JMAC_EDIM;
+    if (N >= INT32_MAX) return JMAC_ERANGE;
+    FwdArgs a;
+    a.P = P; a.QZ = QZ; a.RR = RR; a.a_att = a_att;
+    a.ldp = ldp; a.ldqz = ldqz; a.ldrr = ldrr; a.ldo = ldo;
+    a.rowptr = rowptr; a.col = col; a.etype = etype;
+    a.items = items; a.splits = splits; a.counts = counts;
+    a.N = (int32_t)N; a.D4 = (int32_t)(d / 4); a.loop_rel = loop_rel;
+    a.slope = slope; a.out_scale = out_scale;
+    a.out = out; a.seg_max = seg_max; a.seg_den = seg_den;
+    // ws layout: [part_ml: 2 floats per slot][part_acc: d floats per slot]
+    if (n_parts_max < 0) n_parts_max = 0;
+    if (n_parts_max > 0 && (!ws || ws_bytes < jmac_rel_attn_fwd_workspace_bytes(n_parts_max, d))) return JMAC_EWORKSPACE;
+    a.part_ml = (float*)ws;
+    a.part_acc = ws ? (float*)((char*)ws + align_up((size_t)n_parts_max * 8)) : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = (int)((2 * (d / 4) + 63) / 64);
+    const unsigned grid = persist_grid(n_items_max);
+    JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 4>), dim3(grid), dim3(kBlock), 0, st, a));
+    if (n_splits_max > 0) {
+        const unsigned g2 = persist_grid(n_splits_max);
+        JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_fwd_combine_kernel<NCH>), dim3(g2), dim3(kBlock), 0, st, a));
+    }
+    return (int)hipGetLastError();
+}
+
+// ---- backward workspace carving (shared by the size query and the launcher) ----
+struct BwdWs {
+    size_t da_part, colsum_part, part_dst, part_src, part_rel, wds, bits, total;
+};
+
+static BwdWs bwd_ws_layout(int64_t E, int64_t d, int64_t pd, int64_t ps, int64_t pr, int32_t mode) {
+    BwdWs w;
+    size_t off = 0;
+    w.da_part = off;     off += align_up((size_t)kPersistBlocks * d * 4);
+    w.colsum_part = off; off += align_up((size_t)kPersistBlocks * d * 4);
+    w.part_dst = off;    off += align_up((size_t)(pd > 0 ? pd : 0) * d * 4);
+    w.part_src = off;    off += mode ? align_up((size_t)(ps > 0 ? ps : 0) * 2 * d * 4) : 0;
+    w.part_rel = off;    off += mode ? align_up((size_t)(pr > 0 ? pr : 0) * 2 * d * 4) : 0;
+    w.wds = off;         off += mode ? align_up((size_t)E * 8) : 0;
+    w.bits = off;        off += mode ? align_up((size_t)E * 64) : 0;
+    w.total = off + 256;
+    return w;
+}
+
+size_t jmac_rel_attn_bwd_workspace_bytes(int64_t N, int64_t E, int64_t nrel, int64_t d, int64_t n_parts_max_dst,
+                                         int64_t n_parts_max_src, int64_t n_parts_max_rel, int32_t mode) {
+    (void)N; (void)nrel;
+    if (d <= 0) return 0;
+    return bwd_ws_layout(E < 0 ? 0 : E, d, n_parts_max_dst, n_parts_max_src, n_parts_max_rel, mode).total;
+}
+
+int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR,
+                                    int64_t ldrr, const float* a_att, const int32_t* col, const int32_t* etype,
+                                    const int32_t* dst_of_slot, const jmac_view_t* by_dst, const jmac_view_t* by_src,
+                                    const jmac_view_t* by_rel, int64_t N, int64_t E, int64_t nrel, int64_t d,
+                                    float slope, int32_t loop_rel, float out_scale, const float* out, int64_t ldo,
+                                    const float* seg_max, const float* seg_den, const float* G, int64_t ldg, float* dP,
+                                    int64_t lddp, float* dQZ, int64_t lddqz, float* dRR, int64_t lddrr, float* da,
+                                    int32_t mode, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    if (N < 0 || E < 0 || nrel <= 0) return JMAC_EINVAL;
+    if (!P || !QZ || !RR || !a_att || !by_dst || !out || !seg_max || !seg_den || !G || !dP || !dQZ || !dRR || !da)
+        return JMAC_EINVAL;
+    if (mode != 0 && (!by_src || !by_rel || !dst_of_slot)) return JMAC_EINVAL;
+    if (int rc = check_dims(d, ldp, ldqz, ldrr)) return rc;
+    if (ldo % 4 || ldg % 4 || lddp % 4 || lddqz % 4 || lddrr % 4) return JMAC_EDIM;
+    if (out_scale == 0.f) return JMAC_EINVAL;
+    const BwdWs w = bwd_ws_layout(E, d, by_dst->n_parts_max, mode ? by_src->n_parts_max : 0,
+                                  mode ? by_rel->n_parts_max : 0, mode);
+    if (!ws || ws_bytes < w.total) return JMAC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* wsb = (char*)ws;
+    const int D4 = (int)(d / 4);
+    const int nch = (2 * D4 + 63) / 64;
+
+    BwdArgs a;
+    a.P = P; a.QZ = QZ; a.RR = RR; a.a_att = a_att; a.out = out; a.seg_max = seg_max; a.seg_den = seg_den; a.G = G;
+    a.ldp = ldp; a.ldqz = ldqz; a.ldrr = ldrr; a.ldo = ldo; a.ldg = ldg; a.lddp = lddp; a.lddqz = lddqz; a.lddrr = lddrr;
+    a.rowptr = by_dst->ptr; a.col = col; a.etype = etype; a.dst_of_slot = dst_of_slot;
+    a.items = by_dst->items; a.splits = by_dst->splits; a.counts = by_dst->counts; a.order = nullptr;
+    a.N = (int32_t)N; a.D4 = D4; a.loop_rel = loop_rel; a.nrel = (int32_t)nrel;
+    a.slope = slope; a.out_scale = out_scale;
+    a.dP = dP; a.dQZ = dQZ; a.dRR = dRR;
+    a.da_part = (float*)(wsb + w.da_part);
+    a.part = (float*)(wsb + w.part_dst);
+    a.wds = (float2*)(wsb + w.wds);
+    a.bits = (unsigned char*)(wsb + w.bits);
+    a.sign = 1.f; a.add_self = 0;
+
+    const int T = 256;
+    const unsigned gridA = persist_grid(by_dst->n_items_max);
+    if (mode == 0) {
+        // dQZ / dRR are accumulated with atomics: initialise them (dZ half of dQZ starts at the self term)
+        hipLaunchKernelGGL(init_dqz_kernel, dim3((unsigned)((N * 2 * d + T - 1) / T)), dim3(T), 0, st, dQZ, lddqz, N, d, G, ldg,
+                           out_scale, loop_rel >= 0 ? 1 : 0);
+        hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((nrel * 2 * d + T - 1) / T)), dim3(T), 0, st, dRR, nrel, 2 * d, lddrr, 0.f);
+        JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 0>), dim3(gridA), dim3(kBlock), 0, st, a));
+    } else {
+        JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 1>), dim3(gridA), dim3(kBlock), 0, st, a));
+    }
+    // a_att gradient: deterministic reduction of the per-block partial rows
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((D4 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a.da_part, (int)gridA, D4,
+                       1.f, da);
+    if (by_dst->n_splits_max > 0)
+        hipLaunchKernelGGL(sum_parts_kernel, dim3(persist_grid(by_dst->n_splits_max)), dim3(kBlock), 0, st, by_dst->splits,
+                           by_dst->counts, a.part, D4, 1.f, dP, lddp, nullptr, (int64_t)0, 0, 0.f, 0);
+
+    // column sum of G for the fused self loop:  dRz[loop] -= kappa * sum_i G[i]
+    float* colsum_part = (float*)(wsb + w.colsum_part);
+    unsigned gcs = 0;
+    if (loop_rel >= 0 && N > 0) {
+        gcs = (unsigned)(N < 1024 ? N : 1024);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(gcs), dim3(kBlock), 0, st, G, ldg, N, D4, colsum_part);
+    }
+
+    if (mode != 0) {
+        BwdArgs b = a;
+        b.items = by_src->items; b.splits = by_src->splits; b.counts = by_src->counts; b.order = by_src->order;
+        b.part = (float*)(wsb + w.part_src);
+        b.sign = 1.f; b.add_self = loop_rel >= 0 ? 1 : 0;
+        JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_bwd_gather_kernel<NCH, 4>), dim3(persist_grid(by_src->n_items_max)),
+                                                  dim3(kBlock), 0, st, b, dQZ, lddqz));
+        if (by_src->n_splits_max > 0)
+            hipLaunchKernelGGL(sum_parts_kernel, dim3(persist_grid(by_src->n_splits_max)), dim3(kBlock), 0, st, by_src->splits,
+                               by_src->counts, b.part, 2 * D4, 1.f, dQZ, lddqz, G, ldg, D4, out_scale, b.add_self);
+        BwdArgs c = a;
+        c.items = by_rel->items; c.splits = by_rel->splits; c.counts = by_rel->counts; c.order = by_rel->order;
+        c.part = (float*)(wsb + w.part_rel);
+        c.sign = -1.f; c.add_self = 0;
+        JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_bwd_gather_kernel<NCH, 4>), dim3(persist_grid(by_rel->n_items_max)),
+                                                  dim3(kBlock), 0, st, c, dRR, lddrr));
+        if (by_rel->n_splits_max > 0)
+            hipLaunchKernelGGL(sum_parts_kernel, dim3(persist_grid(by_rel->n_splits_max)), dim3(kBlock), 0, st, by_rel->splits,
+                               by_rel->counts, c.part, 2 * D4, -1.f, dRR, lddrr, nullptr, (int64_t)0, 0, 0.f, 0);
+    }
+    if (loop_rel >= 0 && N > 0) {
+        // pass C wrote zeros (mode 1) / the fill wrote zeros (mode 0) into dRz[loop]: overwrite it
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((D4 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, colsum_part, (int)gcs, D4,
+                           -out_scale, dRR + (int64_t)loop_rel * lddrr + d);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,251 @@
+// graph.hip -- graph ingest for the JMAC hot path on gfx950.
+//
+// COO edge lists (the reference's edge_index [2,E] / edge_type [E] int64, train.py:116-135 and
+// src/utils.py:112-149) -> CSR by aggregation destination, plus the by-source / by-relation groupings
+// and the wave-sized work schedules the aggregation kernels run over.  The degree the reference gets
+// from scatter_add (src/jmac_model.py:103-108) is rowptr[i+1]-rowptr[i] here.
+//
+// Sorting is rocPRIM's device radix sort (stable), so the edge order inside a row -- and therefore
+// the floating-point summation order of every kernel downstream -- is fixed by the input order.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "common.h"
+
+namespace {
+
+__global__ void coo_keys_kernel(const int64_t* __restrict__ edge_index, int64_t E, int32_t* __restrict__ keys,
+                                int32_t* __restrict__ iota) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) {
+        keys[e] = (int32_t)edge_index[e];   // row 0 = destination
+        iota[e] = (int32_t)e;
+    }
+}
+
+__global__ void iota_kernel(int64_t E, int32_t* __restrict__ iota) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) iota[e] = (int32_t)e;
+}
+
+// ptr[r] = first position whose key is >= r, for r in [0, S]; keys sorted ascending.
+__global__ void ptr_from_sorted_kernel(const int32_t* __restrict__ keys, int64_t E, int64_t S,
+                                       int32_t* __restrict__ ptr) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (E == 0) {
+        for (int64_t r = e; r <= S; r += (int64_t)gridDim.x * blockDim.x) ptr[r] = 0;
+        return;
+    }
+    if (e >= E) return;
+    int64_t k0 = (e == 0) ? -1 : keys[e - 1];
+    int64_t k1 = keys[e];
+    for (int64_t r = k0 + 1; r <= k1; ++r) ptr[r] = (int32_t)e;
+    if (e == E - 1)
+        for (int64_t r = k1 + 1; r <= S; ++r) ptr[r] = (int32_t)E;
+}
+
+__global__ void csr_gather_kernel(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ edge_type,
+                                  const int32_t* __restrict__ perm, int64_t E, int32_t* __restrict__ col,
+                                  int32_t* __restrict__ etype) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < E) {
+        int64_t e = perm[s];
+        col[s] = (int32_t)edge_index[E + e];   // row 1 = message source
+        etype[s] = (int32_t)edge_type[e];
+    }
+}
+
+// per segment: number of items, number of partial slots, split flag
+__global__ void seg_counts_kernel(const int32_t* __restrict__ ptr, int64_t S, int32_t chunk,
+                                  int32_t* __restrict__ nitem, int32_t* __restrict__ npart,
+                                  int32_t* __restrict__ nsplit) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < S) {
+        int32_t len = ptr[s + 1] - ptr[s];
+        int32_t nch = len <= chunk ? 1 : (len + chunk - 1) / chunk;
+        nitem[s] = nch;
+        npart[s] = nch > 1 ? nch : 0;
+        nsplit[s] = nch > 1 ? 1 : 0;
+    }
+}
+
+__global__ void items_fill_kernel(const int32_t* __restrict__ ptr, int64_t S, int32_t chunk,
+                                  const int32_t* __restrict__ item_off, const int32_t* __restrict__ part_off,
+                                  const int32_t* __restrict__ split_off, jmac_item_t* __restrict__ items,
+                                  jmac_split_t* __restrict__ splits, int32_t* __restrict__ counts) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    int32_t beg = ptr[s], end = ptr[s + 1];
+    int32_t len = end - beg;
+    int32_t nch = len <= chunk ? 1 : (len + chunk - 1) / chunk;
+    int32_t io = item_off[s];
+    if (nch == 1) {
+        items[io] = jmac_item_t{(int32_t)s, beg, end, -1};
+    } else {
+        int32_t po = part_off[s];
+        for (int32_t c = 0; c < nch; ++c) {
+            int32_t b = beg + c * chunk;
+            int32_t e = b + chunk < end ? b + chunk : end;
+            items[io + c] = jmac_item_t{(int32_t)s, b, e, po + c};
+        }
+        splits[split_off[s]] = jmac_split_t{(int32_t)s, po, nch, 0};
+    }
+    if (s == S - 1) {
+        counts[0] = io + nch;
+        counts[1] = split_off[s] + (nch > 1 ? 1 : 0);
+        counts[2] = part_off[s] + (nch > 1 ? nch : 0);
+        counts[3] = 0;
+    }
+}
+
+__global__ void zero_counts_kernel(int32_t* counts) {
+    if (threadIdx.x < 4) counts[threadIdx.x] = 0;
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+size_t sort_temp_bytes(int64_t E) {
+    size_t bytes = 0;
+    hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, int32_t*, int32_t*, int32_t*, int32_t*>(
+        nullptr, bytes, nullptr, nullptr, nullptr, nullptr, (size_t)E, 0, 32, 0);
+    if (e != hipSuccess || bytes == 0) bytes = (size_t)E * 16 + (8u << 20);   // no device: generous bound
+    return align_up(bytes);
+}
+
+size_t scan_temp_bytes(int64_t S) {
+    size_t bytes = 0;
+    hipError_t e = rocprim::exclusive_scan<rocprim::default_config, int32_t*, int32_t*, int32_t, rocprim::plus<int32_t>>(
+        nullptr, bytes, nullptr, nullptr, 0, (size_t)S, rocprim::plus<int32_t>(), 0);
+    if (e != hipSuccess || bytes == 0) bytes = (size_t)S * 4 + (1u << 20);
+    return align_up(bytes);
+}
+
+// stable sort of (keys, iota) -> (keys_sorted, order)
+int sort_by_key(int32_t* keys_in, int32_t* keys_out, int32_t* vals_in, int32_t* vals_out, int64_t E, int64_t S,
+                void* tmp, size_t tmp_bytes, hipStream_t st) {
+    if (E == 0) return 0;
+    size_t need = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, (size_t)E, 0, 32, st);
+    if (e != hipSuccess) return (int)e;
+    if (need > tmp_bytes) return JMAC_EWORKSPACE;
+    unsigned end_bit = 1;
+    while (end_bit < 32 && ((int64_t)1 << end_bit) < S) ++end_bit;
+    e = rocprim::radix_sort_pairs(tmp, need, keys_in, keys_out, vals_in, vals_out, (size_t)E, 0, end_bit, st);
+    return (int)e;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t jmac_graph_workspace_bytes(int64_t E, int64_t S) {
+    if (E < 0) E = 0;
+    if (S < 0) S = 0;
+    size_t a = 3 * align_up((size_t)E * 4) + sort_temp_bytes(E);
+    size_t b = 6 * align_up((size_t)(S + 1) * 4) + scan_temp_bytes(S + 1);
+    return (a > b ? a : b) + 1024;
+}
+
+int jmac_csr_build(const int64_t* edge_index, const int64_t* edge_type, int64_t E, int64_t N, int32_t* rowptr,
+                   int32_t* col, int32_t* etype, int32_t* perm, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    if (E < 0 || N < 0 || !rowptr || (E > 0 && (!edge_index || !edge_type || !col || !etype || !perm))) return JMAC_EINVAL;
+    if (E >= INT32_MAX || N >= INT32_MAX) return JMAC_ERANGE;
+    hipStream_t st = (hipStream_t)stream;
+    const int T = 256;
+    if (E == 0) {
+        hipLaunchKernelGGL(ptr_from_sorted_kernel, dim3((unsigned)((N + 1 + T - 1) / T)), dim3(T), 0, st, nullptr, 0, N, rowptr);
+        return (int)hipGetLastError();
+    }
+    size_t arr = align_up((size_t)E * 4);
+    if (!ws || ws_bytes < 3 * arr) return JMAC_EWORKSPACE;
+    char* w = (char*)ws;
+    int32_t* keys = (int32_t*)w;
+    int32_t* keys_sorted = (int32_t*)(w + arr);
+    int32_t* iota = (int32_t*)(w + 2 * arr);
+    void* tmp = w + 3 * arr;
+    unsigned nb = (unsigned)((E + T - 1) / T);
+    hipLaunchKernelGGL(coo_keys_kernel, dim3(nb), dim3(T), 0, st, edge_index, E, keys, iota);
+    int rc = sort_by_key(keys, keys_sorted, iota, perm, E, N, tmp, ws_bytes - 3 * arr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ptr_from_sorted_kernel, dim3(nb), dim3(T), 0, st, keys_sorted, E, N, rowptr);
+    hipLaunchKernelGGL(csr_gather_kernel, dim3(nb), dim3(T), 0, st, edge_index, edge_type, perm, E, col, etype);
+    return (int)hipGetLastError();
+}
+
+int jmac_group_build(const int32_t* keys, int64_t E, int64_t S, int32_t* ptr, int32_t* order, void* ws,
+                     size_t ws_bytes, jmac_stream_t stream) {
+    if (E < 0 || S < 0 || !ptr || (E > 0 && (!keys || !order))) return JMAC_EINVAL;
+    if (E >= INT32_MAX || S >= INT32_MAX) return JMAC_ERANGE;
+    hipStream_t st = (hipStream_t)stream;
+    const int T = 256;
+    if (E == 0) {
+        hipLaunchKernelGGL(ptr_from_sorted_kernel, dim3((unsigned)((S + 1 + T - 1) / T)), dim3(T), 0, st, nullptr, 0, S, ptr);
+        return (int)hipGetLastError();
+    }
+    size_t arr = align_up((size_t)E * 4);
+    if (!ws || ws_bytes < 2 * arr) return JMAC_EWORKSPACE;
+    char* w = (char*)ws;
+    int32_t* keys_sorted = (int32_t*)w;
+    int32_t* iota = (int32_t*)(w + arr);
+    void* tmp = w + 2 * arr;
+    unsigned nb = (unsigned)((E + T - 1) / T);
+    hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(T), 0, st, E, iota);
+    int rc = sort_by_key(const_cast<int32_t*>(keys), keys_sorted, iota, order, E, S, tmp, ws_bytes - 2 * arr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ptr_from_sorted_kernel, dim3(nb), dim3(T), 0, st, keys_sorted, E, S, ptr);
+    return (int)hipGetLastError();
+}
+
+int64_t jmac_items_max(int64_t S, int64_t E, int32_t chunk) {
+    if (chunk < 1) chunk = 1;
+    return S + E / chunk + 1;
+}
+int64_t jmac_splits_max(int64_t E, int32_t chunk) {
+    if (chunk < 1) chunk = 1;
+    return E / chunk + 1;
+}
+int64_t jmac_parts_max(int64_t E, int32_t chunk) {
+    if (chunk < 1) chunk = 1;
+    return 2 * (E / chunk) + 2;
+}
+
+int jmac_items_build(const int32_t* ptr, int64_t S, int32_t chunk, jmac_item_t* items, jmac_split_t* splits,
+                     int32_t* counts, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    if (S < 0 || chunk < 1 || !counts || (S > 0 && (!ptr || !items || !splits))) return JMAC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (S == 0) {
+        hipLaunchKernelGGL(zero_counts_kernel, dim3(1), dim3(64), 0, st, counts);
+        return (int)hipGetLastError();
+    }
+    size_t arr = align_up((size_t)S * 4);
+    if (!ws || ws_bytes < 6 * arr) return JMAC_EWORKSPACE;
+    char* w = (char*)ws;
+    int32_t* nitem = (int32_t*)w;
+    int32_t* npart = (int32_t*)(w + arr);
+    int32_t* nsplit = (int32_t*)(w + 2 * arr);
+    int32_t* item_off = (int32_t*)(w + 3 * arr);
+    int32_t* part_off = (int32_t*)(w + 4 * arr);
+    int32_t* split_off = (int32_t*)(w + 5 * arr);
+    void* tmp = w + 6 * arr;
+    size_t tmp_bytes = ws_bytes - 6 * arr;
+    const int T = 256;
+    unsigned nb = (unsigned)((S + T - 1) / T);
+    hipLaunchKernelGGL(seg_counts_kernel, dim3(nb), dim3(T), 0, st, ptr, S, chunk, nitem, npart, nsplit);
+    size_t need = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, need, nitem, item_off, 0, (size_t)S, rocprim::plus<int32_t>(), st);
+    if (e != hipSuccess) return (int)e;
+    if (need > tmp_bytes) return JMAC_EWORKSPACE;
+    e = rocprim::exclusive_scan(tmp, need, nitem, item_off, 0, (size_t)S, rocprim::plus<int32_t>(), st);
+    if (e != hipSuccess) return (int)e;
+    e = rocprim::exclusive_scan(tmp, need, npart, part_off, 0, (size_t)S, rocprim::plus<int32_t>(), st);
+    if (e != hipSuccess) return (int)e;
+    e = rocprim::exclusive_scan(tmp, need, nsplit, split_off, 0, (size_t)S, rocprim::plus<int32_t>(), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(items_fill_kernel, dim3(nb), dim3(T), 0, st, ptr, S, chunk, item_off, part_off, split_off, items,
+                       splits, counts);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

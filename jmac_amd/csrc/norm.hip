@@ -1,0 +1,290 @@
+// norm.hip -- BatchNorm1d + tanh over [N,d] for gfx950 (replaces self.layer_act(self.bn(.)),
+// src/jmac_model.py:52; nn.BatchNorm1d semantics: biased batch variance for normalisation, unbiased
+// for the running estimate, eps inside the sqrt).
+//
+// HBM-bound streaming passes with 16 B per lane.  Column statistics use sums shifted by row 0 of the
+// column (single pass, no catastrophic cancellation), reduced deterministically: per-block partial
+// rows -> one finalising block.  No atomics.
+#include "common.h"
+
+using namespace jmac;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kStatBlocks = 1024;
+
+// partial[b][0][c] = sum_r (x[r][c]-K[c]),  partial[b][1][c] = sum_r (x[r][c]-K[c])^2, K = x[0][:]
+// rows are dealt to blocks round-robin in groups of RPB = kBlock / D4 rows.
+__global__ __launch_bounds__(kBlock) void col_stats_partial_kernel(const float* __restrict__ x, int64_t ldx, int64_t N,
+                                                                   int D4, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* red = reinterpret_cast<float4*>(smem);   // [2][rpb][D4]
+    const int rpb = kBlock / D4 > 0 ? kBlock / D4 : 1;
+    const int tid = threadIdx.x;
+    // when D4 > kBlock a thread covers several column chunks
+    for (int cbase = 0; cbase < D4; cbase += kBlock) {
+        const int rsub = D4 >= kBlock ? 0 : tid / D4;
+        const int c4 = D4 >= kBlock ? cbase + tid : tid % D4;
+        const bool active = (D4 >= kBlock ? c4 < D4 : tid < rpb * D4);
+        float4 s1 = f4zero(), s2 = f4zero();
+        if (active) {
+            const float4 K = ld4(x + c4 * 4);
+            for (int64_t r = (int64_t)blockIdx.x * rpb + rsub; r < N; r += (int64_t)gridDim.x * rpb) {
+                float4 v = ld4(x + r * ldx + c4 * 4);
+                v.x -= K.x; v.y -= K.y; v.z -= K.z; v.w -= K.w;
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+            }
+        }
+        if (D4 >= kBlock) {
+            if (active) {
+                st4(partial + ((int64_t)blockIdx.x * 2 + 0) * D4 * 4 + c4 * 4, s1);
+                st4(partial + ((int64_t)blockIdx.x * 2 + 1) * D4 * 4 + c4 * 4, s2);
+            }
+        } else {
+            if (active) {
+                red[(0 * rpb + rsub) * D4 + c4] = s1;
+                red[(1 * rpb + rsub) * D4 + c4] = s2;
+            }
+            __syncthreads();
+            if (tid < D4) {
+                float4 a1 = red[tid], a2 = red[rpb * D4 + tid];
+                for (int q = 1; q < rpb; ++q) {
+                    float4 b1 = red[q * D4 + tid], b2 = red[(rpb + q) * D4 + tid];
+                    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+                    a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
+                }
+                st4(partial + ((int64_t)blockIdx.x * 2 + 0) * D4 * 4 + tid * 4, a1);
+                st4(partial + ((int64_t)blockIdx.x * 2 + 1) * D4 * 4 + tid * 4, a2);
+            }
+            break;
+        }
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts, const float* __restrict__ x, int64_t N,
+                                   int d, float eps, float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = 0; p < nparts; ++p) {
+        s1 += partial[((int64_t)p * 2 + 0) * d + c];
+        s2 += partial[((int64_t)p * 2 + 1) * d + c];
+    }
+    const float n = (float)N;
+    const float K = x[c];
+    const float mshift = s1 / n;
+    const float mean = K + mshift;
+    float var = s2 / n - mshift * mshift;
+    var = var > 0.f ? var : 0.f;
+    save_mean[c] = mean;
+    save_invstd[c] = rsqrtf(var + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    if (running_var) {
+        const float unbiased = N > 1 ? var * n / (n - 1.f) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+__global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var, int d,
+                                     float eps, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < d) {
+        save_mean[c] = running_mean[c];
+        save_invstd[c] = rsqrtf(running_var[c] + eps);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bn_tanh_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t N, int D4,
+                                                               const float* __restrict__ weight, const float* __restrict__ bias,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               float* __restrict__ y, int64_t ldy) {
+    const int64_t total = N * D4;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / D4;
+        const int c4 = (int)(i % D4);
+        const float4 v = ld4(x + r * ldx + c4 * 4);
+        const float4 mu = ld4(mean + c4 * 4), is = ld4(invstd + c4 * 4), w = ld4(weight + c4 * 4), b = ld4(bias + c4 * 4);
+        float4 o;
+        o.x = tanhf(fmaf((v.x - mu.x) * is.x, w.x, b.x));
+        o.y = tanhf(fmaf((v.y - mu.y) * is.y, w.y, b.y));
+        o.z = tanhf(fmaf((v.z - mu.z) * is.z, w.z, b.z));
+        o.w = tanhf(fmaf((v.w - mu.w) * is.w, w.w, b.w));
+        st4(y + r * ldy + c4 * 4, o);
+    }
+}
+
+// backward column sums: partial[b][0][c] = sum gz, partial[b][1][c] = sum gz * xhat, gz = gy*(1-y^2)
+__global__ __launch_bounds__(kBlock) void bn_bwd_partial_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                const float* __restrict__ y, int64_t ldy,
+                                                                const float* __restrict__ gy, int64_t ldgy, int64_t N, int D4,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* red = reinterpret_cast<float4*>(smem);
+    const int rpb = kBlock / D4 > 0 ? kBlock / D4 : 1;
+    const int tid = threadIdx.x;
+    for (int cbase = 0; cbase < D4; cbase += kBlock) {
+        const int rsub = D4 >= kBlock ? 0 : tid / D4;
+        const int c4 = D4 >= kBlock ? cbase + tid : tid % D4;
+        const bool active = (D4 >= kBlock ? c4 < D4 : tid < rpb * D4);
+        float4 s1 = f4zero(), s2 = f4zero();
+        if (active) {
+            const float4 mu = ld4(mean + c4 * 4), is = ld4(invstd + c4 * 4);
+            for (int64_t r = (int64_t)blockIdx.x * rpb + rsub; r < N; r += (int64_t)gridDim.x * rpb) {
+                const float4 xv = ld4(x + r * ldx + c4 * 4), yv = ld4(y + r * ldy + c4 * 4), g = ld4(gy + r * ldgy + c4 * 4);
+                const float gz0 = g.x * (1.f - yv.x * yv.x), gz1 = g.y * (1.f - yv.y * yv.y);
+                const float gz2 = g.z * (1.f - yv.z * yv.z), gz3 = g.w * (1.f - yv.w * yv.w);
+                s1.x += gz0; s1.y += gz1; s1.z += gz2; s1.w += gz3;
+                s2.x = fmaf(gz0, (xv.x - mu.x) * is.x, s2.x); s2.y = fmaf(gz1, (xv.y - mu.y) * is.y, s2.y);
+                s2.z = fmaf(gz2, (xv.z - mu.z) * is.z, s2.z); s2.w = fmaf(gz3, (xv.w - mu.w) * is.w, s2.w);
+            }
+        }
+        if (D4 >= kBlock) {
+            if (active) {
+                st4(partial + ((int64_t)blockIdx.x * 2 + 0) * D4 * 4 + c4 * 4, s1);
+                st4(partial + ((int64_t)blockIdx.x * 2 + 1) * D4 * 4 + c4 * 4, s2);
+            }
+        } else {
+            if (active) {
+                red[(0 * rpb + rsub) * D4 + c4] = s1;
+                red[(1 * rpb + rsub) * D4 + c4] = s2;
+            }
+            __syncthreads();
+            if (tid < D4) {
+                float4 a1 = red[tid], a2 = red[rpb * D4 + tid];
+                for (int q = 1; q < rpb; ++q) {
+                    float4 b1 = red[q * D4 + tid], b2 = red[(rpb + q) * D4 + tid];
+                    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+                    a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
+                }
+                st4(partial + ((int64_t)blockIdx.x * 2 + 0) * D4 * 4 + tid * 4, a1);
+                st4(partial + ((int64_t)blockIdx.x * 2 + 1) * D4 * 4 + tid * 4, a2);
+            }
+            break;
+        }
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nparts, int d, float* __restrict__ gweight,
+                                       float* __restrict__ gbias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = 0; p < nparts; ++p) {
+        s1 += partial[((int64_t)p * 2 + 0) * d + c];
+        s2 += partial[((int64_t)p * 2 + 1) * d + c];
+    }
+    gbias[c] = s1;
+    gweight[c] = s2;
+}
+
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx,
+                                                              const float* __restrict__ y, int64_t ldy,
+                                                              const float* __restrict__ gy, int64_t ldgy, int64_t N, int D4,
+                                                              const float* __restrict__ weight, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ gweight,
+                                                              const float* __restrict__ gbias, int training,
+                                                              float* __restrict__ gx, int64_t ldgx) {
+    const int64_t total = N * D4;
+    const float invn = 1.f / (float)N;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / D4;
+        const int c4 = (int)(i % D4);
+        const float4 xv = ld4(x + r * ldx + c4 * 4), yv = ld4(y + r * ldy + c4 * 4), g = ld4(gy + r * ldgy + c4 * 4);
+        const float4 mu = ld4(mean + c4 * 4), is = ld4(invstd + c4 * 4), w = ld4(weight + c4 * 4);
+        const float4 gw = ld4(gweight + c4 * 4), gb = ld4(gbias + c4 * 4);
+        float4 o;
+#define JMAC_BN_BWD(comp)                                                                 \
+        {                                                                                 \
+            const float gz = g.comp * (1.f - yv.comp * yv.comp);                          \
+            const float xh = (xv.comp - mu.comp) * is.comp;                               \
+            o.comp = training ? w.comp * is.comp * (gz - invn * (gb.comp + xh * gw.comp)) \
+                              : w.comp * is.comp * gz;                                    \
+        }
+        JMAC_BN_BWD(x) JMAC_BN_BWD(y) JMAC_BN_BWD(z) JMAC_BN_BWD(w)
+#undef JMAC_BN_BWD
+        st4(gx + r * ldgx + c4 * 4, o);
+    }
+}
+
+inline unsigned stat_grid(int64_t N, int D4) {
+    const int rpb = kBlock / D4 > 0 ? kBlock / D4 : 1;
+    int64_t need = (N + rpb - 1) / rpb;
+    if (need < 1) need = 1;
+    return (unsigned)(need < kStatBlocks ? need : kStatBlocks);
+}
+inline size_t stat_smem(int D4) {
+    const int rpb = kBlock / D4 > 0 ? kBlock / D4 : 1;
+    return D4 >= kBlock ? 16 : (size_t)2 * rpb * D4 * 16;
+}
+inline unsigned stream_grid(int64_t total) {
+    int64_t need = (total + kBlock - 1) / kBlock;
+    if (need < 1) need = 1;
+    return (unsigned)(need < 8192 ? need : 8192);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t jmac_bn_tanh_workspace_bytes(int64_t N, int64_t d) {
+    (void)N;
+    return align_up((size_t)kStatBlocks * 2 * (d > 0 ? d : 0) * 4) + 256;
+}
+
+int jmac_bn_tanh_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, const float* weight, const float* bias,
+                         float* running_mean, float* running_var, int32_t training, float momentum, float eps, float* y,
+                         int64_t ldy, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    if (N < 0 || !weight || !bias || !save_mean || !save_invstd) return JMAC_EINVAL;
+    if (d <= 0 || d % 4 || ldx % 4 || ldy % 4) return JMAC_EDIM;
+    if (N == 0) return JMAC_OK;
+    if (!x || !y) return JMAC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int D4 = (int)(d / 4);
+    if (training) {
+        if (!ws || ws_bytes < jmac_bn_tanh_workspace_bytes(N, d)) return JMAC_EWORKSPACE;
+        float* partial = (float*)ws;
+        const unsigned g = stat_grid(N, D4);
+        hipLaunchKernelGGL(col_stats_partial_kernel, dim3(g), dim3(kBlock), stat_smem(D4), st, x, ldx, N, D4, partial);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, partial, (int)g, x, N, (int)d,
+                           eps, momentum, running_mean, running_var, save_mean, save_invstd);
+    } else {
+        if (!running_mean || !running_var) return JMAC_EINVAL;
+        hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, running_mean, running_var,
+                           (int)d, eps, save_mean, save_invstd);
+    }
+    hipLaunchKernelGGL(bn_tanh_apply_kernel, dim3(stream_grid(N * D4)), dim3(kBlock), 0, st, x, ldx, N, D4, weight, bias,
+                       save_mean, save_invstd, y, ldy);
+    return (int)hipGetLastError();
+}
+
+int jmac_bn_tanh_bwd_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy, int64_t ldgy, int64_t N,
+                         int64_t d, const float* weight, const float* save_mean, const float* save_invstd, int32_t training,
+                         float* gx, int64_t ldgx, float* gweight, float* gbias, void* ws, size_t ws_bytes,
+                         jmac_stream_t stream) {
+    if (N < 0 || !weight || !save_mean || !save_invstd || !gweight || !gbias) return JMAC_EINVAL;
+    if (d <= 0 || d % 4 || ldx % 4 || ldy % 4 || ldgy % 4 || ldgx % 4) return JMAC_EDIM;
+    if (!ws || ws_bytes < jmac_bn_tanh_workspace_bytes(N, d)) return JMAC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int D4 = (int)(d / 4);
+    float* partial = (float*)ws;
+    unsigned g = 0;
+    if (N > 0) {
+        if (!x || !y || !gy || !gx) return JMAC_EINVAL;
+        g = stat_grid(N, D4);
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g), dim3(kBlock), stat_smem(D4), st, x, ldx, y, ldy, gy, ldgy, N, D4,
+                           save_mean, save_invstd, partial);
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, partial, (int)g, (int)d,
+                       gweight, gbias);
+    if (N > 0)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(N * D4)), dim3(kBlock), 0, st, x, ldx, y, ldy, gy, ldgy, N, D4,
+                           weight, save_mean, save_invstd, gweight, gbias, training, gx, ldgx);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

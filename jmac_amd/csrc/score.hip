@@ -1,0 +1,473 @@
+// score.hip -- triple and entity-pair scoring for gfx950.
+//
+//  * jmac_l1_score_f32      torch.cdist(er, all_kg_emb, p=1)            src/jmac_model.py:312
+//  * jmac_filtered_rank_f32 filter + sort + np.where ranking loop        src/validate.py:50-64
+//  * jmac_sim_matrix_f32    torch.mm(ILL_vec, KG_vec.t())                modules/utils/util.py:52, train.py:239
+//  * jmac_row_topk_f32 / jmac_sim_topk_f32   sim.topk(k, dim=1)          modules/utils/util.py:53
+//  * jmac_softmax_entropy_f32, jmac_masked_row_softmax_f32               train.py:241-257
+//
+// L1 distance is |a-b| accumulation: not a contraction, so it runs on the VALU (register-tiled through
+// LDS); the similarity matrices are contractions and run on the matrix cores with the fp32-input MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate), so top-k indices are decided on
+// full-precision scores.
+#include "common.h"
+
+using namespace jmac;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------------
+// L1 score: 64x64 output tile per block, 4x4 per thread, K staged 16 at a time (transposed in LDS)
+// ------------------------------------------------------------------------------------------------
+constexpr int L1_T = 64, L1_K = 16, L1_LD = L1_T + 4;
+
+__global__ __launch_bounds__(kBlock) void l1_score_kernel(const float* __restrict__ er, int64_t lder,
+                                                          const float* __restrict__ tab, int64_t ldt, int B, int N, int d,
+                                                          float* __restrict__ out, int64_t ldout, int accumulate) {
+    __shared__ __attribute__((aligned(16))) float As[2][L1_K][L1_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][L1_K][L1_LD];
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int b0 = blockIdx.y * L1_T, n0 = blockIdx.x * L1_T;
+    // loader mapping: one float4 (4 consecutive k) of one row per thread and per operand
+    const int lrow = tid >> 2, lk = (tid & 3) * 4;
+    const int64_t arow = b0 + lrow, brow = n0 + lrow;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    auto gload = [&](const float* base, int64_t ld, int64_t row, int64_t nrows, int k0) -> float4 {
+        float4 v = f4zero();
+        if (row < nrows) {
+            const int k = k0 + lk;
+            if (k + 3 < d) v = ld4(base + row * ld + k);
+            else {
+                const float* p = base + row * ld;
+                if (k + 0 < d) v.x = p[k + 0];
+                if (k + 1 < d) v.y = p[k + 1];
+                if (k + 2 < d) v.z = p[k + 2];
+            }
+        }
+        return v;
+    };
+    auto sstore = [&](float (*S)[L1_LD], float4 v) {
+        S[lk + 0][lrow] = v.x;
+        S[lk + 1][lrow] = v.y;
+        S[lk + 2][lrow] = v.z;
+        S[lk + 3][lrow] = v.w;
+    };
+    const int nk = (d + L1_K - 1) / L1_K;
+    float4 ra = gload(er, lder, arow, B, 0), rb = gload(tab, ldt, brow, N, 0);
+    sstore(As[0], ra);
+    sstore(Bs[0], rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            ra = gload(er, lder, arow, B, (kt + 1) * L1_K);
+            rb = gload(tab, ldt, brow, N, (kt + 1) * L1_K);
+        }
+#pragma unroll
+        for (int k = 0; k < L1_K; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(&As[cur][k][ty * 4]);
+            const float4 b = *reinterpret_cast<const float4*>(&Bs[cur][k][tx * 4]);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+            const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += fabsf(av[i] - bv[j]);
+        }
+        if (kt + 1 < nk) {
+            sstore(As[cur ^ 1], ra);
+            sstore(Bs[cur ^ 1], rb);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t b = b0 + ty * 4 + i;
+        if (b >= B) continue;
+        const int64_t n = n0 + tx * 4;
+        float* o = out + b * ldout + n;
+        if (n + 3 < N && (ldout % 4 == 0)) {
+            float4 v = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+            if (accumulate) {
+                const float4 p = ld4(o);
+                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            }
+            st4(o, v);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (n + j < N) o[j] = accumulate ? o[j] + acc[i][j] : acc[i][j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// filtered rank: one block per query
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void filtered_rank_kernel(const float* __restrict__ score, int64_t lds,
+                                                               const int32_t* __restrict__ gold,
+                                                               const int32_t* __restrict__ filt_ptr,
+                                                               const int32_t* __restrict__ filt_idx, int N,
+                                                               int32_t* __restrict__ rank) {
+    __shared__ int red[kBlock / 64];
+    const int b = blockIdx.x;
+    const float* row = score + (int64_t)b * lds;
+    const int g = gold[b];
+    const float gs = row[g];
+    int cnt = 0;
+    for (int n = threadIdx.x; n < N; n += kBlock) {
+        const float s = row[n];
+        cnt += (s < gs || (s == gs && n < g)) ? 1 : 0;
+    }
+    if (filt_ptr) {
+        for (int f = filt_ptr[b] + threadIdx.x; f < filt_ptr[b + 1]; f += kBlock) {
+            const int n = filt_idx[f];
+            if (n == g || n < 0 || n >= N) continue;
+            const float s = row[n];
+            cnt -= (s < gs || (s == gs && n < g)) ? 1 : 0;
+        }
+    }
+    cnt = wave_sum_i(cnt);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < kBlock / 64; ++w) t += red[w];
+        rank[b] = t + 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// similarity GEMM  C = A * B^T  on the fp32-input MFMA (32x32x2), 128x128 tile per 4-wave block
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int SG_T = 128, SG_K = 8;
+
+__global__ __launch_bounds__(kBlock) void sim_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
+                                                          int64_t ldb, int M, int N, int d, float* __restrict__ C, int64_t ldc) {
+    // LDS image: [row][8 floats]; lane (r = l&31, h = l>>5) reads floats 4h..4h+3 of row r: one contiguous
+    // 1 KiB ds_read_b128 per 32-row block, conflict free.
+    __shared__ __attribute__((aligned(16))) float As[2][SG_T][SG_K];
+    __shared__ __attribute__((aligned(16))) float Bs[2][SG_T][SG_K];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;           // wave grid 2 x 2, each wave 64 x 64
+    const int m0 = blockIdx.y * SG_T, n0 = blockIdx.x * SG_T;
+    const int lrow = tid >> 1, lk = (tid & 1) * 4;     // loader: 128 rows x 2 float4
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto gload = [&](const float* base, int64_t ld, int64_t row, int64_t nrows, int k0) -> float4 {
+        float4 v = f4zero();
+        if (row < nrows) {
+            const int k = k0 + lk;
+            const float* p = base + row * ld;
+            if (k + 3 < d) v = ld4(p + k);
+            else {
+                if (k + 0 < d) v.x = p[k + 0];
+                if (k + 1 < d) v.y = p[k + 1];
+                if (k + 2 < d) v.z = p[k + 2];
+            }
+        }
+        return v;
+    };
+    const int nk = (d + SG_K - 1) / SG_K;
+    float4 ra = gload(A, lda, m0 + lrow, M, 0), rb = gload(Bm, ldb, n0 + lrow, N, 0);
+    *reinterpret_cast<float4*>(&As[0][lrow][lk]) = ra;
+    *reinterpret_cast<float4*>(&Bs[0][lrow][lk]) = rb;
+    __syncthreads();
+    const int r = lane & 31, h = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            ra = gload(A, lda, m0 + lrow, M, (kt + 1) * SG_K);
+            rb = gload(Bm, ldb, n0 + lrow, N, (kt + 1) * SG_K);
+        }
+        float4 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            af[i] = *reinterpret_cast<const float4*>(&As[cur][wm * 64 + i * 32 + r][h * 4]);
+            bf[i] = *reinterpret_cast<const float4*>(&Bs[cur][wn * 64 + i * 32 + r][h * 4]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // MFMA step s contracts k = {s, 4+s} of this 8-deep slice (lane half h supplies k = 4h+s)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+            }
+        if (kt + 1 < nk) {
+            *reinterpret_cast<float4*>(&As[cur ^ 1][lrow][lk]) = ra;
+            *reinterpret_cast<float4*>(&Bs[cur ^ 1][lrow][lk]) = rb;
+        }
+        __syncthreads();
+    }
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t m = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const int64_t n = n0 + wn * 64 + j * 32 + r;
+                if (m < M && n < N) C[m * ldc + n] = acc[i][j][reg];
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row top-k: one block per row, k rounds of (value desc, index asc) arg-max after the previous pick
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void row_topk_kernel(const float* __restrict__ S, int64_t lds, int N, int k,
+                                                          float* __restrict__ val, int32_t* __restrict__ idx, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float wv[kBlock / 64];
+    __shared__ int wi[kBlock / 64];
+    __shared__ float pick_v;
+    __shared__ int pick_i;
+    float* cache = reinterpret_cast<float*>(smem);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* row = S + (int64_t)b * lds;
+    if (use_lds) {
+        for (int n = tid; n < N; n += kBlock) cache[n] = row[n];
+        __syncthreads();
+        row = cache;
+    }
+    float pv = INFINITY;
+    int pi = -1;
+    for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY;
+        int bi = INT32_MAX;
+        for (int n = tid; n < N; n += kBlock) {
+            const float v = row[n];
+            const bool after = (v < pv) || (v == pv && n > pi);       // not yet picked
+            const bool better = (v > bv) || (v == bv && n < bi);
+            if (after && better) {
+                bv = v;
+                bi = n;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if ((tid & 63) == 0) {
+            wv[tid >> 6] = bv;
+            wi[tid >> 6] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < kBlock / 64; ++w)
+                if (wv[w] > bv || (wv[w] == bv && wi[w] < bi)) {
+                    bv = wv[w];
+                    bi = wi[w];
+                }
+            pick_v = bv;
+            pick_i = bi;
+            if (val) val[(int64_t)b * k + r] = bv;
+            idx[(int64_t)b * k + r] = bi == INT32_MAX ? -1 : bi;
+        }
+        __syncthreads();
+        pv = pick_v;
+        pi = pick_i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax entropy of the rows of scale*S;  masked row softmax
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int w = 1; w < kBlock / 64; ++w) r = fmaxf(r, sh[w]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int w = 1; w < kBlock / 64; ++w) r += sh[w];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(kBlock) void row_entropy_kernel(const float* __restrict__ S, int64_t lds, int N, float scale,
+                                                             float* __restrict__ ent) {
+    __shared__ float sh[kBlock / 64];
+    const float* row = S + (int64_t)blockIdx.x * lds;
+    float m = -INFINITY;
+    for (int n = threadIdx.x; n < N; n += kBlock) m = fmaxf(m, row[n] * scale);
+    m = block_max(m, sh);
+    float z = 0.f, y = 0.f;
+    for (int n = threadIdx.x; n < N; n += kBlock) {
+        const float x = row[n] * scale - m;
+        const float e = expf(x);
+        z += e;
+        y = fmaf(e, x, y);
+    }
+    z = block_sum(z, sh);
+    y = block_sum(y, sh);
+    if (threadIdx.x == 0) ent[blockIdx.x] = logf(z) - y / z;
+}
+
+__global__ __launch_bounds__(kBlock) void masked_row_softmax_kernel(const float* __restrict__ S, int64_t lds, int N,
+                                                                    const uint8_t* __restrict__ row_mask,
+                                                                    const uint8_t* __restrict__ col_mask, float fill, float scale,
+                                                                    float* __restrict__ out, int64_t ldo) {
+    __shared__ float sh[kBlock / 64];
+    const int i = blockIdx.x;
+    const float* row = S + (int64_t)i * lds;
+    float* orow = out + (int64_t)i * ldo;
+    const bool rk = row_mask ? row_mask[i] != 0 : true;
+    auto val = [&](int n) -> float {
+        const bool keep = rk && (col_mask ? col_mask[n] != 0 : true);
+        return (keep ? row[n] : fill) * scale;
+    };
+    float m = -INFINITY;
+    for (int n = threadIdx.x; n < N; n += kBlock) m = fmaxf(m, val(n));
+    m = block_max(m, sh);
+    float z = 0.f;
+    for (int n = threadIdx.x; n < N; n += kBlock) z += expf(val(n) - m);
+    z = block_sum(z, sh);
+    const float iz = 1.f / z;
+    for (int n = threadIdx.x; n < N; n += kBlock) orow[n] = expf(val(n) - m) * iz;
+}
+
+int launch_sim(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t d, float* C, int64_t ldc,
+               hipStream_t st) {
+    if (M == 0 || N == 0) return 0;
+    dim3 grid((unsigned)((N + SG_T - 1) / SG_T), (unsigned)((M + SG_T - 1) / SG_T));
+    hipLaunchKernelGGL(sim_gemm_kernel, grid, dim3(kBlock), 0, st, A, lda, B, ldb, (int)M, (int)N, (int)d, C, ldc);
+    return (int)hipGetLastError();
+}
+
+int launch_topk(const float* S, int64_t lds, int64_t L, int64_t N, int32_t k, float* val, int32_t* idx, hipStream_t st) {
+    if (L == 0) return 0;
+    const size_t bytes = (size_t)N * 4;
+    const int use_lds = bytes <= 64 * 1024 ? 1 : 0;   // default LDS limit per workgroup without opt-in
+    hipLaunchKernelGGL(row_topk_kernel, dim3((unsigned)L), dim3(kBlock), use_lds ? bytes : 16, st, S, lds, (int)N, (int)k, val,
+                       idx, use_lds);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int jmac_l1_score_f32(const float* er, int64_t lder, const float* table, int64_t ldt, int64_t B, int64_t N, int64_t d,
+                      float* out, int64_t ldout, int32_t accumulate, jmac_stream_t stream) {
+    if (B < 0 || N < 0 || d <= 0) return JMAC_EINVAL;
+    if (B == 0 || N == 0) return JMAC_OK;
+    if (!er || !table || !out) return JMAC_EINVAL;
+    if (lder % 4 || ldt % 4) return JMAC_EDIM;
+    if (B >= INT32_MAX || N >= INT32_MAX) return JMAC_ERANGE;
+    dim3 grid((unsigned)((N + L1_T - 1) / L1_T), (unsigned)((B + L1_T - 1) / L1_T));
+    hipLaunchKernelGGL(l1_score_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, er, lder, table, ldt, (int)B, (int)N, (int)d,
+                       out, ldout, accumulate);
+    return (int)hipGetLastError();
+}
+
+int jmac_filtered_rank_f32(const float* score, int64_t lds, const int32_t* gold, const int32_t* filt_ptr,
+                           const int32_t* filt_idx, int64_t B, int64_t N, int32_t* rank, jmac_stream_t stream) {
+    if (B < 0 || N <= 0) return JMAC_EINVAL;
+    if (B == 0) return JMAC_OK;
+    if (!score || !gold || !rank || (filt_ptr && !filt_idx && false)) return JMAC_EINVAL;
+    if (N >= INT32_MAX) return JMAC_ERANGE;
+    hipLaunchKernelGGL(filtered_rank_kernel, dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, score, lds, gold, filt_ptr,
+                       filt_idx, (int)N, rank);
+    return (int)hipGetLastError();
+}
+
+int jmac_sim_matrix_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t d, float* C,
+                        int64_t ldc, jmac_stream_t stream) {
+    if (M < 0 || N < 0 || d <= 0) return JMAC_EINVAL;
+    if (M == 0 || N == 0) return JMAC_OK;
+    if (!A || !B || !C) return JMAC_EINVAL;
+    if (lda % 4 || ldb % 4) return JMAC_EDIM;
+    if (M >= INT32_MAX || N >= INT32_MAX) return JMAC_ERANGE;
+    return launch_sim(A, lda, B, ldb, M, N, d, C, ldc, (hipStream_t)stream);
+}
+
+size_t jmac_sim_topk_workspace_bytes(int64_t L, int64_t N) {
+    if (L < 0 || N < 0) return 0;
+    return align_up((size_t)L * (size_t)N * 4) + 256;
+}
+
+int jmac_row_topk_f32(const float* S, int64_t lds, int64_t L, int64_t N, int32_t k, float* val, int32_t* idx,
+                      jmac_stream_t stream) {
+    if (L < 0 || N <= 0 || k <= 0 || k > N) return JMAC_EINVAL;
+    if (L == 0) return JMAC_OK;
+    if (!S || !idx) return JMAC_EINVAL;
+    return launch_topk(S, lds, L, N, k, val, idx, (hipStream_t)stream);
+}
+
+int jmac_sim_topk_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t L, int64_t N, int64_t d, int32_t k,
+                      float* val, int32_t* idx, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    if (L < 0 || N <= 0 || d <= 0 || k <= 0 || k > N) return JMAC_EINVAL;
+    if (L == 0) return JMAC_OK;
+    if (!A || !B || !idx) return JMAC_EINVAL;
+    if (lda % 4 || ldb % 4) return JMAC_EDIM;
+    if (!ws || ws_bytes < jmac_sim_topk_workspace_bytes(L, N)) return JMAC_EWORKSPACE;
+    float* S = (float*)ws;
+    if (int rc = launch_sim(A, lda, B, ldb, L, N, d, S, N, (hipStream_t)stream)) return rc;
+    return launch_topk(S, N, L, N, k, val, idx, (hipStream_t)stream);
+}
+
+size_t jmac_softmax_entropy_workspace_bytes(int64_t n1, int64_t n2) {
+    if (n1 < 0 || n2 < 0) return 0;
+    return 2 * align_up((size_t)n1 * (size_t)n2 * 4) + 256;
+}
+
+int jmac_softmax_entropy_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t n1, int64_t n2, int64_t d,
+                             float scale, float* ent_rows, float* ent_cols, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    if (n1 < 0 || n2 < 0 || d <= 0) return JMAC_EINVAL;
+    if (n1 == 0 || n2 == 0) return JMAC_OK;
+    if (!A || !B || !ent_rows || !ent_cols) return JMAC_EINVAL;
+    if (lda % 4 || ldb % 4) return JMAC_EDIM;
+    if (!ws || ws_bytes < jmac_softmax_entropy_workspace_bytes(n1, n2)) return JMAC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* S = (float*)ws;
+    float* St = (float*)((char*)ws + align_up((size_t)n1 * (size_t)n2 * 4));
+    if (int rc = launch_sim(A, lda, B, ldb, n1, n2, d, S, n2, st)) return rc;
+    if (int rc = launch_sim(B, ldb, A, lda, n2, n1, d, St, n1, st)) return rc;
+    hipLaunchKernelGGL(row_entropy_kernel, dim3((unsigned)n1), dim3(kBlock), 0, st, S, n2, (int)n2, scale, ent_rows);
+    hipLaunchKernelGGL(row_entropy_kernel, dim3((unsigned)n2), dim3(kBlock), 0, st, St, n1, (int)n1, scale, ent_cols);
+    return (int)hipGetLastError();
+}
+
+int jmac_masked_row_softmax_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, const uint8_t* row_mask,
+                                const uint8_t* col_mask, float fill, float scale, float* out, int64_t ldo,
+                                jmac_stream_t stream) {
+    if (n1 < 0 || n2 <= 0) return JMAC_EINVAL;
+    if (n1 == 0) return JMAC_OK;
+    if (!S || !out) return JMAC_EINVAL;
+    hipLaunchKernelGGL(masked_row_softmax_kernel, dim3((unsigned)n1), dim3(kBlock), 0, (hipStream_t)stream, S, lds, (int)n2,
+                       row_mask, col_mask, fill, scale, out, ldo);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

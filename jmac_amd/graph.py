@@ -1,0 +1,139 @@
+"""Device-resident relation graph: CSR by aggregation destination + work schedules.
+
+The reference hands every layer call a COO ``edge_index [2,E]`` / ``edge_type [E]`` pair of int64
+tensors (train.py:116-135, src/utils.py:112-149) and recomputes degrees per call
+(src/jmac_model.py:99-109).  Here the COO pair is converted once by ``jmac_csr_build`` and the result
+is cached per tensor identity, so the drop-in layer can keep the reference's call signature.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import View, check, lib, ptr, require_device, stream
+
+DEFAULT_CHUNK = 256
+
+
+class _Schedule:
+    """items / splits / counts for one grouping of the CSR slots (jmac_items_build)."""
+
+    def __init__(self, seg_ptr: torch.Tensor, n_seg: int, n_entries: int, chunk: int, order: Optional[torch.Tensor]):
+        L = lib()
+        dev = seg_ptr.device
+        self.ptr = seg_ptr
+        self.order = order
+        self.n_items_max = int(L.jmac_items_max(n_seg, n_entries, chunk))
+        self.n_splits_max = int(L.jmac_splits_max(n_entries, chunk))
+        self.n_parts_max = int(L.jmac_parts_max(n_entries, chunk))
+        self.items = torch.empty((self.n_items_max, 4), dtype=torch.int32, device=dev)
+        self.splits = torch.empty((self.n_splits_max, 4), dtype=torch.int32, device=dev)
+        self.counts = torch.zeros(4, dtype=torch.int32, device=dev)
+        ws_bytes = int(L.jmac_graph_workspace_bytes(n_entries, n_seg))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(L.jmac_items_build(ptr(seg_ptr), n_seg, chunk, ptr(self.items), ptr(self.splits), ptr(self.counts),
+                                 ptr(ws), ws_bytes, stream()), "jmac_items_build")
+        self._view = View(ptr(self.ptr), ptr(self.order), ptr(self.items), ptr(self.splits), ptr(self.counts),
+                          self.n_items_max, self.n_splits_max, self.n_parts_max)
+
+    def view(self) -> View:
+        return self._view
+
+
+class RelGraph:
+    """CSR (by destination) of a typed edge list, on one HIP device.
+
+    edge_index[0] = aggregation destination, edge_index[1] = message source
+    (modules/helper/message_passing.py:75,79,87).
+    """
+
+    def __init__(self, edge_index: torch.Tensor, edge_type: torch.Tensor, num_nodes: int, num_rel: int,
+                 chunk: int = DEFAULT_CHUNK):
+        require_device(edge_index, edge_type)
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError("edge_index must be [2, E]")
+        if edge_type.shape[0] != edge_index.shape[1]:
+            raise ValueError("edge_type must be [E]")
+        L = lib()
+        dev = edge_index.device
+        self.N, self.E, self.num_rel, self.chunk = int(num_nodes), int(edge_index.shape[1]), int(num_rel), int(chunk)
+        self.device = dev
+        ei = edge_index.contiguous().to(torch.int64)
+        et = edge_type.contiguous().to(torch.int64)
+        E, N = self.E, self.N
+        self.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        self.col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        self.etype = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        self.perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        ws_bytes = int(L.jmac_graph_workspace_bytes(E, N))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(L.jmac_csr_build(ptr(ei), ptr(et), E, N, ptr(self.rowptr), ptr(self.col), ptr(self.etype), ptr(self.perm),
+                               ptr(ws), ws_bytes, stream()), "jmac_csr_build")
+        self.by_dst = _Schedule(self.rowptr, N, E, chunk, None)
+        self._ei = ei
+        self._bwd_ready = False
+        self.dst_of_slot = None
+        self.by_src = None
+        self.by_rel = None
+
+    # the backward needs the by-source and by-relation groupings of the CSR slots; built on first use
+    def ensure_backward_views(self) -> None:
+        if self._bwd_ready:
+            return
+        L = lib()
+        dev, E, N = self.device, self.E, self.N
+        if E > 0:
+            self.dst_of_slot = self._ei[0].index_select(0, self.perm[:E].long()).to(torch.int32)
+        else:
+            self.dst_of_slot = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def group(keys: torch.Tensor, n_seg: int) -> _Schedule:
+            seg_ptr = torch.empty(n_seg + 1, dtype=torch.int32, device=dev)
+            order = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+            ws_bytes = int(L.jmac_graph_workspace_bytes(E, n_seg))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            check(L.jmac_group_build(ptr(keys), E, n_seg, ptr(seg_ptr), ptr(order), ptr(ws), ws_bytes, stream()),
+                  "jmac_group_build")
+            return _Schedule(seg_ptr, n_seg, E, self.chunk, order)
+
+        self.by_src = group(self.col, N)
+        self.by_rel = group(self.etype, self.num_rel)
+        self._ei = None
+        self._bwd_ready = True
+
+    def degrees(self) -> torch.Tensor:
+        return (self.rowptr[1:] - self.rowptr[:-1])
+
+
+class GraphCache:
+    """Small LRU keyed on the identity of the COO tensors the reference passes to every layer call."""
+
+    def __init__(self, capacity: int = 16):
+        self.capacity = capacity
+        self._d: "OrderedDict[Tuple, RelGraph]" = OrderedDict()
+
+    def get(self, edge_index: torch.Tensor, edge_type: torch.Tensor, num_nodes: int, num_rel: int,
+            chunk: int = DEFAULT_CHUNK) -> RelGraph:
+        key = (edge_index.data_ptr(), edge_type.data_ptr(), tuple(edge_index.shape), edge_index._version,
+               edge_type._version, int(num_nodes), int(num_rel), int(chunk), str(edge_index.device))
+        g = self._d.get(key)
+        if g is None:
+            g = RelGraph(edge_index, edge_type, num_nodes, num_rel, chunk)
+            # keep the COO tensors alive so a recycled data_ptr can never alias a stale entry
+            g._key_refs = (edge_index, edge_type)
+            self._d[key] = g
+            while len(self._d) > self.capacity:
+                self._d.popitem(last=False)
+        else:
+            self._d.move_to_end(key)
+        return g
+
+    def clear(self) -> None:
+        self._d.clear()
+
+
+graph_cache = GraphCache()

@@ -1,0 +1,138 @@
+"""Drop-in RelationAwareLayer on libjmac_hip.so.
+
+Same constructor, ``forward`` signature, parameter names and ``state_dict`` keys as the reference layer
+(src/jmac_model.py:10-53; DBPv1 variant JMAC_DBPv1/models/jmac_model.py:20-63), so that
+``JMAC.__init__`` (src/jmac_model.py:147-149) can instantiate it unchanged and reference checkpoints load.
+
+The per-edge GEMMs of the reference are linear in the gathered rows for comp_op='sub', so they are
+hoisted to per-node / per-relation GEMMs (one [N,d]x[d,3d] and one [nr+1,d]x[d,2d], rocBLAS through
+torch.mm); everything indexed by edges runs in the fused HIP kernels.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.init import xavier_normal_
+
+from . import ops, scatter as jscatter
+from ._lib import require_device
+from .graph import DEFAULT_CHUNK, graph_cache
+
+
+def get_param(shape):
+    """xavier_normal parameter, as modules/helper/helper.py:68-74."""
+    p = nn.Parameter(torch.empty(*shape))
+    xavier_normal_(p.data)
+    return p
+
+
+def _identity(x):
+    return x
+
+
+class RelationAwareLayer(nn.Module):
+    """ctor ``(in_channels, out_channels, rel_dim, act, args)`` reading ``args.leaky_relu_w`` and
+    ``args.comp_op`` (src/jmac_model.py:14-30)."""
+
+    rel_activation = "leaky_relu"      # src/jmac_model.py:41 ; the DBPv1 subclass uses ReLU
+
+    def __init__(self, in_channels, out_channels, rel_dim, act=_identity, args=None):
+        super().__init__()
+        self.layer_act = act
+        self.args = args
+        self.rel_transform_weight1 = get_param((rel_dim, in_channels))
+        self.rel_transform_weight2 = get_param((in_channels, in_channels))
+        self.gcn_weight = get_param((in_channels, out_channels))
+        self.loop_rel = get_param((1, rel_dim))
+        self.w_att = get_param((2 * in_channels, out_channels))
+        self.a_att = get_param((out_channels, 1))
+        self.atv_mlp = nn.LeakyReLU(args.leaky_relu_w)
+        self.bn = nn.BatchNorm1d(out_channels)
+        self.comp_op = getattr(args, "comp_op", None) or getattr(args, "opn", "sub")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.bwd_mode = ops.BWD_MODE_DETERMINISTIC
+        self.chunk = DEFAULT_CHUNK
+
+    # -- pieces ---------------------------------------------------------------------------------
+    def transform_relations(self, rel_emb):
+        rel = torch.cat([rel_emb, self.loop_rel], dim=0)                  # jmac_model.py:39
+        rel = torch.mm(rel, self.rel_transform_weight1)
+        rel = self.atv_mlp(rel) if self.rel_activation == "leaky_relu" else F.relu(rel)
+        return torch.mm(rel, self.rel_transform_weight2)                  # :42
+
+    def _tables(self, ent_emb, rel):
+        """P|Q|Z and Rq|Rz, zero-padded to a multiple of 4 columns for 16-byte rows."""
+        d_in, d = self.in_channels, self.out_channels
+        dp = (d + 3) // 4 * 4
+        wt, wb, wg = self.w_att[:d_in], self.w_att[d_in:], self.gcn_weight
+        a = self.a_att.reshape(-1)
+        if dp != d:
+            pad = lambda w: F.pad(w, (0, dp - d))
+            wt, wb, wg, a = pad(wt), pad(wb), pad(wg), F.pad(a, (0, dp - d))
+        wcat = torch.cat([wt, wb, wg], dim=1)                             # [d_in, 3dp]
+        PQZ = torch.mm(ent_emb, wcat)                                     # [N, 3dp]
+        RR = torch.mm(rel, wcat[:, dp:])                                  # [nr+1, 2dp]
+        return PQZ, RR, a, dp
+
+    def pre_bn(self, ent_emb, rel_emb, edge_index, edge_type):
+        """(message_neighbors + message_self) / 2 of src/jmac_model.py:49-52."""
+        require_device(ent_emb, rel_emb, edge_index, edge_type)
+        n = ent_emb.size(0)
+        rel = self.transform_relations(rel_emb)
+        if self.comp_op == "sub":
+            graph = graph_cache.get(edge_index, edge_type, n, rel.size(0), self.chunk)
+            PQZ, RR, a, dp = self._tables(ent_emb, rel)
+            pre = ops.rel_attn_aggregate(PQZ, RR, a, graph, self.atv_mlp.negative_slope,
+                                         loop_rel=rel.size(0) - 1, out_scale=0.5, bwd_mode=self.bwd_mode)
+            return pre if dp == self.out_channels else pre[:, : self.out_channels]
+        if self.comp_op == "mult":
+            return self._pre_bn_unfactorised(ent_emb, rel, edge_index, edge_type)
+        raise NotImplementedError(self.comp_op)
+
+    def _pre_bn_unfactorised(self, x, rel, edge_index, edge_type):
+        """comp_op='mult' does not factor ((x_j * r) W): per-edge torch GEMMs + this library's
+        torch_scatter-compatible kernels (jmac_scatter_*), i.e. the reference formulation on HIP."""
+        n = x.size(0)
+        slope = self.atv_mlp.negative_slope
+
+        def propagate(ei, et, use_norm):
+            dst, src = ei[0], ei[1]
+            m = x[src] * rel.index_select(0, et)
+            s = torch.mm(F.leaky_relu(torch.mm(torch.cat((x[dst], m), dim=1), self.w_att), slope), self.a_att)
+            o = torch.mm(m, self.gcn_weight)
+            alpha = jscatter.scatter_softmax(s, dst, dim=0, dim_size=n)
+            if use_norm:
+                deg = jscatter.scatter_add(torch.ones_like(dst, dtype=torch.float32), dst, dim=0, dim_size=n)
+                alpha = alpha * deg.sqrt()[dst].view(-1, 1)
+            return jscatter.scatter(o * alpha, dst, dim=0, dim_size=n, reduce="sum")
+
+        loop = torch.arange(n, device=x.device)
+        nb = propagate(edge_index, edge_type, True)
+        sl = propagate(torch.stack([loop, loop]), torch.full((n,), rel.size(0) - 1, dtype=torch.long, device=x.device), False)
+        return (nb + sl) / 2
+
+    # -- reference signature ----------------------------------------------------------------------
+    def forward(self, ent_emb, rel_emb, edge_index, edge_type):
+        pre = self.pre_bn(ent_emb, rel_emb, edge_index, edge_type)
+        bn = self.bn
+        d = self.out_channels
+        if self.layer_act is torch.tanh and d % 4 == 0:
+            if bn.training and bn.track_running_stats:
+                bn.num_batches_tracked.add_(1)
+            use_batch = bn.training or not bn.track_running_stats
+            return ops.bn_tanh(pre, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch,
+                               bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+        return self.layer_act(bn(pre))                                    # jmac_model.py:52
+
+
+class RelationalAwareLayer(RelationAwareLayer):
+    """DBPv1 variant: ctor ``(in_channels, out_channels, num_rels, rel_dim, act, args)``, ReLU between the
+    two relation transforms, ``args.opn`` (JMAC_DBPv1/models/jmac_model.py:20-41,51)."""
+
+    rel_activation = "relu"
+
+    def __init__(self, in_channels, out_channels, num_rels, rel_dim, act=_identity, args=None):
+        super().__init__(in_channels, out_channels, rel_dim, act=act, args=args)
+        self.num_rels = num_rels
+        self.margin = 5.0

@@ -1,0 +1,167 @@
+"""JMAC encoder + scoring call sites on the HIP layer (rows a9-a11, a15, a16 of SURVEY.md section 8).
+
+A host-side mirror of ``class JMAC`` (src/jmac_model.py:125-380): same constructor arguments, same
+parameter / buffer names (reference ``state_dict``s load with ``strict=True``), same method names and
+argument meaning.  The three GNN layers are ``jmac_amd.layer.RelationAwareLayer``; link-prediction
+distances go through ``jmac_amd.scoring.l1_scores``; the dense mixes and the margin losses stay in
+torch exactly as SURVEY.md scopes them.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import scoring
+from .layer import RelationAwareLayer, get_param
+
+
+def _idx(x, device):
+    """Index lists arrive as python lists, int64 tensors or float64 numpy arrays (train.py:190-193)."""
+    if isinstance(x, torch.Tensor):
+        return x.reshape(-1).to(device=device, dtype=torch.long)
+    return torch.as_tensor(np.asarray(x).reshape(-1).astype(np.int64), device=device)
+
+
+class JMAC(nn.Module):
+    def __init__(self, args, entity_name_emb, num_relations, num_entities):
+        super().__init__()
+        self.args = args
+        self.act = torch.tanh
+        self.ent_info_att = torch.as_tensor(np.asarray(entity_name_emb), dtype=torch.float32)   # :133 (plain attribute)
+        assert self.ent_info_att.shape[0] == num_entities
+        d = args.dim
+        self.entity_dim = self.relation_dim = d
+        self.device = args.device
+        self.ent_init_att_completion = get_param((num_entities, d))
+        self.rel_init_att_completion = get_param((num_relations, d))
+        self.rel_init_att_alignment = get_param((num_relations, d))
+        self.completion_dropout = nn.Dropout(args.dropout)
+        self.atv_mlp = nn.LeakyReLU(args.leaky_relu_w)
+        mk = lambda: RelationAwareLayer(d, d, rel_dim=d, act=self.act, args=args)
+        self.conv1_alignment, self.conv2_alignment, self.conv1_completion = mk(), mk(), mk()
+        self.name_linear = get_param((self.ent_info_att.shape[1], d))
+        self.margin_align = args.margin_align
+        self.k = args.num_negative
+        self.margin_completion = nn.Parameter(torch.tensor([float(args.margin_completion)]), requires_grad=False)
+        L = args.num_gcn_layer
+        self.uni_linear1_1, self.uni_linear1_2 = get_param((d * L, d)), get_param((d, d))
+        self.uni_linear2_1, self.uni_linear2_2 = get_param((d * L, d)), get_param((d, d))
+        self.rel_linear11, self.rel_linear12 = get_param((d, d)), get_param((d, d))
+        self.rel_linear21, self.rel_linear22 = get_param((d, d)), get_param((d, d))
+        self.rel_linear11_uni, self.rel_linear12_uni = get_param((d, d)), get_param((d, d))
+        self.all_linear_completion = get_param((d * (L + 1), d))
+        self.forward_base = self.forward_no_name if args.no_name_info else self.forward_name   # :166-169
+
+    # ---- encoders -------------------------------------------------------------------------------
+    def _rel_mlp(self, r, w1, w2):
+        return torch.mm(self.atv_mlp(torch.mm(r, w1)), w2)
+
+    def forward_name(self, edge_index, edge_type, ent_bases, rel_bases):
+        """src/jmac_model.py:172-204."""
+        e0, e1 = ent_bases
+        r0, r1 = rel_bases
+        dev = self.ent_init_att_completion.device
+        comp_att = self.ent_init_att_completion[e0:e1]
+        rel_comp = self.rel_init_att_completion[r0:r1]
+        rel_align = self.rel_init_att_alignment[r0:r1]
+        name_att = torch.mm(self.ent_info_att[e0:e1].to(dev), self.name_linear)
+        comp0 = self.completion_dropout(F.normalize(comp_att))
+        align0 = torch.mm(torch.cat((comp0, name_att), dim=1), self.uni_linear1_1)
+        a1 = self.conv1_alignment(align0, rel_align, edge_index, edge_type)
+        align_layers, comp_layers, comp_rel_layers = [align0, a1], [comp_att], [rel_comp]
+        if self.args.num_gcn_layer == 2:
+            c1 = self.conv1_completion(comp_att, rel_comp, edge_index, edge_type)
+            c1n = self.completion_dropout(F.normalize(c1))
+            a_in = torch.mm(torch.cat((c1n, a1), dim=1), self.uni_linear2_1)
+            rel_c1 = self._rel_mlp(rel_comp, self.rel_linear11, self.rel_linear12)
+            rel_a_in = self._rel_mlp(rel_align, self.rel_linear11_uni, self.rel_linear12_uni)
+            a2 = self.conv2_alignment(a_in, rel_a_in, edge_index, edge_type)
+            align_layers.append(a2)
+            comp_layers.append(c1)
+            comp_rel_layers.append(rel_c1)
+        align_out = torch.mm(torch.cat(align_layers, dim=1), self.all_linear_completion)
+        return align_out, comp_layers, comp_rel_layers
+
+    def forward_no_name(self, edge_index, edge_type, ent_bases, rel_bases):
+        """src/jmac_model.py:207-220."""
+        e0, e1 = ent_bases
+        r0, r1 = rel_bases
+        comp_att = self.ent_init_att_completion[e0:e1]
+        rel_comp = self.rel_init_att_completion[r0:r1]
+        comp_layers, comp_rel_layers = [comp_att], [rel_comp]
+        if self.args.num_gcn_layer == 2:
+            comp_layers.append(self.conv1_completion(comp_att, rel_comp, edge_index, edge_type))
+            comp_rel_layers.append(self._rel_mlp(rel_comp, self.rel_linear11, self.rel_linear12))
+        return comp_layers[-1], comp_layers, comp_rel_layers
+
+    def get_emb(self, edge_index, edge_type, ent_bases, rel_bases, pyt=False):
+        """src/jmac_model.py:223-234."""
+        align_out, comp_layers, _ = self.forward_base(edge_index, edge_type, ent_bases, rel_bases)
+        a = F.normalize(align_out, 2, -1).detach()
+        c = F.normalize(comp_layers[-1], 2, -1).detach()
+        if pyt:
+            return a.cpu(), c.cpu()
+        return a.cpu().numpy(), c.cpu().numpy()
+
+    # ---- scoring ----------------------------------------------------------------------------------
+    def forward_linkpred(self, e_index, r_index, edge_index, edge_type, all_index, ent_bases, rel_bases,
+                         pred_head=False, cached=None):
+        """src/jmac_model.py:295-313.  ``cached`` = a previous forward_base result: the encoder output
+        is constant across evaluation batches (src/validate.py:46-50 recomputes it per batch)."""
+        if cached is None:
+            cached = self.forward_base(edge_index, edge_type, ent_bases, rel_bases)
+        _, comp_layers, comp_rel_layers = cached
+        n = comp_layers[0].shape[0]
+        if not (len(all_index) == n and (n == 0 or (all_index[0] == 0 and all_index[-1] == n - 1))):
+            ai = _idx(all_index, comp_layers[0].device)
+            comp_layers = [c.index_select(0, ai) for c in comp_layers]
+        layers = range(self.args.num_gcn_layer)
+        return scoring.linkpred_dist([comp_layers[l] for l in layers], [comp_rel_layers[l] for l in layers],
+                                     e_index, r_index, pred_head)
+
+    # ---- losses (torch; src/jmac_model.py:237-292, :316-380) ---------------------------------------
+    @staticmethod
+    def _cos_dist(e1, i1, e2, i2):
+        return 1 - torch.sum(F.normalize(e1[i1], 2, -1) * F.normalize(e2[i2], 2, -1), dim=1)
+
+    def alignment_loss_simple(self, links, ent_embeddings1, ent_embeddings2):
+        if not len(links):
+            return 0
+        dev = ent_embeddings1.device
+        links = torch.as_tensor(np.asarray(links), dtype=torch.long, device=dev)
+        return self._cos_dist(ent_embeddings1, links[:, 0], ent_embeddings2, links[:, 1]).mean()
+
+    def alignment_loss(self, feeddict, edge_index1, edge_type1, edge_index2, edge_type2):
+        links = feeddict["links"]
+        if not len(links):
+            return 0
+        e1, _, _ = self.forward_base(edge_index1, edge_type1, feeddict["ent_bases1"], feeddict["rel_bases1"])
+        e2, _, _ = self.forward_base(edge_index2, edge_type2, feeddict["ent_bases2"], feeddict["rel_bases2"])
+        dev = e1.device
+        lk = torch.as_tensor(np.asarray(links), dtype=torch.long, device=dev)
+        n = len(lk)
+        d = (self._cos_dist(e1, lk[:, 0], e2, lk[:, 1]) + self.margin_align).view(n, 1)
+        total = 0
+        for left, right in (("neg_left", "neg_right"), ("neg2_left", "neg2_right")):
+            b = self._cos_dist(e1, _idx(feeddict[left], dev), e2, _idx(feeddict[right], dev))
+            total = total + F.relu(d - b.view(n, -1)).sum()
+        return total / (2 * self.k * n)
+
+    def completion_loss(self, data, edge_index1, edge_type1, edge_index2, edge_type2, feeddict, source=True):
+        _, comp1, rel1 = self.forward_base(edge_index1, edge_type1, feeddict["ent_bases1"], feeddict["rel_bases1"])
+        _, comp2, rel2 = self.forward_base(edge_index2, edge_type2, feeddict["ent_bases2"], feeddict["rel_bases2"])
+        h, t, r = data["batch_h"], data["batch_t"], data["batch_r"]
+        bs = self.args.batch_size
+        loss = 0
+        for layer in range(self.args.num_gcn_layer):
+            ent, rel = (comp1[layer], rel1[layer]) if source else (comp2[layer], rel2[layer])
+            score = torch.norm(ent[h] + rel[r] - ent[t], 1, -1).flatten()
+            pos, neg = score[:bs], score[bs:]
+            # the reference consumes the b-major negative block as n-major (view(-1, B).permute): kept as is
+            pos = pos.view(-1, min(bs, len(pos))).permute(1, 0)
+            neg = neg.view(-1, min(bs, len(neg))).permute(1, 0)
+            loss_res = torch.max(pos - neg, -self.margin_completion).mean() + self.margin_completion
+            loss = loss + loss_res + self.alignment_loss_simple(feeddict["links"], comp1[layer], comp2[layer])
+        return loss

@@ -1,0 +1,146 @@
+"""torch.autograd.Function wrappers over the C ABI (include/jmac_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every arithmetic step of the hot path
+runs in libjmac_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import check, lib, ptr, require_device, stream
+from .graph import RelGraph
+
+BWD_MODE_ATOMIC = 0
+BWD_MODE_DETERMINISTIC = 1
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError("jmac_amd ops compute in fp32 (got %s)" % t.dtype)
+    return t
+
+
+class _RelAttnAggregate(torch.autograd.Function):
+    """out = out_scale * ( sqrt(deg) * softmax-weighted sum over in-edges of (Z[j]-Rz[t]) + [Z[i]-Rz[loop]] ).
+
+    PQZ: [N, 3d] = P | Q | Z (one GEMM output), RR: [nrel, 2d] = Rq | Rz, a: [d].
+    """
+
+    @staticmethod
+    def forward(ctx, PQZ, RR, a, graph: RelGraph, slope: float, loop_rel: int, out_scale: float, bwd_mode: int):
+        require_device(PQZ, RR, a)
+        PQZ, RR, a = _f32c(PQZ).contiguous(), _f32c(RR).contiguous(), _f32c(a).contiguous()
+        N, d3 = PQZ.shape
+        d = d3 // 3
+        if graph.N != N:
+            raise ValueError("graph has %d nodes, tables have %d rows" % (graph.N, N))
+        L = lib()
+        dev = PQZ.device
+        out = torch.empty((N, d), dtype=torch.float32, device=dev)
+        seg_max = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+        seg_den = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+        s = graph.by_dst
+        ws_bytes = int(L.jmac_rel_attn_fwd_workspace_bytes(s.n_parts_max, d))
+        ws = _ws(ws_bytes, dev)
+        esz = PQZ.element_size()
+        check(L.jmac_rel_attn_aggregate_fwd_f32(
+            ptr(PQZ), d3, PQZ.data_ptr() + d * esz, d3, ptr(RR), RR.shape[1], ptr(a),
+            ptr(graph.rowptr), ptr(graph.col), ptr(graph.etype), ptr(s.items), ptr(s.splits), ptr(s.counts),
+            s.n_items_max, s.n_splits_max, s.n_parts_max, N, d, float(slope), int(loop_rel), float(out_scale),
+            ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(ws), ws_bytes, stream()), "jmac_rel_attn_aggregate_fwd_f32")
+        ctx.save_for_backward(PQZ, RR, a, out, seg_max, seg_den)
+        ctx.graph, ctx.slope, ctx.loop_rel, ctx.out_scale, ctx.bwd_mode = graph, slope, loop_rel, out_scale, bwd_mode
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        PQZ, RR, a, out, seg_max, seg_den = ctx.saved_tensors
+        graph: RelGraph = ctx.graph
+        L = lib()
+        dev = PQZ.device
+        N, d3 = PQZ.shape
+        d = d3 // 3
+        nrel = RR.shape[0]
+        G = _f32c(G).contiguous()
+        mode = int(ctx.bwd_mode)
+        if mode == BWD_MODE_DETERMINISTIC:
+            graph.ensure_backward_views()
+        dPQZ = torch.empty_like(PQZ)
+        dRR = torch.empty_like(RR)
+        da = torch.empty_like(a)
+        vd = graph.by_dst.view()
+        vs = graph.by_src.view() if mode else None
+        vr = graph.by_rel.view() if mode else None
+        ws_bytes = int(L.jmac_rel_attn_bwd_workspace_bytes(
+            N, graph.E, nrel, d, graph.by_dst.n_parts_max,
+            graph.by_src.n_parts_max if mode else 0, graph.by_rel.n_parts_max if mode else 0, mode))
+        ws = _ws(ws_bytes, dev)
+        esz = PQZ.element_size()
+        check(L.jmac_rel_attn_aggregate_bwd_f32(
+            ptr(PQZ), d3, PQZ.data_ptr() + d * esz, d3, ptr(RR), RR.shape[1], ptr(a),
+            ptr(graph.col), ptr(graph.etype), ptr(graph.dst_of_slot) if mode else None,
+            C.byref(vd), C.byref(vs) if mode else None, C.byref(vr) if mode else None,
+            N, graph.E, nrel, d, float(ctx.slope), int(ctx.loop_rel), float(ctx.out_scale),
+            ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(G), d,
+            ptr(dPQZ), d3, dPQZ.data_ptr() + d * esz, d3, ptr(dRR), dRR.shape[1], ptr(da),
+            mode, ptr(ws), ws_bytes, stream()), "jmac_rel_attn_aggregate_bwd_f32")
+        return dPQZ, dRR, da, None, None, None, None, None
+
+
+def rel_attn_aggregate(PQZ: torch.Tensor, RR: torch.Tensor, a: torch.Tensor, graph: RelGraph, slope: float,
+                       loop_rel: int = -1, out_scale: float = 1.0,
+                       bwd_mode: int = BWD_MODE_DETERMINISTIC) -> torch.Tensor:
+    return _RelAttnAggregate.apply(PQZ, RR, a, graph, float(slope), int(loop_rel), float(out_scale), int(bwd_mode))
+
+
+class _BnTanh(torch.autograd.Function):
+    """tanh(BatchNorm1d(x)) with nn.BatchNorm1d semantics (src/jmac_model.py:52)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training: bool, momentum: float, eps: float):
+        require_device(x, weight, bias)
+        x = _f32c(x).contiguous()
+        N, d = x.shape
+        L = lib()
+        dev = x.device
+        y = torch.empty_like(x)
+        save_mean = torch.empty(d, dtype=torch.float32, device=dev)
+        save_invstd = torch.empty(d, dtype=torch.float32, device=dev)
+        ws_bytes = int(L.jmac_bn_tanh_workspace_bytes(N, d))
+        ws = _ws(ws_bytes, dev)
+        check(L.jmac_bn_tanh_fwd_f32(ptr(x), d, N, d, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
+                                     1 if training else 0, float(momentum), float(eps), ptr(y), d, ptr(save_mean),
+                                     ptr(save_invstd), ptr(ws), ws_bytes, stream()), "jmac_bn_tanh_fwd_f32")
+        ctx.save_for_backward(x, y, weight, save_mean, save_invstd)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, weight, save_mean, save_invstd = ctx.saved_tensors
+        N, d = x.shape
+        L = lib()
+        dev = x.device
+        gy = _f32c(gy).contiguous()
+        gx = torch.empty_like(x)
+        gw = torch.empty(d, dtype=torch.float32, device=dev)
+        gb = torch.empty(d, dtype=torch.float32, device=dev)
+        ws_bytes = int(L.jmac_bn_tanh_workspace_bytes(N, d))
+        ws = _ws(ws_bytes, dev)
+        check(L.jmac_bn_tanh_bwd_f32(ptr(x), d, ptr(y), d, ptr(gy), d, N, d, ptr(weight), ptr(save_mean), ptr(save_invstd),
+                                     1 if ctx.training else 0, ptr(gx), d, ptr(gw), ptr(gb), ptr(ws), ws_bytes, stream()),
+              "jmac_bn_tanh_bwd_f32")
+        return gx, gw, gb, None, None, None, None, None
+
+
+def bn_tanh(x, weight, bias, running_mean, running_var, training: bool, momentum: float = 0.1, eps: float = 1e-5):
+    if x.shape[1] % 4 != 0:
+        raise ValueError("bn_tanh needs d % 4 == 0 (pad on the host)")
+    return _BnTanh.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps))

@@ -1,0 +1,168 @@
+"""Completion / alignment scoring on libjmac_hip.so (boundary B3).
+
+    l1_scores            == torch.cdist(er, table, p=1)                      src/jmac_model.py:312
+    linkpred_dist        == JMAC.forward_linkpred after forward_base          src/jmac_model.py:301-313
+    filtered_rank        == filter + sort + np.where of CompletionEvaluator   src/validate.py:50-64
+    sim_topk / get_neg   == mm + topk                                         modules/utils/util.py:31-54
+    align_entropy        == first half of compute_alignment_quality           train.py:235-248
+    alignment_quality    == compute_alignment_quality                         train.py:231-259
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from ._lib import check, lib, ptr, require_device, stream
+
+
+def _rows16(t: torch.Tensor) -> torch.Tensor:
+    """fp32, contiguous, row length padded to a multiple of 4 (16-byte rows) with zeros."""
+    if t.dtype != torch.float32:
+        raise TypeError("fp32 only")
+    d = t.shape[1]
+    if d % 4:
+        t = torch.nn.functional.pad(t, (0, 4 - d % 4))
+    return t.contiguous()
+
+
+def l1_scores(er: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] = None,
+              accumulate: bool = False) -> torch.Tensor:
+    require_device(er, table)
+    er, table = _rows16(er), _rows16(table)       # zero padding adds |0-0| = 0
+    B, d = er.shape
+    N = table.shape[0]
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.float32, device=er.device)
+        accumulate = False
+    check(lib().jmac_l1_score_f32(ptr(er), er.shape[1], ptr(table), table.shape[1], B, N, d, ptr(out), out.stride(0),
+                                  1 if accumulate else 0, stream()), "jmac_l1_score_f32")
+    return out
+
+
+def linkpred_dist(comp_layers: Sequence[torch.Tensor], comp_rel_layers: Sequence[torch.Tensor], e_index, r_index,
+                  pred_head: bool = False) -> torch.Tensor:
+    dev = comp_layers[0].device
+    e_index = torch.as_tensor(e_index, dtype=torch.long, device=dev)
+    r_index = torch.as_tensor(r_index, dtype=torch.long, device=dev)
+    dist = None
+    for ent, rel in zip(comp_layers, comp_rel_layers):
+        e, r = ent[e_index], rel[r_index]
+        er = e - r if pred_head else e + r                               # jmac_model.py:308-311
+        dist = l1_scores(er, ent, out=dist, accumulate=dist is not None)
+    return dist
+
+
+def build_filter_csr(heads, rels, true_tail: Dict, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Pack er_vocab[(h, r)] lists (src/validate.py:53; knowledgegraph.py:62-86) as CSR over the batch."""
+    ptr_l, idx = [0], []
+    for h, r in zip(heads, rels):
+        tails = np.unique(np.asarray(true_tail.get((int(h), int(r)), []), dtype=np.int64))
+        idx.extend(tails.tolist())
+        ptr_l.append(len(idx))
+    return (torch.tensor(ptr_l, dtype=torch.int32, device=device),
+            torch.tensor(idx if idx else [0], dtype=torch.int32, device=device))
+
+
+def filtered_rank(dist: torch.Tensor, gold, filt_ptr: Optional[torch.Tensor] = None,
+                  filt_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """1-based rank of the gold tail under ascending distance; filtered entries are skipped.
+    Ties: an equal score counts as ranked before the gold iff its index is lower."""
+    require_device(dist)
+    if dist.dtype != torch.float32 or dist.stride(1) != 1:
+        raise TypeError("dist must be fp32 with unit column stride")
+    B, N = dist.shape
+    gold = torch.as_tensor(gold, device=dist.device).to(torch.int32).contiguous()
+    rank = torch.empty(B, dtype=torch.int32, device=dist.device)
+    check(lib().jmac_filtered_rank_f32(ptr(dist), dist.stride(0), ptr(gold), ptr(filt_ptr), ptr(filt_idx), B, N, ptr(rank),
+                                       stream()), "jmac_filtered_rank_f32")
+    return rank
+
+
+def sim_matrix(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    require_device(a, b)
+    a, b = _rows16(a), _rows16(b)
+    M, d = a.shape
+    N = b.shape[0]
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    check(lib().jmac_sim_matrix_f32(ptr(a), d, ptr(b), d, M, N, d, ptr(c), N, stream()), "jmac_sim_matrix_f32")
+    return c
+
+
+def sim_topk(a: torch.Tensor, b: torch.Tensor, k: int, return_values: bool = False):
+    """Indices [L,k] (int64) of the k most similar rows of b for every row of a (descending; ties -> lower index)."""
+    require_device(a, b)
+    a, b = _rows16(a), _rows16(b)
+    L_, d = a.shape
+    N = b.shape[0]
+    L = lib()
+    idx = torch.empty((L_, k), dtype=torch.int32, device=a.device)
+    val = torch.empty((L_, k), dtype=torch.float32, device=a.device) if return_values else None
+    ws_bytes = int(L.jmac_sim_topk_workspace_bytes(L_, N))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=a.device)
+    check(L.jmac_sim_topk_f32(ptr(a), d, ptr(b), d, L_, N, d, int(k), ptr(val), ptr(idx), ptr(ws), ws_bytes, stream()),
+          "jmac_sim_topk_f32")
+    idx = idx.to(torch.int64)
+    return (idx, val) if return_values else idx
+
+
+def row_topk(s: torch.Tensor, k: int):
+    require_device(s)
+    s = s.contiguous()
+    L_, N = s.shape
+    idx = torch.empty((L_, k), dtype=torch.int32, device=s.device)
+    val = torch.empty((L_, k), dtype=torch.float32, device=s.device)
+    check(lib().jmac_row_topk_f32(ptr(s), N, L_, N, int(k), ptr(val), ptr(idx), stream()), "jmac_row_topk_f32")
+    return val, idx.to(torch.int64)
+
+
+def get_neg(ILL, emb_src: torch.Tensor, emb_dst: torch.Tensor, k: int) -> torch.Tensor:
+    """Same contract as modules/utils/util.py:31-54: flattened [len(ILL)*k] int64 indices into emb_dst."""
+    ill = torch.as_tensor(ILL, dtype=torch.long, device=emb_src.device)
+    return sim_topk(emb_src.index_select(0, ill), emb_dst, k).reshape(-1)
+
+
+def align_entropy(e1: torch.Tensor, e2: torch.Tensor, scale: float = 20.0):
+    """(entropy, row entropies [n1], column entropies [n2]) of softmax(scale * e1 e2^T)."""
+    require_device(e1, e2)
+    e1, e2 = _rows16(e1), _rows16(e2)
+    n1, d = e1.shape
+    n2 = e2.shape[0]
+    L = lib()
+    hr = torch.empty(n1, dtype=torch.float32, device=e1.device)
+    hc = torch.empty(n2, dtype=torch.float32, device=e1.device)
+    ws_bytes = int(L.jmac_softmax_entropy_workspace_bytes(n1, n2))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=e1.device)
+    check(L.jmac_softmax_entropy_f32(ptr(e1), d, ptr(e2), d, n1, n2, d, float(scale), ptr(hr), ptr(hc), ptr(ws), ws_bytes,
+                                     stream()), "jmac_softmax_entropy_f32")
+    return hr.mean() + hc.mean(), hr, hc
+
+
+def masked_row_softmax(s: torch.Tensor, row_mask: Optional[torch.Tensor], col_mask: Optional[torch.Tensor],
+                       fill: float = -1.0, scale: float = 20.0) -> torch.Tensor:
+    require_device(s)
+    s = s.contiguous()
+    n1, n2 = s.shape
+    out = torch.empty_like(s)
+    rm = row_mask.to(torch.uint8).contiguous() if row_mask is not None else None
+    cm = col_mask.to(torch.uint8).contiguous() if col_mask is not None else None
+    check(lib().jmac_masked_row_softmax_f32(ptr(s), n2, n1, n2, ptr(rm), ptr(cm), float(fill), float(scale), ptr(out), n2,
+                                            stream()), "jmac_masked_row_softmax_f32")
+    return out
+
+
+def alignment_quality(emb1: torch.Tensor, emb2: torch.Tensor, list1, list2, scale: float = 20.0):
+    """compute_alignment_quality, train.py:231-259: (entropy, softmax rows [N1,N2], softmax cols [N2,N1]).
+    The O(N*T) python membership scans of :252-253 become boolean masks."""
+    dev = emb1.device
+    l1 = torch.as_tensor(list1, dtype=torch.long, device=dev)
+    l2 = torch.as_tensor(list2, dtype=torch.long, device=dev)
+    entropy, _, _ = align_entropy(emb1.index_select(0, l1), emb2.index_select(0, l2), scale)
+    m1 = torch.zeros(emb1.shape[0], dtype=torch.bool, device=dev)
+    m1[l1] = True
+    m2 = torch.zeros(emb2.shape[0], dtype=torch.bool, device=dev)
+    m2[l2] = True
+    simi = sim_matrix(emb1, emb2)
+    simi_t = sim_matrix(emb2, emb1)
+    return entropy, masked_row_softmax(simi, m1, m2, -1.0, scale), masked_row_softmax(simi_t, m2, m1, -1.0, scale)

@@ -1,0 +1,332 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REFERENCE itself (imported from /root/reference, build
+container only) on seeded inputs and stores inputs + reference outputs as small .npz fixtures.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py          # writes tests/golden/*.npz
+
+Nothing from the reference is copied: it is imported, called, and only arrays are saved.
+Accommodations applied at import time:
+  1. ``torch_scatter`` (third party, absent) -> oracle/_shim/torch_scatter (published algorithm);
+  2. ``np.int`` / ``np.float`` / ``np.bool`` aliases restored (removed in numpy >= 1.24);
+  3. ``train.py`` has a syntax error at line 101 -> its text is read, that one line is repaired in
+     memory, and the module is exec'd (cwd is a temp dir: its Logger mkdirs ``logging/``);
+  4. the DBPv1 variant lives in a second package tree with clashing module names -> generated in a
+     child process with its own sys.path.
+The GPU box never runs this file; it only reads the fixtures.
+"""
+import argparse
+import logging
+import os
+import subprocess
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("JMAC_REFERENCE", "/root/reference")
+
+np.int = int        # noqa  (accommodation 2)
+np.float = float    # noqa
+if not hasattr(np, "bool"):
+    np.bool = bool  # noqa
+
+import torch  # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def _paths(variant):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "oracle", "_shim"))
+    if variant == "dbpv1":
+        sys.path.insert(0, os.path.join(REF, "JMAC_DBPv1"))
+    else:
+        sys.path.insert(0, REF)
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def _save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+# ----------------------------------------------------------------------------------------------
+# graphs
+# ----------------------------------------------------------------------------------------------
+def tiny_graph():
+    # 10 nodes. node 0: hub (6 in-edges incl. duplicate and a self edge); nodes 5,7,9: no in-edge.
+    dst = [0, 0, 0, 0, 0, 0, 1, 2, 2, 3, 4, 4, 6, 8, 8, 8]
+    src = [1, 2, 2, 0, 9, 5, 0, 3, 3, 3, 1, 7, 6, 0, 1, 2]
+    typ = [0, 1, 1, 2, 3, 0, 0, 2, 2, 1, 3, 3, 0, 1, 2, 3]
+    return 10, 4, np.array([dst, src], dtype=np.int64), np.array(typ, dtype=np.int64)
+
+
+def random_graph(rng, n, nr, e, hub_frac=0.2):
+    w = 1.0 / np.arange(1, n + 1) ** 0.9
+    w = w / w.sum()
+    dst = rng.choice(n, size=e, p=w)
+    dst[: int(e * hub_frac)] = rng.integers(0, max(1, n // 50), int(e * hub_frac))
+    src = rng.integers(0, n, e)
+    typ = rng.integers(0, nr, e)
+    # leave the top tenth of ids without in-edges (empty segments at the end, too)
+    dst = np.where(dst >= n - n // 10, dst // 2, dst)
+    perm = rng.permutation(e)
+    return np.stack([dst[perm], src[perm]]).astype(np.int64), typ[perm].astype(np.int64)
+
+
+def ja_slice(limit, bidirectional):
+    import pandas as pd
+    df = pd.read_csv(os.path.join(REF, "datasetdbp5l/kg/ja-train.tsv"), sep="\t", header=None).values
+    df = df[(df[:, 0] < limit) & (df[:, 2] < limit)]
+    h, r, t = df[:, 0], df[:, 1], df[:, 2]
+    if bidirectional:      # src/utils.py:127-149: sender = h|t, receiver = t|h, same relation id
+        ei = np.stack([np.concatenate([h, t]), np.concatenate([t, h])])
+        et = np.concatenate([r, r])
+    else:                  # train.py:130-132: [head, tail]
+        ei = np.stack([h, t])
+        et = r
+    return ei.astype(np.int64), et.astype(np.int64)
+
+
+# ----------------------------------------------------------------------------------------------
+# layer fixtures
+# ----------------------------------------------------------------------------------------------
+def run_layer_case(layer_cls, make_layer, name, n, nr, d, ei, et, seed, x_scale=1.0):
+    """Reference layer fwd (train + eval BN) and bwd on seeded inputs; returns dict of arrays."""
+    import oracle.jmac_oracle as orc
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    layer = make_layer(d)
+    with torch.no_grad():   # non-trivial BN affine so that its grads are exercised
+        layer.bn.weight.copy_(1 + 0.1 * torch.randn(d, generator=g))
+        layer.bn.bias.copy_(0.1 * torch.randn(d, generator=g))
+    X = (torch.randn(n, d, generator=g) * x_scale / np.sqrt(d) * 4).requires_grad_(True)
+    R = (torch.randn(nr, d, generator=g) / np.sqrt(d) * 4).requires_grad_(True)
+    G = torch.randn(n, d, generator=g)
+    edge_index = torch.from_numpy(ei)
+    edge_type = torch.from_numpy(et)
+
+    layer.train()
+    out = layer(X, R, edge_index, edge_type)
+    (out * G).sum().backward()
+    arrays = dict(
+        n=n, nr=nr, d=d, slope=layer.atv_mlp.negative_slope,
+        edge_index=ei, edge_type=et, X=_np(X), R=_np(R), G=_np(G),
+        out_train=_np(out), grad_X=_np(X.grad), grad_R=_np(R.grad),
+        running_mean_after=_np(layer.bn.running_mean), running_var_after=_np(layer.bn.running_var),
+    )
+    for pname, p in layer.named_parameters():
+        arrays["param." + pname] = _np(p)
+        arrays["grad." + pname] = _np(p.grad) if p.grad is not None else np.zeros(p.shape, np.float32)
+
+    # pre-BN neighbour aggregate, captured through the reference's own propagate()
+    with torch.no_grad():
+        rel = torch.cat([R, layer.loop_rel], 0) @ layer.rel_transform_weight1
+        rel = (layer.act_rel(rel) if hasattr(layer, "act_rel") else layer.atv_mlp(rel)) @ layer.rel_transform_weight2
+        norm = layer.compute_norm(edge_index, n)
+        nb = layer.propagate("add", edge_index, x=X, edge_type=edge_type, rel_embed=rel,
+                             edge_norm=norm, mode="in")
+        arrays["nb"] = _np(nb)
+        arrays["rel_transformed"] = _np(rel)
+
+    layer.eval()
+    with torch.no_grad():
+        arrays["out_eval"] = _np(layer(X, R, edge_index, edge_type))
+
+    # cross-check the oracle restatement right here (fails generation if it drifts)
+    p = {k[len("param."):]: torch.from_numpy(v) for k, v in arrays.items() if k.startswith("param.")}
+    rel_act = "relu" if hasattr(layer, "act_rel") else "leaky_relu"
+    o = orc.layer_forward(p, X.detach(), R.detach(), edge_index, edge_type, float(arrays["slope"]),
+                          "sub", rel_act, True)
+    err = (o - out.detach()).abs().max().item()
+    assert err < 5e-6, (name, err)
+    print("  %-18s N=%d E=%d d=%d  oracle-vs-reference max|err| = %.2e" % (name, n, ei.shape[1], d, err))
+    return arrays
+
+
+def gen_root():
+    from src.jmac_model import RelationAwareLayer, JMAC
+    from src.knowledgegraph import KnowledgeGraph
+    from src.validate import CompletionEvaluator
+    from modules.utils.util import get_neg
+    import oracle.jmac_oracle as orc
+
+    args = types.SimpleNamespace(leaky_relu_w=0.05, comp_op="sub")
+    mk = lambda d: RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=args)
+    rng = np.random.default_rng(7)
+
+    print("layer fixtures (reference: src/jmac_model.py RelationAwareLayer)")
+    n, nr, ei, et = tiny_graph()
+    _save("layer_tiny", **run_layer_case(RelationAwareLayer, mk, "tiny", n, nr, 8, ei, et, 1))
+    ei, et = random_graph(rng, 200, 12, 900)
+    _save("layer_rand200", **run_layer_case(RelationAwareLayer, mk, "rand200", 200, 12, 32, ei, et, 2))
+    ei, et = random_graph(rng, 160, 30, 1100)
+    _save("layer_d300", **run_layer_case(RelationAwareLayer, mk, "d300", 160, 30, 300, ei, et, 3))
+    ei, et = ja_slice(1000, bidirectional=False)
+    _save("layer_ja_train", **run_layer_case(RelationAwareLayer, mk, "ja_train", 1000, 961, 32, ei, et, 5))
+    ei, et = ja_slice(1000, bidirectional=True)
+    _save("layer_ja_bidir", **run_layer_case(RelationAwareLayer, mk, "ja_bidir", 1000, 961, 32, ei, et, 6))
+    # no edges at all: every segment empty
+    _save("layer_noedge", **run_layer_case(RelationAwareLayer, mk, "noedge", 17, 3, 12,
+                                           np.zeros((2, 0), np.int64), np.zeros((0,), np.int64), 7))
+
+    # ------------------------------------------------------------------------------------------
+    # model-level fixture: two small KGs in global tables (bases), name info on, 2 GCN layers
+    # ------------------------------------------------------------------------------------------
+    print("model fixture (reference: JMAC.forward_name/get_emb/forward_linkpred/losses, CompletionEvaluator)")
+    torch.manual_seed(11)
+    d, nrel = 48, 9
+    n1, n2 = 130, 110
+    margs = types.SimpleNamespace(dim=d, dropout=0.0, leaky_relu_w=0.05, comp_op="sub", num_gcn_layer=2,
+                                  num_negative=5, margin_align=1.0, margin_completion=5.0, batch_size=40,
+                                  no_name_info=False, device=torch.device("cpu"))
+    name_emb = rng.standard_normal((n1 + n2, 20)).astype(np.float32)
+    model = JMAC(margs, name_emb, 2 * nrel, n1 + n2)
+
+    def kg_triples(n, m):
+        h = rng.integers(0, n, m); r = rng.integers(0, nrel - 1, m); t = rng.integers(0, n, m)
+        return np.unique(np.stack([h, r, t], 1), axis=0)
+
+    tr1 = kg_triples(n1, 420)
+    tr2 = kg_triples(n2, 300)
+    k1 = int(len(tr1) * 0.7); k2 = int(len(tr1) * 0.85)
+    perm = rng.permutation(len(tr1)); tr1 = tr1[perm]
+    kg1 = KnowledgeGraph("aa", tr1[:k1], tr1[k1:k2], tr1[k2:], n1, nrel, False, 0, 0, "cpu")
+    kg1.upper_entity_base, kg1.upper_relation_base = n1, nrel
+    kg2 = KnowledgeGraph("bb", tr2[:200], tr2[200:250], tr2[250:], n2, nrel, True, n1, nrel, "cpu")
+    kg2.upper_entity_base, kg2.upper_relation_base = n1 + n2, 2 * nrel
+
+    def bidir(tr):
+        h, r, t = tr[:, 0], tr[:, 1], tr[:, 2]
+        return np.stack([np.concatenate([h, t]), np.concatenate([t, h])]).astype(np.int64), np.concatenate([r, r]).astype(np.int64)
+
+    kg1.edge_index, kg1.edge_type = bidir(kg1.train_data)
+    kg2.edge_index, kg2.edge_type = bidir(kg2.train_data)
+    e1i, e1t = torch.from_numpy(kg1.edge_index), torch.from_numpy(kg1.edge_type)
+    # train-mode graph for kg2 is single direction (train.py:130-135)
+    e2i = torch.from_numpy(np.stack([kg2.train_data[:, 0], kg2.train_data[:, 2]]).astype(np.int64))
+    e2t = torch.from_numpy(kg2.train_data[:, 1].astype(np.int64))
+    eb1, rb1 = [0, n1], [0, nrel]
+    eb2, rb2 = [n1, n1 + n2], [nrel, 2 * nrel]
+
+    # a few train-mode steps so BN running stats are non-trivial, then eval
+    model.train()
+    with torch.no_grad():
+        for _ in range(2):
+            model.forward_base(e1i, e1t, eb1, rb1)
+            model.forward_base(e2i, e2t, eb2, rb2)
+    model.eval()
+    arrays = {"name_emb": name_emb, "n1": n1, "n2": n2, "nrel": nrel, "d": d,
+              "e1_index": kg1.edge_index, "e1_type": kg1.edge_type, "e2_index": _np(e2i), "e2_type": _np(e2t),
+              "train1": kg1.train_data, "val1": kg1.val_data, "test1": kg1.test_data}
+    for k, v in model.state_dict().items():
+        arrays["state." + k] = _np(v)
+    with torch.no_grad():
+        a1, c1, r1 = model.forward_base(e1i, e1t, eb1, rb1)
+        a2, c2, r2 = model.forward_base(e2i, e2t, eb2, rb2)
+        arrays.update(align1=_np(a1), comp1_l0=_np(c1[0]), comp1_l1=_np(c1[1]), rel1_l0=_np(r1[0]), rel1_l1=_np(r1[1]),
+                      align2=_np(a2), comp2_l1=_np(c2[1]))
+        g1a, g1c = model.get_emb(e1i, e1t, eb1, rb1, pyt=True)
+        g2a, g2c = model.get_emb(e2i, e2t, eb2, rb2, pyt=True)
+        arrays.update(emb1_align=_np(g1a), emb1_comp=_np(g1c), emb2_align=_np(g2a), emb2_comp=_np(g2c))
+        hb = kg1.h_val.tolist(); rb = kg1.r_val.tolist(); tb = kg1.t_val.tolist()
+        dist = model.forward_linkpred(hb, rb, e1i, e1t, list(range(n1)), eb1, rb1)
+        arrays.update(lp_h=np.array(hb), lp_r=np.array(rb), lp_t=np.array(tb), lp_dist=_np(dist))
+        fp, fi = orc.build_filter_csr(hb, rb, kg1.true_tail)
+        arrays.update(filt_ptr=fp, filt_idx=fi)
+        ev = CompletionEvaluator(kg1, model, "cpu", None)
+        lg = logging.getLogger("golden"); lg.setLevel(logging.ERROR)
+        for filt in (False, True):
+            h1, h10, mrr = ev.test(margs, is_val=True, filterr=filt, logger=lg)
+            arrays["eval_filt%d" % int(filt)] = np.array([h1, h10, mrr], dtype=np.float64)
+        # the oracle's rank function reproduces the evaluator's metrics on the reference's distances
+        for filt in (False, True):
+            ranks = orc.filtered_ranks(dist, tb, fp if filt else None, fi if filt else None)
+            got = np.array(orc.ranking_metrics(ranks))
+            assert np.allclose(got, arrays["eval_filt%d" % int(filt)], atol=1e-12), (got, arrays["eval_filt%d" % int(filt)])
+            arrays["ranks_filt%d" % int(filt)] = ranks
+
+    # get_neg / compute_alignment_quality on the normalised embeddings (train.py:183-184, :145)
+    links = np.stack([rng.permutation(n1)[:30], rng.permutation(n2)[:30]], 1)
+    neg_right = get_neg(links[:, 0].tolist(), g1a, g2a, margs.num_negative)
+    neg2_left = get_neg(links[:, 1].tolist(), g2a, g1a, margs.num_negative)
+    arrays.update(links=links, neg_right=_np(neg_right), neg2_left=_np(neg2_left))
+
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd(); os.chdir(tmp)
+    try:
+        src = open(os.path.join(REF, "train.py")).read().split("\n")
+        assert "--no_name_info, action" in src[100]
+        src[100] = src[100].replace("'--no_name_info, action", "'--no_name_info', action")   # accommodation 3
+        train_mod = types.ModuleType("ref_train")
+        train_mod.__dict__["__name__"] = "ref_train"
+        exec(compile("\n".join(src), "train.py", "exec"), train_mod.__dict__)
+    finally:
+        os.chdir(cwd)
+    t1 = rng.permutation(n1)[:25].tolist(); t2 = rng.permutation(n2)[:25].tolist()
+    ent, sm1, sm2 = train_mod.compute_alignment_quality(g1a, g2a, t1, t2)
+    arrays.update(aq_list1=np.array(t1), aq_list2=np.array(t2), aq_entropy=np.float64(ent.item()),
+                  aq_softmax_rows=_np(sm1), aq_softmax_cols=_np(sm2))
+
+    # losses in train mode (dropout p = 0 so they are deterministic), with grads of a few leaves
+    model.train()
+    B, K = margs.batch_size, margs.num_negative
+    trip = torch.from_numpy(kg1.train_data[:B].astype(np.int64))
+    neg = torch.from_numpy(rng.integers(0, n1, (B, K)).astype(np.int64))
+    sub, rel, obj = trip[:, 0], trip[:, 1], trip[:, 2]
+    data = {"batch_h": sub.repeat(K + 1), "batch_r": rel.repeat(K + 1), "batch_t": torch.cat((obj, neg.view(-1)))}
+    pos = np.ones((len(links), K)) * links[:, 0].reshape(-1, 1)
+    pos2 = np.ones((len(links), K)) * links[:, 1].reshape(-1, 1)
+    feed = {"neg_left": pos.reshape(-1), "neg_right": neg_right, "neg2_left": neg2_left, "neg2_right": pos2.reshape(-1),
+            "links": links, "ent_bases1": eb1, "ent_bases2": eb2, "rel_bases1": rb1, "rel_bases2": rb2}
+    bn_before = {k: _np(v) for k, v in model.state_dict().items() if "running" in k}
+    model.zero_grad()
+    closs = model.completion_loss(data, e1i, e1t, e2i, e2t, feed, True)
+    closs.backward()
+    arrays.update(batch_h=_np(data["batch_h"]), batch_r=_np(data["batch_r"]), batch_t=_np(data["batch_t"]),
+                  completion_loss=np.float64(closs.item()),
+                  closs_grad_ent=_np(model.ent_init_att_completion.grad),
+                  closs_grad_w_att=_np(model.conv1_completion.w_att.grad),
+                  closs_grad_a_att=_np(model.conv1_completion.a_att.grad),
+                  closs_grad_rel=_np(model.rel_init_att_completion.grad))
+    for k, v in bn_before.items():
+        arrays["bn_before." + k] = v
+    model.load_state_dict({**model.state_dict(), **{k: torch.from_numpy(v) for k, v in bn_before.items()}})
+    model.zero_grad()
+    aloss = model.alignment_loss(feed, e1i, e1t, e2i, e2t)
+    aloss.backward()
+    arrays.update(alignment_loss=np.float64(aloss.item()),
+                  aloss_grad_name_linear=_np(model.name_linear.grad),
+                  aloss_grad_conv2_gcn=_np(model.conv2_alignment.gcn_weight.grad),
+                  aloss_grad_ent=_np(model.ent_init_att_completion.grad))
+    _save("model_small", **arrays)
+
+
+def gen_dbpv1():
+    from models.jmac_model import RelationalAwareLayer
+    args = types.SimpleNamespace(leaky_relu_w=0.05, opn="sub")
+    mk = lambda d: RelationalAwareLayer(d, d, 14, rel_dim=d, act=torch.tanh, args=args)
+    rng = np.random.default_rng(21)
+    print("layer fixture (reference: JMAC_DBPv1/models/jmac_model.py RelationalAwareLayer)")
+    ei, et = random_graph(rng, 180, 14, 800)
+    _save("layer_dbpv1", **run_layer_case(RelationalAwareLayer, mk, "dbpv1", 180, 14, 40, ei, et, 8))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", default="all", choices=["all", "root", "dbpv1"])
+    a = ap.parse_args()
+    if a.variant == "all":
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+        for v in ("root", "dbpv1"):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--variant", v], env=env)
+    else:
+        _paths(a.variant)
+        {"root": gen_root, "dbpv1": gen_dbpv1}[a.variant]()

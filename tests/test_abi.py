@@ -1,0 +1,70 @@
+"""CPU: the C-ABI library loads, exports every symbol include/jmac_hip.h declares, validates arguments
+before touching a device, and the product path refuses to run without a HIP device (no CPU fallback)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import jmac_amd
+from jmac_amd import _lib
+
+
+def test_library_exports_every_declared_symbol():
+    names = _lib.header_symbols()
+    assert len(names) >= 25
+    L = _lib.lib()
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(_lib._SIGS) == set(names)
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(names) <= exported
+
+
+def test_argument_validation_needs_no_device():
+    L = _lib.lib()
+    assert L.jmac_version() >= 100
+    assert L.jmac_l1_score_f32(None, 4, None, 4, -1, 3, 4, None, 4, 0, None) == -1          # negative size
+    assert L.jmac_l1_score_f32(None, 4, None, 4, 2, 3, 4, None, 4, 0, None) == -1           # null pointers
+    assert L.jmac_sim_matrix_f32(ctypes.c_void_p(16), 3, ctypes.c_void_p(16), 4, 2, 2, 4, ctypes.c_void_p(16), 2, None) == -2
+    assert L.jmac_csr_build(None, None, -5, 3, None, None, None, None, None, 0, None) == -1
+    assert b"workspace" in L.jmac_strerror(-3)
+    assert L.jmac_items_max(10, 100, 8) == 10 + 12 + 1
+    assert L.jmac_rel_attn_fwd_workspace_bytes(4, 300) >= 4 * 300 * 4 + 32
+
+
+def test_no_cpu_fallback():
+    from jmac_amd.layer import RelationAwareLayer
+    from util import make_args
+    layer = RelationAwareLayer(8, 8, 8, act=torch.tanh, args=make_args())
+    x, r = torch.randn(5, 8), torch.randn(3, 8)
+    ei = torch.tensor([[0, 1], [1, 2]])
+    with pytest.raises(_lib.JmacError):
+        layer(x, r, ei, torch.tensor([0, 1]))
+    from jmac_amd import scoring
+    with pytest.raises(_lib.JmacError):
+        scoring.l1_scores(torch.randn(2, 8), torch.randn(3, 8))
+
+
+def test_product_never_imports_oracle():
+    root = os.path.dirname(os.path.abspath(jmac_amd.__file__))
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dp, f)).read()
+                assert "oracle" not in text.replace("# oracle", ""), os.path.join(dp, f)
+
+
+def test_state_dict_keys_match_reference():
+    from util import load_golden, make_args
+    from jmac_amd.model import JMAC
+    g = load_golden("model_small")
+    ref_keys = sorted(k[len("state."):] for k in g if k.startswith("state."))
+    args = make_args(dim=int(g["d"]), dropout=0.0, num_gcn_layer=2, num_negative=5, margin_align=1.0,
+                     margin_completion=5.0, batch_size=40, no_name_info=False, device="cpu")
+    m = JMAC(args, g["name_emb"], 2 * int(g["nrel"]), int(g["n1"]) + int(g["n2"]))
+    assert sorted(m.state_dict().keys()) == ref_keys
+    m.load_state_dict({k: torch.from_numpy(g["state." + k]) for k in ref_keys}, strict=True)

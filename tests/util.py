@@ -1,0 +1,56 @@
+"""Shared helpers for the parity tests."""
+import os
+import types
+
+import numpy as np
+import torch
+
+from conftest import load_golden  # noqa: F401
+
+LAYER_CASES = ["layer_tiny", "layer_rand200", "layer_d300", "layer_ja_train", "layer_ja_bidir", "layer_noedge"]
+
+
+def layer_params(g, device="cpu"):
+    return {k[len("param."):]: torch.from_numpy(v).to(device) for k, v in g.items() if k.startswith("param.")}
+
+
+def layer_grads(g):
+    return {k[len("grad."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("grad.")}
+
+
+def t(a, device="cpu"):
+    return torch.from_numpy(np.asarray(a)).to(device)
+
+
+def rel_err(a, b):
+    """max |a-b| / max(|b|) -- the '1e-4 relative' of BASELINE.json north_star."""
+    a = torch.as_tensor(a, dtype=torch.float64).cpu()
+    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    denom = max(b.abs().max().item(), 1e-30)
+    return ((a - b).abs().max().item()) / denom
+
+
+def make_args(slope=0.05, comp_op="sub", **kw):
+    return types.SimpleNamespace(leaky_relu_w=slope, comp_op=comp_op, opn=comp_op, **kw)
+
+
+def random_graph(rng, n, nr, e, hub=None):
+    w = 1.0 / np.arange(1, n + 1) ** 0.9
+    dst = rng.choice(n, size=e, p=w / w.sum())
+    if hub is not None:
+        dst[: hub] = 3                      # one destination with `hub` in-edges (forces split segments)
+    src = rng.integers(0, n, e)
+    typ = rng.integers(0, nr, e)
+    p = rng.permutation(e)
+    return np.stack([dst[p], src[p]]).astype(np.int64), typ[p].astype(np.int64)
+
+
+def assert_close(got, ref, rtol, atol=1e-6, what=""):
+    """|got-ref|_max <= rtol*|ref|_max + atol.  atol covers quantities that are mathematically zero
+    (e.g. d loss/d loop_rel under train-mode BN: a constant row shift cancels in the batch mean)."""
+    got = torch.as_tensor(got, dtype=torch.float64).cpu()
+    ref = torch.as_tensor(ref, dtype=torch.float64).cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs().max().item() if ref.numel() else 0.0
+    bound = rtol * (ref.abs().max().item() if ref.numel() else 0.0) + atol
+    assert err <= bound, "%s: max|err| %.3e > %.3e" % (what, err, bound)
