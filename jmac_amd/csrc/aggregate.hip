@@ -731,7 +731,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
                                                   dim3(kBlock), 0, st, c, dRR, lddrr));
         if (by_rel->n_splits_max > 0)
             hipLaunchKernelGGL(sum_parts_kernel, dim3(persist_grid(by_rel->n_splits_max)), dim3(kBlock), 0, st, by_rel->splits,
-                               by_rel->counts, c.part, 2 * D4, -1.f, dRR, lddrr, nullptr, (int64_t)0, 0, 0.f, 0);
+                               by_rel->counts, c.part, 2 * D4, 1.f, dRR, lddrr, nullptr, (int64_t)0, 0, 0.f, 0);
     }
     if (loop_rel >= 0 && N > 0) {
         // pass C wrote zeros (mode 1) / the fill wrote zeros (mode 0) into dRz[loop]: overwrite it

@@ -11,35 +11,34 @@ constexpr int kWave = 64;
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
-// ---- cross-lane reductions: 4 fused v_add_f32_dpp + v_permlane16_swap + v_permlane32_swap --------
-#define JMAC_DPP_ADD(v, ctrl)                                                                            \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
-#define JMAC_DPP_MAX(v, ctrl)                                                                            \
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true)))
+// ---- cross-lane reductions -----------------------------------------------------------------------
+// xor-butterfly inside each 16-lane row with 4 fused v_*_dpp, then the gfx9 row_bcast:15 / row_bcast:31
+// steps fold the four rows into lane 63, which v_readlane broadcasts through an SGPR.
+// (v_permlane{16,32}_swap would also do the cross-row steps, but hipcc 7.2 folds r[0] op r[1] of
+//  permlane*_swap(x, x) into x op x -- wrong results -- so it is not used.)
+#define JMAC_DPP(v, old, ctrl, rmask)                                                                   \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)),       \
+                                                          __builtin_bit_cast(int, v), ctrl, rmask, 0xF, false))
 
-// all 64 lanes receive the sum
+// every lane receives the sum over the 64 lanes (wave-uniform result)
 __device__ __forceinline__ float wave_sum(float v) {
-    JMAC_DPP_ADD(v, 0xB1);    // quad_perm [1,0,3,2]
-    JMAC_DPP_ADD(v, 0x4E);    // quad_perm [2,3,0,1]
-    JMAC_DPP_ADD(v, 0x141);   // row_half_mirror
-    JMAC_DPP_ADD(v, 0x140);   // row_mirror
-    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    v = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
-    auto q = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    v = __builtin_bit_cast(float, q[0]) + __builtin_bit_cast(float, q[1]);
-    return v;
+    v += JMAC_DPP(v, 0.f, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+    v += JMAC_DPP(v, 0.f, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+    v += JMAC_DPP(v, 0.f, 0x141, 0xF);   // row_half_mirror
+    v += JMAC_DPP(v, 0.f, 0x140, 0xF);   // row_mirror      -> every lane holds its row's sum
+    v += JMAC_DPP(v, 0.f, 0x142, 0xA);   // row_bcast:15 into rows 1,3
+    v += JMAC_DPP(v, 0.f, 0x143, 0xC);   // row_bcast:31 into rows 2,3 -> lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-    JMAC_DPP_MAX(v, 0xB1);
-    JMAC_DPP_MAX(v, 0x4E);
-    JMAC_DPP_MAX(v, 0x141);
-    JMAC_DPP_MAX(v, 0x140);
-    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    v = fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-    auto q = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    v = fmaxf(__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, q[1]));
-    return v;
+    v = fmaxf(v, JMAC_DPP(v, -INFINITY, 0xB1, 0xF));
+    v = fmaxf(v, JMAC_DPP(v, -INFINITY, 0x4E, 0xF));
+    v = fmaxf(v, JMAC_DPP(v, -INFINITY, 0x141, 0xF));
+    v = fmaxf(v, JMAC_DPP(v, -INFINITY, 0x140, 0xF));
+    v = fmaxf(v, JMAC_DPP(v, -INFINITY, 0x142, 0xA));
+    v = fmaxf(v, JMAC_DPP(v, -INFINITY, 0x143, 0xC));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ int wave_sum_i(int v) {

@@ -1,0 +1,57 @@
+"""GPU: graph ingest (jmac_csr_build / jmac_group_build / jmac_items_build) -- bit-exact index work."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from util import random_graph
+
+
+def _csr_ref(ei, et, n):
+    order = np.argsort(ei[0], kind="stable")
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, ei[0] + 1, 1)
+    return np.cumsum(rowptr), ei[1][order], et[order], order
+
+
+@pytest.mark.parametrize("n,nr,e,chunk", [(50, 5, 400, 16), (1000, 40, 20000, 64), (7, 2, 0, 8), (3000, 961, 9000, 256)])
+def test_csr_and_schedules(n, nr, e, chunk):
+    from jmac_amd.graph import RelGraph
+    rng = np.random.default_rng(n + e)
+    ei, et = random_graph(rng, n, nr, e, hub=min(e, 5 * chunk + 3) if e else None) if e else (np.zeros((2, 0), np.int64), np.zeros(0, np.int64))
+    g = RelGraph(torch.from_numpy(ei).cuda(), torch.from_numpy(et).cuda(), n, nr + 1, chunk)
+    rowptr, col, typ, perm = _csr_ref(ei, et, n)
+    assert (g.rowptr.cpu().numpy() == rowptr).all()
+    if e:
+        assert (g.perm[:e].cpu().numpy() == perm).all()          # stable
+        assert (g.col[:e].cpu().numpy() == col).all()
+        assert (g.etype[:e].cpu().numpy() == typ).all()
+    # schedule: items tile every row exactly, chunks <= chunk, partial slots consecutive
+    cnt = g.by_dst.counts.cpu().numpy()
+    items = g.by_dst.items.cpu().numpy()[: cnt[0]]
+    splits = g.by_dst.splits.cpu().numpy()[: cnt[1]]
+    assert cnt[0] <= g.by_dst.n_items_max and cnt[1] <= g.by_dst.n_splits_max and cnt[2] <= g.by_dst.n_parts_max
+    cover = np.zeros(max(e, 1), dtype=np.int64)
+    seen_rows = np.zeros(n, dtype=np.int64)
+    for seg, b, en, ps in items:
+        assert rowptr[seg] <= b <= en <= rowptr[seg + 1] and en - b <= chunk
+        cover[b:en] += 1
+        seen_rows[seg] += 1
+        deg = rowptr[seg + 1] - rowptr[seg]
+        assert (ps < 0) == (deg <= chunk)
+    assert (cover[:e] == 1).all() and (seen_rows >= 1).all()
+    for seg, p0, nch, _ in splits:
+        mine = items[items[:, 0] == seg]
+        assert len(mine) == nch and (np.sort(mine[:, 3]) == np.arange(p0, p0 + nch)).all()
+    # backward views
+    g.ensure_backward_views()
+    if e:
+        assert (g.dst_of_slot.cpu().numpy() == ei[0][perm]).all()
+        so = g.by_src.order[:e].cpu().numpy()
+        assert (so == np.argsort(col, kind="stable")).all()
+        sp = g.by_src.ptr.cpu().numpy()
+        assert (np.diff(sp) == np.bincount(col, minlength=n)).all()
+        to = g.by_rel.order[:e].cpu().numpy()
+        assert (to == np.argsort(typ, kind="stable")).all()
+        assert (np.diff(g.by_rel.ptr.cpu().numpy()) == np.bincount(typ, minlength=nr + 1)).all()

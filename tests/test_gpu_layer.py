@@ -1,0 +1,163 @@
+"""GPU parity: the HIP RelationAwareLayer (through the C ABI) against the golden vectors captured from
+the reference and against the CPU oracle on seeded random graphs.  Tolerance: 1e-4 relative
+(BASELINE.json north_star), fp32."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle.jmac_oracle as orc
+from util import LAYER_CASES, assert_close, layer_grads, layer_params, load_golden, make_args, random_graph, rel_err, t
+
+RTOL = 1e-4
+
+
+def _make_layer(g, cls_name="RelationAwareLayer", mode=1, chunk=None):
+    from jmac_amd import layer as jl
+    d = int(g["d"])
+    args = make_args(float(g["slope"]))
+    if cls_name == "RelationalAwareLayer":
+        lay = jl.RelationalAwareLayer(d, d, int(g["nr"]), rel_dim=d, act=torch.tanh, args=args)
+    else:
+        lay = jl.RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=args)
+    sd = {k: v for k, v in layer_params(g).items()}
+    missing = lay.load_state_dict(sd, strict=False)
+    assert set(missing.missing_keys) <= {"bn.running_mean", "bn.running_var", "bn.num_batches_tracked"}
+    lay.bwd_mode = mode
+    if chunk:
+        lay.chunk = chunk
+    return lay.cuda()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("case", LAYER_CASES + ["layer_dbpv1"])
+def test_layer_matches_reference_golden(case, mode):
+    g = load_golden(case)
+    lay = _make_layer(g, "RelationalAwareLayer" if case == "layer_dbpv1" else "RelationAwareLayer", mode,
+                      chunk=4 if case == "layer_tiny" else None)
+    X = t(g["X"], "cuda").requires_grad_(True)
+    R = t(g["R"], "cuda").requires_grad_(True)
+    ei, et = t(g["edge_index"], "cuda"), t(g["edge_type"], "cuda")
+    lay.train()
+    with torch.no_grad():
+        pre = lay.pre_bn(X, R, ei, et)
+    out = lay(X, R, ei, et)
+    assert_close(out, g["out_train"], RTOL, 1e-6, "out_train")
+    assert_close(lay.bn.running_mean, g["running_mean_after"], RTOL, 1e-7, "running_mean")
+    assert_close(lay.bn.running_var, g["running_var_after"], RTOL, 1e-7, "running_var")
+    (out * t(g["G"], "cuda")).sum().backward()
+    gscale = float(np.abs(g["grad_R"]).max()) if g["grad_R"].size else 0.0
+    assert_close(X.grad, g["grad_X"], RTOL, 1e-6, "grad_X")
+    assert_close(R.grad, g["grad_R"], RTOL, 1e-6, "grad_R")
+    for name, ref in layer_grads(g).items():
+        got = dict(lay.named_parameters())[name].grad
+        got = got if got is not None else torch.zeros_like(ref)
+        atol = 1e-4 * gscale + 1e-6 if name == "loop_rel" else 1e-6
+        assert_close(got, ref, RTOL, atol, "grad " + name)
+    lay.eval()
+    with torch.no_grad():
+        assert_close(lay(X, R, ei, et), g["out_eval"], RTOL, 1e-6, "out_eval")
+    # the fused kernel output before BN equals the oracle's (nb + self)/2
+    _, _, pre_ref = orc.layer_pre_bn(layer_params(g), t(g["X"]), t(g["R"]), t(g["edge_index"]), t(g["edge_type"]),
+                                     float(g["slope"]), "sub", "relu" if case == "layer_dbpv1" else "leaky_relu")
+    assert_close(pre, pre_ref, RTOL, 1e-7, "pre_bn")
+
+
+def _oracle_case(n, nr, d, e, seed, hub=None, slope=0.05):
+    rng = np.random.default_rng(seed)
+    ei, et = random_graph(rng, n, nr, e, hub=hub)
+    gen = torch.Generator().manual_seed(seed)
+    X = torch.randn(n, d, generator=gen) * (4 / np.sqrt(d))
+    R = torch.randn(nr, d, generator=gen) * (4 / np.sqrt(d))
+    G = torch.randn(n, d, generator=gen)
+    return torch.from_numpy(ei), torch.from_numpy(et), X, R, G
+
+
+@pytest.mark.parametrize("n,nr,d,e,hub,chunk", [
+    (600, 25, 300, 5000, 700, 64),      # d=300 (BASELINE dim), a hub split into 11 chunks
+    (500, 17, 256, 4000, 300, 128),     # d=256 (reference default)
+    (300, 9, 128, 2500, None, 256),
+    (257, 6, 20, 1500, 200, 32),        # NCH=1, tiny d
+    (200, 8, 512, 900, None, 256),      # max d
+    (150, 5, 30, 700, 100, 16),         # d % 4 != 0 -> host pads to 32
+])
+@pytest.mark.parametrize("mode", [1, 0])
+def test_layer_matches_oracle_random(n, nr, d, e, hub, chunk, mode):
+    """Oracle evaluated in float64: an fp32 CPU evaluation can land on the other side of a LeakyReLU kink
+    (observed at d=512: fp32-CPU vs f64 differ by 2e-2 in grad w_att while HIP-fp32 vs f64 agree to 1e-6)."""
+    from jmac_amd.layer import RelationAwareLayer
+    ei, et, X, R, G = _oracle_case(n, nr, d, e, seed=n + d, hub=hub)
+    torch.manual_seed(d)
+    lay = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())
+    with torch.no_grad():
+        lay.bn.weight.uniform_(0.5, 1.5)
+        lay.bn.bias.uniform_(-0.2, 0.2)
+    f64 = torch.float64
+    p = {k: v.detach().clone().to(f64).requires_grad_(True) for k, v in lay.named_parameters()}
+    Xc, Rc = X.clone().to(f64).requires_grad_(True), R.clone().to(f64).requires_grad_(True)
+    ref = orc.layer_forward(p, Xc, Rc, ei, et, 0.05, "sub", "leaky_relu", True,
+                            torch.zeros(d, dtype=f64), torch.ones(d, dtype=f64))
+    (ref * G.to(f64)).sum().backward()
+    lay = lay.cuda()
+    lay.bwd_mode, lay.chunk = mode, chunk
+    Xg, Rg = X.cuda().requires_grad_(True), R.cuda().requires_grad_(True)
+    out = lay(Xg, Rg, ei.cuda(), et.cuda())
+    assert_close(out, ref, RTOL, 1e-6, "out")
+    (out * G.cuda()).sum().backward()
+    assert_close(Xg.grad, Xc.grad, RTOL, 1e-6, "grad_X")
+    assert_close(Rg.grad, Rc.grad, RTOL, 1e-6, "grad_R")
+    gscale = Rc.grad.abs().max().item()
+    for name, prm in lay.named_parameters():
+        atol = 1e-4 * gscale + 1e-6 if name == "loop_rel" else 1e-6
+        assert_close(prm.grad, p[name].grad, RTOL, atol, "grad " + name)
+
+
+def test_deterministic_backward_is_bitwise_reproducible():
+    from jmac_amd.layer import RelationAwareLayer
+    ei, et, X, R, G = _oracle_case(400, 12, 300, 6000, seed=5, hub=500)
+    torch.manual_seed(0)
+    lay = RelationAwareLayer(300, 300, rel_dim=300, act=torch.tanh, args=make_args()).cuda()
+    lay.chunk = 64
+    grads = []
+    for _ in range(2):
+        Xg, Rg = X.cuda().requires_grad_(True), R.cuda().requires_grad_(True)
+        lay.zero_grad()
+        (lay(Xg, Rg, ei.cuda(), et.cuda()) * G.cuda()).sum().backward()
+        grads.append([Xg.grad.clone(), Rg.grad.clone(), lay.w_att.grad.clone(), lay.a_att.grad.clone()])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+
+
+def test_edge_permutation_invariance_and_chunking():
+    """Same multiset of edges in a different COO order / different chunk size -> same result (to rounding)."""
+    from jmac_amd.layer import RelationAwareLayer
+    ei, et, X, R, _ = _oracle_case(300, 7, 64, 3000, seed=9, hub=400)
+    torch.manual_seed(1)
+    lay = RelationAwareLayer(64, 64, rel_dim=64, act=torch.tanh, args=make_args()).cuda().eval()
+    outs = []
+    for chunk, perm in ((256, None), (16, torch.randperm(3000)), (1024, torch.randperm(3000))):
+        lay.chunk = chunk
+        e2, t2 = (ei, et) if perm is None else (ei[:, perm], et[perm])
+        with torch.no_grad():
+            outs.append(lay.pre_bn(X.cuda(), R.cuda(), e2.cuda().contiguous(), t2.cuda().contiguous()))
+    assert_close(outs[1], outs[0], 1e-5, 1e-7)
+    assert_close(outs[2], outs[0], 1e-5, 1e-7)
+
+
+def test_comp_op_mult_runs_on_scatter_kernels():
+    from jmac_amd.layer import RelationAwareLayer
+    ei, et, X, R, G = _oracle_case(120, 5, 16, 500, seed=3)
+    torch.manual_seed(2)
+    lay = RelationAwareLayer(16, 16, rel_dim=16, act=torch.tanh, args=make_args(comp_op="mult"))
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in lay.named_parameters()}
+    Xc = X.clone().requires_grad_(True)
+    ref = orc.layer_forward(p, Xc, R, ei, et, 0.05, "mult", "leaky_relu", True)
+    (ref * G).sum().backward()
+    lay = lay.cuda()
+    Xg = X.cuda().requires_grad_(True)
+    out = lay(Xg, R.cuda(), ei.cuda(), et.cuda())
+    assert_close(out, ref, RTOL, 1e-6)
+    (out * G.cuda()).sum().backward()
+    assert_close(Xg.grad, Xc.grad, RTOL, 1e-6)
+    assert_close(lay.w_att.grad, p["w_att"].grad, RTOL, 1e-6)

@@ -1,0 +1,139 @@
+"""GPU parity: scoring kernels (L1 score, filtered rank, MFMA similarity, top-k, entropy, masked softmax,
+torch_scatter trio) against the oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle.jmac_oracle as orc
+from util import assert_close, load_golden, t
+
+
+@pytest.mark.parametrize("B,N,d", [(37, 301, 48), (128, 1000, 300), (5, 64, 7), (1000, 2111, 256)])
+def test_l1_scores(B, N, d):
+    from jmac_amd import scoring
+    gen = torch.Generator().manual_seed(B + N)
+    er, tab = torch.randn(B, d, generator=gen), torch.randn(N, d, generator=gen)
+    ref = torch.cdist(er.double(), tab.double(), p=1)
+    out = scoring.l1_scores(er.cuda(), tab.cuda())
+    assert_close(out, ref, 1e-5)
+    out2 = scoring.l1_scores(er.cuda(), tab.cuda(), out=out.clone(), accumulate=True)
+    assert_close(out2, 2 * ref, 1e-5)
+
+
+def test_linkpred_and_ranks_match_reference_golden():
+    from jmac_amd import scoring
+    g = load_golden("model_small")
+    comp = [t(g["comp1_l0"], "cuda"), t(g["comp1_l1"], "cuda")]
+    rel = [t(g["rel1_l0"], "cuda"), t(g["rel1_l1"], "cuda")]
+    dist = scoring.linkpred_dist(comp, rel, g["lp_h"].tolist(), g["lp_r"].tolist())
+    assert_close(dist, g["lp_dist"], 1e-5)
+    gold = g["lp_t"]
+    fp, fi = t(g["filt_ptr"], "cuda"), t(g["filt_idx"], "cuda")
+    # bit-exact index work: the kernel's ranks equal the oracle's rank function on the SAME distances
+    for filt in (False, True):
+        got = scoring.filtered_rank(dist, gold, fp if filt else None, fi if filt else None).cpu().numpy()
+        want = orc.filtered_ranks(dist.cpu(), gold.tolist(), g["filt_ptr"] if filt else None, g["filt_idx"] if filt else None)
+        assert (got == want).all()
+        # and the reference's own ranks wherever the gold's margin to its neighbours exceeds rounding
+        ref = g["ranks_filt%d" % int(filt)]
+        d_ref = g["lp_dist"]
+        gd = d_ref[np.arange(len(gold)), gold][:, None]
+        gap = np.abs(d_ref - gd)
+        gap[np.arange(len(gold)), gold] = np.inf
+        safe = gap.min(1) > 1e-4 * np.abs(gd[:, 0])
+        assert safe.mean() > 0.5 and (got[safe] == ref[safe]).all()
+        assert np.allclose(orc.ranking_metrics(got), g["eval_filt%d" % int(filt)], atol=0.02)
+
+
+def test_filtered_rank_ties_and_random():
+    from jmac_amd import scoring
+    rng = np.random.default_rng(0)
+    B, N = 64, 777
+    dist = torch.from_numpy(rng.integers(0, 40, (B, N)).astype(np.float32))     # many exact ties
+    gold = rng.integers(0, N, B)
+    ptr = [0]
+    idx = []
+    for b in range(B):
+        f = rng.choice(N, rng.integers(0, 30), replace=False)
+        idx.extend(f.tolist())
+        ptr.append(len(idx))
+    ptr, idx = np.array(ptr, np.int32), np.array(idx + [0], np.int32)
+    got = scoring.filtered_rank(dist.cuda(), gold, t(ptr, "cuda"), t(idx, "cuda")).cpu().numpy()
+    assert (got == orc.filtered_ranks(dist, gold.tolist(), ptr, idx)).all()
+
+
+@pytest.mark.parametrize("M,N,d", [(33, 70, 8), (300, 1000, 300), (129, 257, 48), (2264, 3000, 256)])
+def test_sim_matrix_mfma(M, N, d):
+    from jmac_amd import scoring
+    gen = torch.Generator().manual_seed(M)
+    a, b = torch.randn(M, d, generator=gen), torch.randn(N, d, generator=gen)
+    # exact-integer check of the MFMA operand / accumulator maps with an asymmetric B
+    ai = torch.randint(-3, 4, (M, d), generator=gen).float()
+    bi = (torch.arange(N).view(-1, 1) % 5 + torch.arange(d).view(1, -1) % 3).float()
+    assert torch.equal(scoring.sim_matrix(ai.cuda(), bi.cuda()).cpu(), ai @ bi.t())
+    assert_close(scoring.sim_matrix(a.cuda(), b.cuda()), a.double() @ b.double().t(), 1e-5)
+
+
+def test_get_neg_matches_reference_golden():
+    from jmac_amd import scoring
+    g = load_golden("model_small")
+    e1, e2 = t(g["emb1_align"], "cuda"), t(g["emb2_align"], "cuda")
+    links = g["links"]
+    k = g["neg_right"].shape[0] // len(links)
+    assert (scoring.get_neg(links[:, 0].tolist(), e1, e2, k).cpu().numpy() == g["neg_right"]).all()
+    assert (scoring.get_neg(links[:, 1].tolist(), e2, e1, k).cpu().numpy() == g["neg2_left"]).all()
+
+
+@pytest.mark.parametrize("L,N,k", [(50, 1000, 25), (7, 30000, 25), (3, 40, 40)])
+def test_topk_bit_exact_with_ties(L, N, k):
+    from jmac_amd import scoring
+    gen = torch.Generator().manual_seed(N)
+    s = torch.randint(0, 50, (L, N), generator=gen).float()          # heavy ties -> exercises lowest-index rule
+    val, idx = scoring.row_topk(s.cuda(), k)
+    want = orc.topk_lowest_index(s, k)
+    assert (idx.cpu() == want).all()
+    assert torch.equal(val.cpu(), s.gather(1, want))
+    s2 = torch.randn(L, N, generator=gen)
+    _, idx2 = scoring.row_topk(s2.cuda(), k)
+    assert (idx2.cpu() == s2.topk(k, dim=1)[1]).all()
+
+
+def test_alignment_quality_matches_reference_golden():
+    from jmac_amd import scoring
+    g = load_golden("model_small")
+    e1, e2 = t(g["emb1_align"], "cuda"), t(g["emb2_align"], "cuda")
+    ent, sm1, sm2 = scoring.alignment_quality(e1, e2, g["aq_list1"].tolist(), g["aq_list2"].tolist())
+    assert abs(ent.item() - float(g["aq_entropy"])) < 1e-4 * abs(float(g["aq_entropy"]))
+    assert_close(sm1, g["aq_softmax_rows"], 1e-4)
+    assert_close(sm2, g["aq_softmax_cols"], 1e-4)
+    gen = torch.Generator().manual_seed(4)
+    a = torch.nn.functional.normalize(torch.randn(500, 300, generator=gen))
+    b = torch.nn.functional.normalize(torch.randn(700, 300, generator=gen))
+    e, hr, hc = scoring.align_entropy(a.cuda(), b.cuda())
+    eo, hro, hco = orc.alignment_entropy(a, b)
+    assert_close(hr, hro, 1e-4) and assert_close(hc, hco, 1e-4)
+    assert abs(e.item() - eo.item()) < 1e-4 * eo.item()
+
+
+def test_scatter_trio_matches_oracle():
+    from jmac_amd import scatter as js
+    gen = torch.Generator().manual_seed(8)
+    E, d, N = 5000, 24, 300
+    src = torch.randn(E, d, generator=gen)
+    idx = torch.randint(0, N - 20, (E,), generator=gen)
+    assert_close(js.scatter_add(src.cuda(), idx.cuda(), dim=0, dim_size=N), orc.scatter_sum(src, idx, N), 1e-5)
+    assert_close(js.scatter(src.cuda(), idx.cuda(), dim=0, out=None, dim_size=N, reduce="sum"), orc.scatter_sum(src, idx, N), 1e-5)
+    sc = src[:, :1].contiguous()
+    sg = sc.cuda().requires_grad_(True)
+    so = sc.clone().requires_grad_(True)
+    y = js.scatter_softmax(sg, idx.cuda(), dim=0)
+    yo = orc.scatter_softmax(so, idx, N)
+    assert_close(y, yo, 1e-5)
+    w = torch.randn(E, 1, generator=gen)
+    (y * w.cuda()).sum().backward()
+    (yo * w).sum().backward()
+    assert_close(sg.grad, so.grad, 1e-4, 1e-7)
+    deg = js.scatter_add(torch.ones(E).cuda(), idx.cuda(), dim=0, dim_size=N)
+    assert torch.equal(deg.cpu(), torch.bincount(idx, minlength=N).float())
