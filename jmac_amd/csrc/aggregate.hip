@@ -534,13 +534,30 @@ __global__ __launch_bounds__(kBlock) void colsum_partial_kernel(const float* __r
     }
 }
 
-__global__ __launch_bounds__(kBlock) void colsum_final_kernel(const float* __restrict__ partial, int nparts, int W4,
-                                                              float scale, float* __restrict__ outp) {
-    const int tid = blockIdx.x * kBlock + threadIdx.x;
-    if (tid < W4) {
-        float4 acc = f4zero();
-        for (int p = 0; p < nparts; ++p) acc = add4(acc, ld4(partial + ((int64_t)p * W4 + tid) * 4));
-        st4(outp + tid * 4, mul4(acc, scale));
+// out[c] = scale * sum_p partial[p][c]: 64 columns x 16 row lanes per 1024-thread block
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ partial, int nparts, int W, float scale,
+                                                           float* __restrict__ outp) {
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < W) {
+        int p = rl;
+        for (; p + 48 < nparts; p += 64) {
+            a0 += partial[(int64_t)p * W + c];
+            a1 += partial[(int64_t)(p + 16) * W + c];
+            a2 += partial[(int64_t)(p + 32) * W + c];
+            a3 += partial[(int64_t)(p + 48) * W + c];
+        }
+        for (; p < nparts; p += 16) a0 += partial[(int64_t)p * W + c];
+    }
+    red[rl][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rl == 0 && c < W) {
+        float s = red[0][threadIdx.x];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) s += red[r][threadIdx.x];
+        outp[c] = s * scale;
     }
 }
 
@@ -580,6 +597,12 @@ inline unsigned persist_grid(int64_t n_items_max) {
     }
 
 }  // namespace
+
+namespace jmac {
+void launch_reduce_rows(const float* partial, int nparts, int W, float scale, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((W + 63) / 64)), dim3(1024), 0, st, partial, nparts, W, scale, out);
+}
+}  // namespace jmac
 
 extern "C" {
 
@@ -699,8 +722,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
         JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 1>), dim3(gridA), dim3(kBlock), 0, st, a));
     }
     // a_att gradient: deterministic reduction of the per-block partial rows
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((D4 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a.da_part, (int)gridA, D4,
-                       1.f, da);
+    launch_reduce_rows(a.da_part, (int)gridA, (int)d, 1.f, da, st);
     if (by_dst->n_splits_max > 0)
         hipLaunchKernelGGL(sum_parts_kernel, dim3(persist_grid(by_dst->n_splits_max)), dim3(kBlock), 0, st, by_dst->splits,
                            by_dst->counts, a.part, D4, 1.f, dP, lddp, nullptr, (int64_t)0, 0, 0.f, 0);
@@ -709,7 +731,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
     float* colsum_part = (float*)(wsb + w.colsum_part);
     unsigned gcs = 0;
     if (loop_rel >= 0 && N > 0) {
-        gcs = (unsigned)(N < 1024 ? N : 1024);
+        gcs = (unsigned)(N < 512 ? N : 512);
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(gcs), dim3(kBlock), 0, st, G, ldg, N, D4, colsum_part);
     }
 
@@ -735,8 +757,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
     }
     if (loop_rel >= 0 && N > 0) {
         // pass C wrote zeros (mode 1) / the fill wrote zeros (mode 0) into dRz[loop]: overwrite it
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((D4 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, colsum_part, (int)gcs, D4,
-                           -out_scale, dRR + (int64_t)loop_rel * lddrr + d);
+        launch_reduce_rows(colsum_part, (int)gcs, (int)d, -out_scale, dRR + (int64_t)loop_rel * lddrr + d, st);
     }
     return (int)hipGetLastError();
 }

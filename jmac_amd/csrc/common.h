@@ -61,4 +61,8 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// out[c] = scale * sum_p partial[p*W + c], c in [0,W): deterministic, parallel over columns and row lanes
+// (defined in aggregate.hip; used for the a_att gradient, the self-loop column sum and the BN statistics)
+void launch_reduce_rows(const float* partial, int nparts, int W, float scale, float* out, hipStream_t st);
+
 }  // namespace jmac

@@ -12,7 +12,7 @@ using namespace jmac;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kStatBlocks = 1024;
+constexpr int kStatBlocks = 512;
 
 // partial[b][0][c] = sum_r (x[r][c]-K[c]),  partial[b][1][c] = sum_r (x[r][c]-K[c])^2, K = x[0][:]
 // rows are dealt to blocks round-robin in groups of RPB = kBlock / D4 rows.
@@ -63,17 +63,14 @@ __global__ __launch_bounds__(kBlock) void col_stats_partial_kernel(const float* 
     }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts, const float* __restrict__ x, int64_t N,
+// sums[0][c], sums[1][c] = reduced partials
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ x, int64_t N,
                                    int d, float eps, float momentum, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ save_mean,
                                    float* __restrict__ save_invstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int p = 0; p < nparts; ++p) {
-        s1 += partial[((int64_t)p * 2 + 0) * d + c];
-        s2 += partial[((int64_t)p * 2 + 1) * d + c];
-    }
+    const float s1 = sums[c], s2 = sums[d + c];
     const float n = (float)N;
     const float K = x[c];
     const float mshift = s1 / n;
@@ -169,17 +166,12 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_partial_kernel(const float* __r
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nparts, int d, float* __restrict__ gweight,
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int d, float* __restrict__ gweight,
                                        float* __restrict__ gbias) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int p = 0; p < nparts; ++p) {
-        s1 += partial[((int64_t)p * 2 + 0) * d + c];
-        s2 += partial[((int64_t)p * 2 + 1) * d + c];
-    }
-    gbias[c] = s1;
-    gweight[c] = s2;
+    gbias[c] = sums[c];
+    gweight[c] = sums[d + c];
 }
 
 __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx,
@@ -233,7 +225,7 @@ extern "C" {
 
 size_t jmac_bn_tanh_workspace_bytes(int64_t N, int64_t d) {
     (void)N;
-    return align_up((size_t)kStatBlocks * 2 * (d > 0 ? d : 0) * 4) + 256;
+    return align_up((size_t)(kStatBlocks + 1) * 2 * (d > 0 ? d : 0) * 4) + 256;
 }
 
 int jmac_bn_tanh_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, const float* weight, const float* bias,
@@ -250,7 +242,9 @@ int jmac_bn_tanh_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, cons
         float* partial = (float*)ws;
         const unsigned g = stat_grid(N, D4);
         hipLaunchKernelGGL(col_stats_partial_kernel, dim3(g), dim3(kBlock), stat_smem(D4), st, x, ldx, N, D4, partial);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, partial, (int)g, x, N, (int)d,
+        float* sums = partial + (size_t)kStatBlocks * 2 * d;
+        launch_reduce_rows(partial, (int)g, (int)(2 * d), 1.f, sums, st);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, sums, x, N, (int)d,
                            eps, momentum, running_mean, running_var, save_mean, save_invstd);
     } else {
         if (!running_mean || !running_var) return JMAC_EINVAL;
@@ -279,8 +273,9 @@ int jmac_bn_tanh_bwd_f32(const float* x, int64_t ldx, const float* y, int64_t ld
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g), dim3(kBlock), stat_smem(D4), st, x, ldx, y, ldy, gy, ldgy, N, D4,
                            save_mean, save_invstd, partial);
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, partial, (int)g, (int)d,
-                       gweight, gbias);
+    float* sums = partial + (size_t)kStatBlocks * 2 * d;
+    launch_reduce_rows(partial, (int)g, (int)(2 * d), 1.f, sums, st);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, sums, (int)d, gweight, gbias);
     if (N > 0)
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(N * D4)), dim3(kBlock), 0, st, x, ldx, y, ldy, gy, ldgy, N, D4,
                            weight, save_mean, save_invstd, gweight, gbias, training, gx, ldgx);

@@ -16,7 +16,18 @@ import torch
 from . import _lib
 from ._lib import View, check, lib, ptr, require_device, stream
 
-DEFAULT_CHUNK = 256
+DEFAULT_CHUNK = None          # None -> auto_chunk()
+
+
+def auto_chunk(n_entries: int) -> int:
+    """Entries per work item: aim for >= ~16k items (2 per wave slot of 256 CUs x 32 waves) so that small
+    graphs are not latency-bound on a handful of long segments, capped at 512 (the chunk size the hardware
+    guide measured for skewed per-destination sums) and floored at 32 to bound the partial-row traffic."""
+    c = max(1, int(n_entries) // 16384)
+    p = 1
+    while p < c:
+        p *= 2
+    return int(min(512, max(32, p)))
 
 
 class _Schedule:
@@ -37,6 +48,10 @@ class _Schedule:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         check(L.jmac_items_build(ptr(seg_ptr), n_seg, chunk, ptr(self.items), ptr(self.splits), ptr(self.counts),
                                  ptr(ws), ws_bytes, stream()), "jmac_items_build")
+        # one host read at build time (never on the hot path): exact launch bounds, and the combine
+        # kernels are skipped altogether when no segment was split
+        n_items, n_splits, n_parts, _ = self.counts.tolist()
+        self.n_items_max, self.n_splits_max, self.n_parts_max = int(n_items), int(n_splits), int(n_parts)
         self._view = View(ptr(self.ptr), ptr(self.order), ptr(self.items), ptr(self.splits), ptr(self.counts),
                           self.n_items_max, self.n_splits_max, self.n_parts_max)
 
@@ -52,8 +67,10 @@ class RelGraph:
     """
 
     def __init__(self, edge_index: torch.Tensor, edge_type: torch.Tensor, num_nodes: int, num_rel: int,
-                 chunk: int = DEFAULT_CHUNK):
+                 chunk: Optional[int] = DEFAULT_CHUNK):
         require_device(edge_index, edge_type)
+        if chunk is None:
+            chunk = auto_chunk(int(edge_index.shape[1]))
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise ValueError("edge_index must be [2, E]")
         if edge_type.shape[0] != edge_index.shape[1]:
@@ -117,9 +134,10 @@ class GraphCache:
         self._d: "OrderedDict[Tuple, RelGraph]" = OrderedDict()
 
     def get(self, edge_index: torch.Tensor, edge_type: torch.Tensor, num_nodes: int, num_rel: int,
-            chunk: int = DEFAULT_CHUNK) -> RelGraph:
+            chunk: Optional[int] = DEFAULT_CHUNK) -> RelGraph:
         key = (edge_index.data_ptr(), edge_type.data_ptr(), tuple(edge_index.shape), edge_index._version,
-               edge_type._version, int(num_nodes), int(num_rel), int(chunk), str(edge_index.device))
+               edge_type._version, int(num_nodes), int(num_rel), -1 if chunk is None else int(chunk),
+               str(edge_index.device))
         g = self._d.get(key)
         if g is None:
             g = RelGraph(edge_index, edge_type, num_nodes, num_rel, chunk)

@@ -124,7 +124,7 @@ class JMAC(nn.Module):
     # ---- losses (torch; src/jmac_model.py:237-292, :316-380) ---------------------------------------
     @staticmethod
     def _cos_dist(e1, i1, e2, i2):
-        return 1 - torch.sum(F.normalize(e1[i1], 2, -1) * F.normalize(e2[i2], 2, -1), dim=1)
+        return 1 - torch.sum(F.normalize(e1.index_select(0, i1), 2, -1) * F.normalize(e2.index_select(0, i2), 2, -1), dim=1)
 
     def alignment_loss_simple(self, links, ent_embeddings1, ent_embeddings2):
         if not len(links):
@@ -157,7 +157,9 @@ class JMAC(nn.Module):
         loss = 0
         for layer in range(self.args.num_gcn_layer):
             ent, rel = (comp1[layer], rel1[layer]) if source else (comp2[layer], rel2[layer])
-            score = torch.norm(ent[h] + rel[r] - ent[t], 1, -1).flatten()
+            # index_select == ent[h] (src/jmac_model.py:345-347); its backward is one index_add pass instead
+            # of advanced indexing's sort-based index_put
+            score = torch.norm(ent.index_select(0, h) + rel.index_select(0, r) - ent.index_select(0, t), 1, -1).flatten()
             pos, neg = score[:bs], score[bs:]
             # the reference consumes the b-major negative block as n-major (view(-1, B).permute): kept as is
             pos = pos.view(-1, min(bs, len(pos))).permute(1, 0)

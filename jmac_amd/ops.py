@@ -16,6 +16,16 @@ from .graph import RelGraph
 BWD_MODE_ATOMIC = 0
 BWD_MODE_DETERMINISTIC = 1
 
+# bench.py sets this to a list to collect (name, start_event, end_event) around the aggregation launches;
+# events are recorded on the stream the kernels are launched on (torch's current stream).
+PROFILE = None
+
+
+def _ev():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
 
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
@@ -50,11 +60,14 @@ class _RelAttnAggregate(torch.autograd.Function):
         ws_bytes = int(L.jmac_rel_attn_fwd_workspace_bytes(s.n_parts_max, d))
         ws = _ws(ws_bytes, dev)
         esz = PQZ.element_size()
+        ev0 = _ev() if PROFILE is not None else None
         check(L.jmac_rel_attn_aggregate_fwd_f32(
             ptr(PQZ), d3, PQZ.data_ptr() + d * esz, d3, ptr(RR), RR.shape[1], ptr(a),
             ptr(graph.rowptr), ptr(graph.col), ptr(graph.etype), ptr(s.items), ptr(s.splits), ptr(s.counts),
             s.n_items_max, s.n_splits_max, s.n_parts_max, N, d, float(slope), int(loop_rel), float(out_scale),
             ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(ws), ws_bytes, stream()), "jmac_rel_attn_aggregate_fwd_f32")
+        if ev0 is not None:
+            PROFILE.append(("rel_attn_fwd", ev0, _ev()))
         ctx.save_for_backward(PQZ, RR, a, out, seg_max, seg_den)
         ctx.graph, ctx.slope, ctx.loop_rel, ctx.out_scale, ctx.bwd_mode = graph, slope, loop_rel, out_scale, bwd_mode
         return out
@@ -83,6 +96,7 @@ class _RelAttnAggregate(torch.autograd.Function):
             graph.by_src.n_parts_max if mode else 0, graph.by_rel.n_parts_max if mode else 0, mode))
         ws = _ws(ws_bytes, dev)
         esz = PQZ.element_size()
+        ev0 = _ev() if PROFILE is not None else None
         check(L.jmac_rel_attn_aggregate_bwd_f32(
             ptr(PQZ), d3, PQZ.data_ptr() + d * esz, d3, ptr(RR), RR.shape[1], ptr(a),
             ptr(graph.col), ptr(graph.etype), ptr(graph.dst_of_slot) if mode else None,
@@ -91,6 +105,8 @@ class _RelAttnAggregate(torch.autograd.Function):
             ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(G), d,
             ptr(dPQZ), d3, dPQZ.data_ptr() + d * esz, d3, ptr(dRR), dRR.shape[1], ptr(da),
             mode, ptr(ws), ws_bytes, stream()), "jmac_rel_attn_aggregate_bwd_f32")
+        if ev0 is not None:
+            PROFILE.append(("rel_attn_bwd", ev0, _ev()))
         return dPQZ, dRR, da, None, None, None, None, None
 
 
