@@ -12,6 +12,8 @@
 // wave; logits are reduced across the wave with DPP + permlane swaps; the softmax is online (running
 // max / denominator), so each edge row is read exactly once.  The relation table [Rq|Rz] stays
 // L2-resident.  HBM-bound by design: see DESIGN.md for the byte model.
+#include <cstdlib>
+
 #include "common.h"
 
 using namespace jmac;
@@ -35,18 +37,32 @@ struct FwdArgs {
     float *part_acc, *part_ml;
 };
 
-template <int NCH>
+// Lane -> chunk map of one [Q|Z] row.  D4T != 0 fixes d/4 at compile time, so that "does chunk k hold any
+// attention-half (h) lane / any message-half (v) lane / any lane past the row end" fold to constants and
+// the unused half of the per-chunk arithmetic disappears; D4T == 0 is the generic run-time form.
+// Every gather is issued at a CLAMPED offset (lanes past the row end re-read chunk 0) so that no load sits
+// behind an exec-mask branch: hipcc puts an s_waitcnt inside such branches, which serialises the gathers.
+template <int NCH, int D4T>
 struct Lanes {
-    int coff[NCH];     // float offset of this lane's chunk inside a [Q|Z] row
+    int D4r;
+    int coff[NCH];     // float offset of this lane's chunk inside a [Q|Z] row (unclamped)
+    int coffc[NCH];    // clamped: 0 for lanes past the row end
     bool valid[NCH];
     bool is_h[NCH];
-    __device__ __forceinline__ void init(int lane, int D4) {
+    __device__ __forceinline__ int D4() const { return D4T ? D4T : D4r; }
+    __device__ __forceinline__ bool any_h(int k) const { return 64 * k < D4(); }
+    __device__ __forceinline__ bool any_v(int k) const { return 64 * (k + 1) > D4(); }
+    __device__ __forceinline__ bool all_valid(int k) const { return 64 * (k + 1) <= 2 * D4(); }
+    __device__ __forceinline__ bool is_v(int k) const { return valid[k] && !is_h[k]; }
+    __device__ __forceinline__ void init(int lane, int d4_runtime) {
+        D4r = d4_runtime;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            int c = lane + 64 * k;
-            valid[k] = c < 2 * D4;
-            is_h[k] = c < D4;
+            const int c = lane + 64 * k;
+            valid[k] = c < 2 * D4();
+            is_h[k] = c < D4();
             coff[k] = c * 4;
+            coffc[k] = valid[k] ? c * 4 : 0;
         }
     }
 };
@@ -61,67 +77,79 @@ __device__ __forceinline__ float4 fma4(float4 a, float s, float4 c) {
 __device__ __forceinline__ float4 leaky4(float4 h, float slope) {
     return make_float4(leaky(h.x, slope), leaky(h.y, slope), leaky(h.z, slope), leaky(h.w, slope));
 }
+__device__ __forceinline__ float4 sel4(bool c, float4 a) { return c ? a : f4zero(); }
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int NCH, int U>
+template <int NCH, int U, int D4T>
 __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = gridDim.x * kWavesPerBlock;
     const int n_items = a.counts[0];
-    Lanes<NCH> L;
+    Lanes<NCH, D4T> L;
     L.init(lane, a.D4);
-    const int voff = 4 * a.D4;
+    const int voff = 4 * L.D4();
     float4 av[NCH];
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) av[k] = (L.valid[k] && L.is_h[k]) ? ld4(a.a_att + L.coff[k]) : f4zero();
+    for (int k = 0; k < NCH; ++k) av[k] = L.any_h(k) ? sel4(L.is_h[k], ld4(a.a_att + (L.is_h[k] ? L.coff[k] : 0))) : f4zero();
+    const bool has_loop = a.loop_rel >= 0;
+    const float* rloop = a.RR + (int64_t)(has_loop ? a.loop_rel : 0) * a.ldrr;
 
     for (int it = blockIdx.x * kWavesPerBlock + wave; it < n_items; it += nwaves) {
         const jmac_item_t item = a.items[it];
         const int i = item.seg;
-        float4 pv[NCH], acc[NCH];
+        float4 pv[NCH], acc[NCH], zs[NCH];
+        const float* prow = a.P + (int64_t)i * a.ldp;
+        const float* zrow = a.QZ + (int64_t)i * a.ldqz;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            pv[k] = (L.valid[k] && L.is_h[k]) ? ld4(a.P + (int64_t)i * a.ldp + L.coff[k]) : f4zero();
+            pv[k] = L.any_h(k) ? ld4(prow + (L.is_h[k] ? L.coff[k] : 0)) : f4zero();
+            // self-loop term Z[i] - Rz[loop] (v-role lanes), fetched up front so it overlaps the edge loop
+            zs[k] = (L.any_v(k) && has_loop) ? sub4(ld4(zrow + L.coffc[k]), ld4(rloop + L.coffc[k])) : f4zero();
             acc[k] = f4zero();
         }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+            if (L.any_h(k) && L.any_v(k)) pv[k] = sel4(L.is_h[k], pv[k]);
         float m = -INFINITY, l = 0.f;
         for (int e0 = item.beg; e0 < item.end; e0 += 64) {
             const int nb = min(64, item.end - e0);
-            int my_col = 0, my_typ = 0;
-            if (lane < nb) {
-                my_col = a.col[e0 + lane];
-                my_typ = a.etype[e0 + lane];
-            }
+            const int le = min(lane, nb - 1);
+            const int my_col = a.col[e0 + le];
+            const int my_typ = a.etype[e0 + le];
             for (int u0 = 0; u0 < nb; u0 += U) {
-                float4 df[U][NCH];
-                float s[U];
+                float4 q[U][NCH], r[U][NCH];
+                // 1) issue every gather of the group (edges past the end re-read the last edge, weight 0)
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const bool ev = (u0 + u) < nb;   // wave-uniform
-                    if (ev) {
-                        const int j = bcast_i(my_col, u0 + u);
-                        const int t = bcast_i(my_typ, u0 + u);
-                        const float* qrow = a.QZ + (int64_t)j * a.ldqz;
-                        const float* rrow = a.RR + (int64_t)t * a.ldrr;
+                    const int idx = min(u0 + u, nb - 1);
+                    const int j = bcast_i(my_col, idx);
+                    const int t = bcast_i(my_typ, idx);
+                    const float* qrow = a.QZ + (int64_t)j * a.ldqz;
+                    const float* rrow = a.RR + (int64_t)t * a.ldrr;
 #pragma unroll
-                        for (int k = 0; k < NCH; ++k)
-                            df[u][k] = L.valid[k] ? sub4(ld4(qrow + L.coff[k]), ld4(rrow + L.coff[k])) : f4zero();
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < NCH; ++k) df[u][k] = f4zero();
+                    for (int k = 0; k < NCH; ++k) {
+                        q[u][k] = ld4(qrow + L.coffc[k]);
+                        r[u][k] = ld4(rrow + L.coffc[k]);
                     }
                 }
+                // 2) logits
+                float s[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     float part = 0.f;
 #pragma unroll
-                    for (int k = 0; k < NCH; ++k) part += dot4(av[k], leaky4(add4(pv[k], df[u][k]), a.slope));
+                    for (int k = 0; k < NCH; ++k) {
+                        q[u][k] = sub4(q[u][k], r[u][k]);
+                        if (!L.all_valid(k)) q[u][k] = sel4(L.valid[k], q[u][k]);
+                        if (L.any_h(k)) part += dot4(av[k], leaky4(add4(pv[k], q[u][k]), a.slope));
+                    }
                     s[u] = wave_sum(part);
                     if (!((u0 + u) < nb)) s[u] = -INFINITY;
                 }
+                // 3) online softmax update
                 float gmax = s[0];
 #pragma unroll
                 for (int u = 1; u < U; ++u) gmax = fmaxf(gmax, s[u]);
@@ -136,10 +164,11 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
                 l = l * sc + wsum;
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
-                    float4 r = mul4(acc[k], sc);
+                    if (!L.any_v(k)) continue;
+                    float4 x = mul4(acc[k], sc);
 #pragma unroll
-                    for (int u = 0; u < U; ++u) r = fma4(df[u][k], w[u], r);
-                    acc[k] = r;
+                    for (int u = 0; u < U; ++u) x = fma4(q[u][k], w[u], x);
+                    acc[k] = x;
                 }
                 m = mn;
             }
@@ -149,13 +178,8 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
             const float scale = l > 0.f ? sqrtf((float)deg) / l : 0.f;
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                if (L.valid[k] && !L.is_h[k]) {
-                    float4 o = mul4(acc[k], scale);
-                    if (a.loop_rel >= 0) {
-                        float4 z = ld4(a.QZ + (int64_t)i * a.ldqz + L.coff[k]);
-                        float4 rz = ld4(a.RR + (int64_t)a.loop_rel * a.ldrr + L.coff[k]);
-                        o = add4(o, sub4(z, rz));
-                    }
+                if (L.any_v(k) && L.is_v(k)) {
+                    const float4 o = add4(mul4(acc[k], scale), zs[k]);
                     st4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff), mul4(o, a.out_scale));
                 }
             }
@@ -166,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
         } else {
 #pragma unroll
             for (int k = 0; k < NCH; ++k)
-                if (L.valid[k] && !L.is_h[k]) st4(a.part_acc + (int64_t)item.pslot * voff + (L.coff[k] - voff), acc[k]);
+                if (L.any_v(k) && L.is_v(k)) st4(a.part_acc + (int64_t)item.pslot * voff + (L.coff[k] - voff), acc[k]);
             if (lane == 0) {
                 a.part_ml[2 * item.pslot] = m;
                 a.part_ml[2 * item.pslot + 1] = l;
@@ -182,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_combine_kernel(FwdArgs a)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = gridDim.x * kWavesPerBlock;
     const int n_splits = a.counts[1];
-    Lanes<NCH> L;
+    Lanes<NCH, 0> L;
     L.init(lane, a.D4);
     const int voff = 4 * a.D4;
     for (int sp = blockIdx.x * kWavesPerBlock + wave; sp < n_splits; sp += nwaves) {
@@ -199,14 +223,16 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_combine_kernel(FwdArgs a)
             const float f = expf(a.part_ml[2 * ps] - M);
             lsum += a.part_ml[2 * ps + 1] * f;
 #pragma unroll
-            for (int k = 0; k < NCH; ++k)
-                if (L.valid[k] && !L.is_h[k]) acc[k] = fma4(ld4(a.part_acc + (int64_t)ps * voff + (L.coff[k] - voff)), f, acc[k]);
+            for (int k = 0; k < NCH; ++k) {
+                const int o = L.is_v(k) ? L.coff[k] - voff : 0;
+                acc[k] = fma4(ld4(a.part_acc + (int64_t)ps * voff + o), f, acc[k]);
+            }
         }
         const int deg = a.rowptr[i + 1] - a.rowptr[i];
         const float scale = lsum > 0.f ? sqrtf((float)deg) / lsum : 0.f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            if (L.valid[k] && !L.is_h[k]) {
+            if (L.is_v(k)) {
                 float4 o = mul4(acc[k], scale);
                 if (a.loop_rel >= 0) {
                     float4 z = ld4(a.QZ + (int64_t)i * a.ldqz + L.coff[k]);
@@ -246,7 +272,7 @@ struct BwdArgs {
 };
 
 // Pass A: by destination.  MODE 0: float atomics into dQZ / dRR.  MODE 1: per-edge records.
-template <int NCH, int U, int MODE>
+template <int NCH, int U, int MODE, int D4T>
 __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
     constexpr int NCH_H = (NCH + 1) / 2;
     __shared__ float4 red[kWavesPerBlock][NCH_H][64];
@@ -254,40 +280,46 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = gridDim.x * kWavesPerBlock;
     const int n_items = a.counts[0];
-    Lanes<NCH> L;
+    Lanes<NCH, D4T> L;
     L.init(lane, a.D4);
-    const int voff = 4 * a.D4;
+    const int voff = 4 * L.D4();
     const float kappa = a.out_scale;
-    float4 av[NCH];
+    const float inv_kappa = 1.f / kappa;
+    float4 av[NCH_H];
     float4 da[NCH_H];
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) av[k] = (L.valid[k] && L.is_h[k]) ? ld4(a.a_att + L.coff[k]) : f4zero();
-#pragma unroll
-    for (int k = 0; k < NCH_H; ++k) da[k] = f4zero();
+    for (int k = 0; k < NCH_H; ++k) {
+        av[k] = sel4(L.is_h[k], ld4(a.a_att + (L.is_h[k] ? L.coff[k] : 0)));
+        da[k] = f4zero();
+    }
+    const bool has_loop = a.loop_rel >= 0;
+    const float* rloop = a.RR + (int64_t)(has_loop ? a.loop_rel : 0) * a.ldrr;
 
     for (int it = blockIdx.x * kWavesPerBlock + wave; it < n_items; it += nwaves) {
         const jmac_item_t item = a.items[it];
         const int i = item.seg;
-        float4 pv[NCH], gv[NCH], accP[NCH_H];
+        float4 pv[NCH_H], gv[NCH], accP[NCH_H];
         float tpart = 0.f;
+        const float* prow = a.P + (int64_t)i * a.ldp;
+        const float* zrow = a.QZ + (int64_t)i * a.ldqz;
+        const float* grow = a.G + (int64_t)i * a.ldg;
+        const float* orow = a.out + (int64_t)i * a.ldo;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            pv[k] = (L.valid[k] && L.is_h[k]) ? ld4(a.P + (int64_t)i * a.ldp + L.coff[k]) : f4zero();
-            gv[k] = f4zero();
-            if (L.valid[k] && !L.is_h[k]) {
-                gv[k] = mul4(ld4(a.G + (int64_t)i * a.ldg + (L.coff[k] - voff)), kappa);
-                // nb_i = out/kappa - (Z[i] - Rz[loop])
-                float4 nbv = mul4(ld4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff)), 1.f / kappa);
-                if (a.loop_rel >= 0) {
-                    float4 z = ld4(a.QZ + (int64_t)i * a.ldqz + L.coff[k]);
-                    float4 rz = ld4(a.RR + (int64_t)a.loop_rel * a.ldrr + L.coff[k]);
-                    nbv = sub4(nbv, sub4(z, rz));
-                }
-                tpart += dot4(gv[k], nbv);
-            }
+        for (int k = 0; k < NCH_H; ++k) {
+            pv[k] = sel4(L.is_h[k], ld4(prow + (L.is_h[k] ? L.coff[k] : 0)));
+            accP[k] = f4zero();
         }
 #pragma unroll
-        for (int k = 0; k < NCH_H; ++k) accP[k] = f4zero();
+        for (int k = 0; k < NCH; ++k) {
+            gv[k] = f4zero();
+            if (!L.any_v(k)) continue;
+            const int vo = L.is_v(k) ? L.coff[k] - voff : 0;
+            const float4 g = mul4(ld4(grow + vo), kappa);
+            float4 nbv = mul4(ld4(orow + vo), inv_kappa);          // nb_i = out/kappa - (Z[i] - Rz[loop])
+            if (has_loop) nbv = sub4(nbv, sub4(ld4(zrow + L.coffc[k]), ld4(rloop + L.coffc[k])));
+            gv[k] = sel4(L.is_v(k), g);
+            tpart += dot4(gv[k], nbv);
+        }
         const float t_i = wave_sum(tpart);
         const float m_i = a.seg_max[i];
         const float l_i = a.seg_den[i];
@@ -296,28 +328,23 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
 
         for (int e0 = item.beg; e0 < item.end; e0 += 64) {
             const int nb = min(64, item.end - e0);
-            int my_col = 0, my_typ = 0;
-            if (lane < nb) {
-                my_col = a.col[e0 + lane];
-                my_typ = a.etype[e0 + lane];
-            }
+            const int le = min(lane, nb - 1);
+            const int my_col = a.col[e0 + le];
+            const int my_typ = a.etype[e0 + le];
             float my_w = 0.f, my_ds = 0.f;
             for (int u0 = 0; u0 < nb; u0 += U) {
-                float4 df[U][NCH];
+                float4 q[U][NCH], r[U][NCH];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const bool ev = (u0 + u) < nb;
-                    if (ev) {
-                        const int j = bcast_i(my_col, u0 + u);
-                        const int t = bcast_i(my_typ, u0 + u);
-                        const float* qrow = a.QZ + (int64_t)j * a.ldqz;
-                        const float* rrow = a.RR + (int64_t)t * a.ldrr;
+                    const int idx = min(u0 + u, nb - 1);
+                    const int j = bcast_i(my_col, idx);
+                    const int t = bcast_i(my_typ, idx);
+                    const float* qrow = a.QZ + (int64_t)j * a.ldqz;
+                    const float* rrow = a.RR + (int64_t)t * a.ldrr;
 #pragma unroll
-                        for (int k = 0; k < NCH; ++k)
-                            df[u][k] = L.valid[k] ? sub4(ld4(qrow + L.coff[k]), ld4(rrow + L.coff[k])) : f4zero();
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < NCH; ++k) df[u][k] = f4zero();
+                    for (int k = 0; k < NCH; ++k) {
+                        q[u][k] = ld4(qrow + L.coffc[k]);
+                        r[u][k] = ld4(rrow + L.coffc[k]);
                     }
                 }
 #pragma unroll
@@ -327,11 +354,12 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
                     float spart = 0.f, upart = 0.f;
 #pragma unroll
                     for (int k = 0; k < NCH; ++k) {
+                        q[u][k] = sub4(q[u][k], r[u][k]);
                         if (k < NCH_H) {
-                            hv[k] = add4(pv[k], df[u][k]);
-                            spart += dot4(av[k], leaky4(hv[k], a.slope));
+                            hv[k] = add4(pv[k], q[u][k]);
+                            if (L.any_h(k)) spart += dot4(av[k], leaky4(hv[k], a.slope));
                         }
-                        upart += dot4(gv[k], df[u][k]);   // gv is zero on h-role chunks
+                        if (L.any_v(k)) upart += dot4(gv[k], q[u][k]);   // gv is zero off the v-role lanes
                     }
                     const float s = wave_sum(spart);
                     const float uu = wave_sum(upart);
@@ -383,10 +411,10 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
             if (MODE == 1 && lane < nb) a.wds[e0 + lane] = make_float2(my_w, my_ds);
         }
         // dP row (h-role chunks)
-        float* prow = item.pslot < 0 ? a.dP + (int64_t)i * a.lddp : a.part + (int64_t)item.pslot * voff;
+        float* dprow = item.pslot < 0 ? a.dP + (int64_t)i * a.lddp : a.part + (int64_t)item.pslot * voff;
 #pragma unroll
         for (int k = 0; k < NCH_H; ++k)
-            if (L.valid[k] && L.is_h[k]) st4(prow + L.coff[k], accP[k]);
+            if (L.valid[k] && L.is_h[k]) st4(dprow + L.coff[k], accP[k]);
     }
     // block-level reduction of the a_att gradient, one partial row per block
 #pragma unroll
@@ -408,20 +436,23 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
 // Pass B (by source, sign=+1) and pass C (by relation, sign=-1): sum the per-edge records.
 //   row[h-half] = sign * sum_e ds_e * a (.) lrelu'(h_e)         (sign bits from pass A)
 //   row[v-half] = sign * sum_e w_e * g_{dst(e)}  (+ g_j for the fused self loop in pass B)
-template <int NCH, int U>
+template <int NCH, int U, int D4T>
 __global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs a, float* __restrict__ outp, int64_t ldout) {
     constexpr int NCH_H = (NCH + 1) / 2;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = gridDim.x * kWavesPerBlock;
     const int n_items = a.counts[0];
-    Lanes<NCH> L;
+    Lanes<NCH, D4T> L;
     L.init(lane, a.D4);
-    const int voff = 4 * a.D4;
+    const int voff = 4 * L.D4();
     const float kappa = a.out_scale;
-    float4 av[NCH];
+    float4 av[NCH_H];
+    int goff[NCH];
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) av[k] = (L.valid[k] && L.is_h[k]) ? ld4(a.a_att + L.coff[k]) : f4zero();
+    for (int k = 0; k < NCH_H; ++k) av[k] = sel4(L.is_h[k], ld4(a.a_att + (L.is_h[k] ? L.coff[k] : 0)));
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) goff[k] = L.is_v(k) ? L.coff[k] - voff : 0;
 
     for (int it = blockIdx.x * kWavesPerBlock + wave; it < n_items; it += nwaves) {
         const jmac_item_t item = a.items[it];
@@ -431,54 +462,47 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs a, 
         for (int k = 0; k < NCH; ++k) acc[k] = f4zero();
         for (int x0 = item.beg; x0 < item.end; x0 += 64) {
             const int nb = min(64, item.end - x0);
-            int my_slot = 0, my_dst = 0;
-            float2 my_wd = make_float2(0.f, 0.f);
-            if (lane < nb) {
-                my_slot = a.order[x0 + lane];
-                my_dst = a.dst_of_slot[my_slot];
-                my_wd = a.wds[my_slot];
-            }
+            const int le = min(lane, nb - 1);
+            const int my_slot = a.order[x0 + le];
+            const int my_dst = a.dst_of_slot[my_slot];
+            const float2 my_wd = a.wds[my_slot];
             for (int u0 = 0; u0 < nb; u0 += U) {
                 float4 gq[U][NCH];
                 unsigned bw[U];
                 float w[U], ds[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
+                    const int idx = min(u0 + u, nb - 1);
                     const bool ev = (u0 + u) < nb;
-                    w[u] = 0.f;
-                    ds[u] = 0.f;
+                    const int slot = bcast_i(my_slot, idx);
+                    const int i = bcast_i(my_dst, idx);
+                    w[u] = ev ? bcast_f(my_wd.x, idx) * kappa : 0.f;
+                    ds[u] = ev ? bcast_f(my_wd.y, idx) : 0.f;
+                    const float* grow = a.G + (int64_t)i * a.ldg;
 #pragma unroll
-                    for (int k = 0; k < NCH; ++k) gq[u][k] = f4zero();
-                    bw[u] = 0u;
-                    if (ev) {
-                        const int slot = bcast_i(my_slot, u0 + u);
-                        const int i = bcast_i(my_dst, u0 + u);
-                        w[u] = bcast_f(my_wd.x, u0 + u);
-                        ds[u] = bcast_f(my_wd.y, u0 + u);
-                        const float* grow = a.G + (int64_t)i * a.ldg;
-#pragma unroll
-                        for (int k = 0; k < NCH; ++k)
-                            if (L.valid[k] && !L.is_h[k]) gq[u][k] = ld4(grow + (L.coff[k] - voff));
-                        bw[u] = a.bits[(int64_t)slot * 64 + lane];
-                    }
+                    for (int k = 0; k < NCH; ++k)
+                        if (L.any_v(k)) gq[u][k] = ld4(grow + goff[k]);
+                    bw[u] = a.bits[(int64_t)slot * 64 + lane];
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const float wk = w[u] * kappa;
 #pragma unroll
                     for (int k = 0; k < NCH; ++k) {
-                        if (k < NCH_H && L.is_h[k]) {
+                        float4 hpart = f4zero();
+                        if (k < NCH_H && L.any_h(k)) {
                             const unsigned nib = bw[u] >> (4 * k);
-                            const float g0 = (nib & 1u) ? 1.f : a.slope;
-                            const float g1 = (nib & 2u) ? 1.f : a.slope;
-                            const float g2 = (nib & 4u) ? 1.f : a.slope;
-                            const float g3 = (nib & 8u) ? 1.f : a.slope;
-                            acc[k].x = fmaf(ds[u] * av[k].x, g0, acc[k].x);
-                            acc[k].y = fmaf(ds[u] * av[k].y, g1, acc[k].y);
-                            acc[k].z = fmaf(ds[u] * av[k].z, g2, acc[k].z);
-                            acc[k].w = fmaf(ds[u] * av[k].w, g3, acc[k].w);
+                            hpart.x = ds[u] * av[k].x * ((nib & 1u) ? 1.f : a.slope);
+                            hpart.y = ds[u] * av[k].y * ((nib & 2u) ? 1.f : a.slope);
+                            hpart.z = ds[u] * av[k].z * ((nib & 4u) ? 1.f : a.slope);
+                            hpart.w = ds[u] * av[k].w * ((nib & 8u) ? 1.f : a.slope);
+                        }
+                        if (L.any_h(k) && L.any_v(k)) {
+                            const float4 vpart = mul4(gq[u][k], w[u]);
+                            acc[k] = add4(acc[k], L.is_h[k] ? hpart : vpart);
+                        } else if (L.any_h(k)) {
+                            acc[k] = add4(acc[k], hpart);
                         } else {
-                            acc[k] = fma4(gq[u][k], wk, acc[k]);
+                            acc[k] = fma4(gq[u][k], w[u], acc[k]);
                         }
                     }
                 }
@@ -513,9 +537,18 @@ __global__ __launch_bounds__(kBlock) void sum_parts_kernel(const jmac_split_t* _
     for (int sp = blockIdx.x * kWavesPerBlock + wave; sp < n_splits; sp += nwaves) {
         const jmac_split_t s = splits[sp];
         for (int c4 = lane; c4 < W4; c4 += 64) {
-            float4 acc = f4zero();
-            for (int c = 0; c < s.nchunks; ++c) acc = add4(acc, ld4(part + ((int64_t)(s.pslot0 + c) * W4 + c4) * 4));
-            acc = mul4(acc, sign);
+            // fixed summation order (4 interleaved partial sums), 4 rows in flight per lane
+            float4 a0 = f4zero(), a1 = f4zero(), a2 = f4zero(), a3 = f4zero();
+            const float* base = part + ((int64_t)s.pslot0 * W4 + c4) * 4;
+            int c = 0;
+            for (; c + 3 < s.nchunks; c += 4) {
+                a0 = add4(a0, ld4(base + (int64_t)(c + 0) * W4 * 4));
+                a1 = add4(a1, ld4(base + (int64_t)(c + 1) * W4 * 4));
+                a2 = add4(a2, ld4(base + (int64_t)(c + 2) * W4 * 4));
+                a3 = add4(a3, ld4(base + (int64_t)(c + 3) * W4 * 4));
+            }
+            for (; c < s.nchunks; ++c) a0 = add4(a0, ld4(base + (int64_t)c * W4 * 4));
+            float4 acc = mul4(add4(add4(a0, a1), add4(a2, a3)), sign);
             if (add_self && c4 >= D4) acc = fma4(ld4(G + (int64_t)s.seg * ldg + (c4 - D4) * 4), kappa, acc);
             st4(outp + (int64_t)s.seg * ldout + c4 * 4, acc);
         }
@@ -582,10 +615,16 @@ inline int check_dims(int64_t d, int64_t ld0, int64_t ld1, int64_t ld2) {
     return 0;
 }
 
+inline int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
 inline unsigned persist_grid(int64_t n_items_max) {
+    static const int cap = env_int("JMAC_GRID", kPersistBlocks);   // tuning knob (debug)
     int64_t need = (n_items_max + kWavesPerBlock - 1) / kWavesPerBlock;
     if (need < 1) need = 1;
-    return (unsigned)(need < kPersistBlocks ? need : kPersistBlocks);
+    return (unsigned)(need < cap ? need : cap);
 }
 
 #define JMAC_DISPATCH_NCH(nch, ...)                       \
@@ -595,6 +634,12 @@ inline unsigned persist_grid(int64_t n_items_max) {
         case 3: { constexpr int NCH = 3; __VA_ARGS__; } break; \
         default: { constexpr int NCH = 4; __VA_ARGS__; } break; \
     }
+
+// d = 256 and d = 300 (the reference's default and BASELINE's dim) get compile-time chunk roles
+#define JMAC_DISPATCH_D(D4v, nch, ...)                                        \
+    if ((D4v) == 64) { constexpr int NCH = 2; constexpr int D4T = 64; __VA_ARGS__; } \
+    else if ((D4v) == 75) { constexpr int NCH = 3; constexpr int D4T = 75; __VA_ARGS__; } \
+    else { constexpr int D4T = 0; JMAC_DISPATCH_NCH(nch, __VA_ARGS__); }
 
 }  // namespace
 
@@ -639,7 +684,12 @@ int jmac_rel_attn_aggregate_fwd_f32(const float* P, int64_t ldp, const float* QZ
     hipStream_t st = (hipStream_t)stream;
     const int nch = (int)((2 * (d / 4) + 63) / 64);
     const unsigned grid = persist_grid(n_items_max);
-    JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 4>), dim3(grid), dim3(kBlock), 0, st, a));
+    static const int fwd_u = env_int("JMAC_FWD_U", 4);             // tuning knob (debug)
+    if (fwd_u == 2) {
+        JMAC_DISPATCH_D(a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 2, D4T>), dim3(grid), dim3(kBlock), 0, st, a));
+    } else {
+        JMAC_DISPATCH_D(a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 4, D4T>), dim3(grid), dim3(kBlock), 0, st, a));
+    }
     if (n_splits_max > 0) {
         const unsigned g2 = persist_grid(n_splits_max);
         JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_fwd_combine_kernel<NCH>), dim3(g2), dim3(kBlock), 0, st, a));
@@ -717,9 +767,9 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
         hipLaunchKernelGGL(init_dqz_kernel, dim3((unsigned)((N * 2 * d + T - 1) / T)), dim3(T), 0, st, dQZ, lddqz, N, d, G, ldg,
                            out_scale, loop_rel >= 0 ? 1 : 0);
         hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((nrel * 2 * d + T - 1) / T)), dim3(T), 0, st, dRR, nrel, 2 * d, lddrr, 0.f);
-        JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 0>), dim3(gridA), dim3(kBlock), 0, st, a));
+        JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 0, D4T>), dim3(gridA), dim3(kBlock), 0, st, a));
     } else {
-        JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 1>), dim3(gridA), dim3(kBlock), 0, st, a));
+        JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 1, D4T>), dim3(gridA), dim3(kBlock), 0, st, a));
     }
     // a_att gradient: deterministic reduction of the per-block partial rows
     launch_reduce_rows(a.da_part, (int)gridA, (int)d, 1.f, da, st);
@@ -740,7 +790,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
         b.items = by_src->items; b.splits = by_src->splits; b.counts = by_src->counts; b.order = by_src->order;
         b.part = (float*)(wsb + w.part_src);
         b.sign = 1.f; b.add_self = loop_rel >= 0 ? 1 : 0;
-        JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_bwd_gather_kernel<NCH, 4>), dim3(persist_grid(by_src->n_items_max)),
+        JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_gather_kernel<NCH, 4, D4T>), dim3(persist_grid(by_src->n_items_max)),
                                                   dim3(kBlock), 0, st, b, dQZ, lddqz));
         if (by_src->n_splits_max > 0)
             hipLaunchKernelGGL(sum_parts_kernel, dim3(persist_grid(by_src->n_splits_max)), dim3(kBlock), 0, st, by_src->splits,
@@ -749,7 +799,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
         c.items = by_rel->items; c.splits = by_rel->splits; c.counts = by_rel->counts; c.order = by_rel->order;
         c.part = (float*)(wsb + w.part_rel);
         c.sign = -1.f; c.add_self = 0;
-        JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_bwd_gather_kernel<NCH, 4>), dim3(persist_grid(by_rel->n_items_max)),
+        JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_gather_kernel<NCH, 4, D4T>), dim3(persist_grid(by_rel->n_items_max)),
                                                   dim3(kBlock), 0, st, c, dRR, lddrr));
         if (by_rel->n_splits_max > 0)
             hipLaunchKernelGGL(sum_parts_kernel, dim3(persist_grid(by_rel->n_splits_max)), dim3(kBlock), 0, st, by_rel->splits,
