@@ -74,7 +74,10 @@ __device__ __forceinline__ float4 mul4(float4 a, float s) { return make_float4(a
 __device__ __forceinline__ float4 fma4(float4 a, float s, float4 c) {
     return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
 }
+// MAXFORM (specialised kernels; the launcher guarantees 0 <= slope <= 1): max(x, slope*x)
+template <bool MAXFORM>
 __device__ __forceinline__ float4 leaky4(float4 h, float slope) {
+    if (MAXFORM) return make_float4(leaky01(h.x, slope), leaky01(h.y, slope), leaky01(h.z, slope), leaky01(h.w, slope));
     return make_float4(leaky(h.x, slope), leaky(h.y, slope), leaky(h.z, slope), leaky(h.w, slope));
 }
 __device__ __forceinline__ float4 sel4(bool c, float4 a) { return c ? a : f4zero(); }
@@ -100,14 +103,12 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
     for (int it = blockIdx.x * kWavesPerBlock + wave; it < n_items; it += nwaves) {
         const jmac_item_t item = a.items[it];
         const int i = item.seg;
-        float4 pv[NCH], acc[NCH], zs[NCH];
+        float4 pv[NCH], acc[NCH];
         const float* prow = a.P + (int64_t)i * a.ldp;
         const float* zrow = a.QZ + (int64_t)i * a.ldqz;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             pv[k] = L.any_h(k) ? ld4(prow + (L.is_h[k] ? L.coff[k] : 0)) : f4zero();
-            // self-loop term Z[i] - Rz[loop] (v-role lanes), fetched up front so it overlaps the edge loop
-            zs[k] = (L.any_v(k) && has_loop) ? sub4(ld4(zrow + L.coffc[k]), ld4(rloop + L.coffc[k])) : f4zero();
             acc[k] = f4zero();
         }
 #pragma unroll
@@ -144,21 +145,24 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
                     for (int k = 0; k < NCH; ++k) {
                         q[u][k] = sub4(q[u][k], r[u][k]);
                         if (!L.all_valid(k)) q[u][k] = sel4(L.valid[k], q[u][k]);
-                        if (L.any_h(k)) part += dot4(av[k], leaky4(add4(pv[k], q[u][k]), a.slope));
+                        if (L.any_h(k)) part += dot4(av[k], leaky4<D4T != 0>(add4(pv[k], q[u][k]), a.slope));
                     }
-                    s[u] = wave_sum(part);
-                    if (!((u0 + u) < nb)) s[u] = -INFINITY;
+                    s[u] = part;
                 }
+                wave_sum_n<U>(s);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (!((u0 + u) < nb)) s[u] = -INFINITY;
                 // 3) online softmax update
                 float gmax = s[0];
 #pragma unroll
                 for (int u = 1; u < U; ++u) gmax = fmaxf(gmax, s[u]);
                 const float mn = fmaxf(m, gmax);
-                const float sc = expf(m - mn);
+                const float sc = fast_exp(m - mn);
                 float w[U], wsum = 0.f;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    w[u] = expf(s[u] - mn);
+                    w[u] = fast_exp(s[u] - mn);
                     wsum += w[u];
                 }
                 l = l * sc + wsum;
@@ -176,6 +180,10 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
         if (item.pslot < 0) {
             const int deg = item.end - item.beg;
             const float scale = l > 0.f ? sqrtf((float)deg) / l : 0.f;
+            float4 zs[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)   // self-loop term Z[i] - Rz[loop] (v-role lanes)
+                zs[k] = (L.any_v(k) && has_loop) ? sub4(ld4(zrow + L.coffc[k]), ld4(rloop + L.coffc[k])) : f4zero();
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 if (L.any_v(k) && L.is_v(k)) {
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_combine_kernel(FwdArgs a)
         for (int k = 0; k < NCH; ++k) acc[k] = f4zero();
         for (int c = 0; c < s.nchunks; ++c) {
             const int ps = s.pslot0 + c;
-            const float f = expf(a.part_ml[2 * ps] - M);
+            const float f = fast_exp(a.part_ml[2 * ps] - M);
             lsum += a.part_ml[2 * ps + 1] * f;
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
@@ -357,13 +365,13 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
                         q[u][k] = sub4(q[u][k], r[u][k]);
                         if (k < NCH_H) {
                             hv[k] = add4(pv[k], q[u][k]);
-                            if (L.any_h(k)) spart += dot4(av[k], leaky4(hv[k], a.slope));
+                            if (L.any_h(k)) spart += dot4(av[k], leaky4<D4T != 0>(hv[k], a.slope));
                         }
                         if (L.any_v(k)) upart += dot4(gv[k], q[u][k]);   // gv is zero off the v-role lanes
                     }
                     const float s = wave_sum(spart);
                     const float uu = wave_sum(upart);
-                    const float alpha = expf(s - m_i) * inv_l;
+                    const float alpha = fast_exp(s - m_i) * inv_l;
                     const float w = c_i * alpha;
                     const float ds = w * uu - alpha * t_i;
                     if (lane == u0 + u) {
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
                                                      h.z > 0.f ? 1.f : a.slope, h.w > 0.f ? 1.f : a.slope);
                         dh[k] = make_float4(ds * av[k].x * g.x, ds * av[k].y * g.y, ds * av[k].z * g.z, ds * av[k].w * g.w);
                         accP[k] = add4(accP[k], dh[k]);
-                        da[k] = fma4(leaky4(h, a.slope), ds, da[k]);
+                        da[k] = fma4(leaky4<D4T != 0>(h, a.slope), ds, da[k]);
                         if (MODE == 1)
                             mybits |= ((h.x > 0.f ? 1u : 0u) | (h.y > 0.f ? 2u : 0u) | (h.z > 0.f ? 4u : 0u) |
                                        (h.w > 0.f ? 8u : 0u)) << (4 * k);
@@ -637,8 +645,8 @@ inline unsigned persist_grid(int64_t n_items_max) {
 
 // d = 256 and d = 300 (the reference's default and BASELINE's dim) get compile-time chunk roles
 #define JMAC_DISPATCH_D(D4v, nch, ...)                                        \
-    if ((D4v) == 64) { constexpr int NCH = 2; constexpr int D4T = 64; __VA_ARGS__; } \
-    else if ((D4v) == 75) { constexpr int NCH = 3; constexpr int D4T = 75; __VA_ARGS__; } \
+    if ((D4v) == 64 && slope01) { constexpr int NCH = 2; constexpr int D4T = 64; __VA_ARGS__; } \
+    else if ((D4v) == 75 && slope01) { constexpr int NCH = 3; constexpr int D4T = 75; __VA_ARGS__; } \
     else { constexpr int D4T = 0; JMAC_DISPATCH_NCH(nch, __VA_ARGS__); }
 
 }  // namespace
@@ -685,6 +693,7 @@ int jmac_rel_attn_aggregate_fwd_f32(const float* P, int64_t ldp, const float* QZ
     const int nch = (int)((2 * (d / 4) + 63) / 64);
     const unsigned grid = persist_grid(n_items_max);
     static const int fwd_u = env_int("JMAC_FWD_U", 4);             // tuning knob (debug)
+    const bool slope01 = slope >= 0.f && slope <= 1.f;
     if (fwd_u == 2) {
         JMAC_DISPATCH_D(a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 2, D4T>), dim3(grid), dim3(kBlock), 0, st, a));
     } else {
@@ -762,6 +771,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
 
     const int T = 256;
     const unsigned gridA = persist_grid(by_dst->n_items_max);
+    const bool slope01 = slope >= 0.f && slope <= 1.f;
     if (mode == 0) {
         // dQZ / dRR are accumulated with atomics: initialise them (dZ half of dQZ starts at the self term)
         hipLaunchKernelGGL(init_dqz_kernel, dim3((unsigned)((N * 2 * d + T - 1) / T)), dim3(T), 0, st, dQZ, lddqz, N, d, G, ldg,

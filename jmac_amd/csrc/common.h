@@ -54,6 +54,30 @@ __device__ __forceinline__ float bcast_f(float v, int src) {
 }
 
 __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
+// identical to leaky() whenever 0 <= slope <= 1 (x>0: x >= slope*x; x<0: slope*x >= x); 2 VALU ops instead of 3
+__device__ __forceinline__ float leaky01(float x, float slope) { return fmaxf(x, x * slope); }
+// exp through v_exp_f32 (2^x): relative error ~1e-6 for the |x| <~ 30 softmax arguments used here
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
+// U independent wave sums with the DPP steps interleaved, so the VALU->DPP hazard slots of one chain are
+// filled by the others instead of s_nop
+template <int U>
+__device__ __forceinline__ void wave_sum_n(float (&v)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] += JMAC_DPP(v[u], 0.f, 0xB1, 0xF);
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] += JMAC_DPP(v[u], 0.f, 0x4E, 0xF);
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] += JMAC_DPP(v[u], 0.f, 0x141, 0xF);
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] += JMAC_DPP(v[u], 0.f, 0x140, 0xF);
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] += JMAC_DPP(v[u], 0.f, 0x142, 0xA);
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] += JMAC_DPP(v[u], 0.f, 0x143, 0xC);
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[u]), 63));
+}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -71,31 +71,38 @@ __global__ void seg_counts_kernel(const int32_t* __restrict__ ptr, int64_t S, in
     }
 }
 
+// Items of split segments (the long ones, up to `chunk` entries each) come FIRST in the schedule, the
+// unsplit segments follow in segment order: with the kernels' round-robin item->wave map every wave then
+// starts with its share of the long items and short segments fill in behind them (longest-first balancing).
 __global__ void items_fill_kernel(const int32_t* __restrict__ ptr, int64_t S, int32_t chunk,
-                                  const int32_t* __restrict__ item_off, const int32_t* __restrict__ part_off,
-                                  const int32_t* __restrict__ split_off, jmac_item_t* __restrict__ items,
-                                  jmac_split_t* __restrict__ splits, int32_t* __restrict__ counts) {
+                                  const int32_t* __restrict__ part_off, const int32_t* __restrict__ split_off,
+                                  jmac_item_t* __restrict__ items, jmac_split_t* __restrict__ splits,
+                                  int32_t* __restrict__ counts) {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
+    // totals from the last segment (every thread reads the same three words)
+    const int32_t last_len = ptr[S] - ptr[S - 1];
+    const int32_t last_nch = last_len <= chunk ? 1 : (last_len + chunk - 1) / chunk;
+    const int32_t n_parts = part_off[S - 1] + (last_nch > 1 ? last_nch : 0);
+    const int32_t n_splits = split_off[S - 1] + (last_nch > 1 ? 1 : 0);
     int32_t beg = ptr[s], end = ptr[s + 1];
     int32_t len = end - beg;
     int32_t nch = len <= chunk ? 1 : (len + chunk - 1) / chunk;
-    int32_t io = item_off[s];
     if (nch == 1) {
-        items[io] = jmac_item_t{(int32_t)s, beg, end, -1};
+        items[n_parts + (int32_t)s - split_off[s]] = jmac_item_t{(int32_t)s, beg, end, -1};
     } else {
         int32_t po = part_off[s];
         for (int32_t c = 0; c < nch; ++c) {
             int32_t b = beg + c * chunk;
             int32_t e = b + chunk < end ? b + chunk : end;
-            items[io + c] = jmac_item_t{(int32_t)s, b, e, po + c};
+            items[po + c] = jmac_item_t{(int32_t)s, b, e, po + c};
         }
         splits[split_off[s]] = jmac_split_t{(int32_t)s, po, nch, 0};
     }
     if (s == S - 1) {
-        counts[0] = io + nch;
-        counts[1] = split_off[s] + (nch > 1 ? 1 : 0);
-        counts[2] = part_off[s] + (nch > 1 ? nch : 0);
+        counts[0] = n_parts + (int32_t)S - n_splits;
+        counts[1] = n_splits;
+        counts[2] = n_parts;
         counts[3] = 0;
     }
 }
@@ -237,14 +244,11 @@ int jmac_items_build(const int32_t* ptr, int64_t S, int32_t chunk, jmac_item_t* 
     hipError_t e = rocprim::exclusive_scan(nullptr, need, nitem, item_off, 0, (size_t)S, rocprim::plus<int32_t>(), st);
     if (e != hipSuccess) return (int)e;
     if (need > tmp_bytes) return JMAC_EWORKSPACE;
-    e = rocprim::exclusive_scan(tmp, need, nitem, item_off, 0, (size_t)S, rocprim::plus<int32_t>(), st);
-    if (e != hipSuccess) return (int)e;
     e = rocprim::exclusive_scan(tmp, need, npart, part_off, 0, (size_t)S, rocprim::plus<int32_t>(), st);
     if (e != hipSuccess) return (int)e;
     e = rocprim::exclusive_scan(tmp, need, nsplit, split_off, 0, (size_t)S, rocprim::plus<int32_t>(), st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(items_fill_kernel, dim3(nb), dim3(T), 0, st, ptr, S, chunk, item_off, part_off, split_off, items,
-                       splits, counts);
+    hipLaunchKernelGGL(items_fill_kernel, dim3(nb), dim3(T), 0, st, ptr, S, chunk, part_off, split_off, items, splits, counts);
     return (int)hipGetLastError();
 }
 

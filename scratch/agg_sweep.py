@@ -10,6 +10,13 @@ d = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 do_bwd = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 n, e, nr = int(1_000_000 * scale), int(20_000_000 * scale), 1000
 ei, et, n, nrel = synth.power_law_graph(n, e, nr, seed=1234)
+dbg = os.environ.get("DBG", "")
+if "samerel" in dbg: et[:] = 0
+if "samesrc" in dbg: ei[1][:] = 7
+if "regular" in dbg:
+    ei[0] = np.repeat(np.arange(n), e // n)[:e]
+if "uniform" in dbg:
+    ei[0] = np.random.default_rng(1).integers(0, n, e)
 dev = torch.device("cuda")
 g = RelGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(et).to(dev), n, nrel, chunk)
 gen = torch.Generator(device=dev).manual_seed(0)
@@ -25,7 +32,7 @@ with torch.no_grad():
     for _ in range(5): ops.rel_attn_aggregate(PQZ, RR, a, g, 0.05, nrel - 1, 0.5, 1)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
-print("GRID=%s U=%s chunk=%s items=%d splits=%d  fwd %.3f ms  %.0f GB/s (%.1f%% of 8TB/s)" % (os.environ.get("JMAC_GRID"), os.environ.get("JMAC_FWD_U"), g.chunk, g.by_dst.n_items_max, g.by_dst.n_splits_max, ms, fb / ms / 1e6, fb / ms / 1e6 / 80))
+print(dbg, "GRID=%s U=%s chunk=%s items=%d splits=%d  fwd %.3f ms  %.0f GB/s (%.1f%% of 8TB/s)" % (os.environ.get("JMAC_GRID"), os.environ.get("JMAC_FWD_U"), g.chunk, g.by_dst.n_items_max, g.by_dst.n_splits_max, ms, fb / ms / 1e6, fb / ms / 1e6 / 80))
 if do_bwd:
     g.ensure_backward_views()
     out = ops.rel_attn_aggregate(PQZ, RR, a, g, 0.05, nrel - 1, 0.5, 1)
