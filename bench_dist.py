@@ -1,0 +1,111 @@
+"""Destination-sharded synthetic workload for bench.py (--gpus N > 1, or --workload synth-1m at N = 1).
+
+BASELINE config 4 scaled weakly: every rank owns ``n_loc`` = 1M x scale entities and the ``e_loc`` = 20M x scale
+triples that point INTO them (power-law in-degree inside the rank's range, sources uniform over the whole
+graph, relation types Zipf over 1 000), so per-GPU work is fixed as N grows ("weak") and the 8-GPU run is
+the 8M-entity / 160M-triple graph.  One step = two stacked RelationAwareLayers forward + backward over the
+whole graph (jmac_amd.dist.ShardedRelationAwareLayer: per layer one all-gather of the [Q|Z] table over xGMI,
+one [2,d] all-reduce for the BN statistics; backward one reduce-scatter per layer) + gradient all-reduce +
+fused Adam.  value = 2 layers x E_total / step time.
+"""
+import os
+import time
+import types
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _local_graph(rank, world, n_loc, e_loc, nr, seed=1234):
+    """Edges whose destination is owned by `rank`; ids are global."""
+    from jmac_amd import synth
+    ei, et, _, _ = synth.power_law_graph(n_loc, e_loc, nr, seed=seed + 17 * rank)
+    rng = np.random.default_rng(seed + 1000 + rank)
+    ei[0] += rank * n_loc                                             # own destination range
+    ei[1] = rng.integers(0, n_loc * world, size=e_loc, dtype=np.int64)  # sources: anywhere
+    return ei, et
+
+
+def run_sharded(a, rank, world, device):
+    from jmac_amd import ops, synth
+    from jmac_amd.dist import ShardedGraph, ShardedRelationAwareLayer, allreduce_grads
+    from jmac_amd.layer import RelationAwareLayer
+    d, nr = a.dim, 1000
+    n_loc, e_loc = int(1_000_000 * a.synth_scale), int(20_000_000 * a.synth_scale)
+    ei, et = _local_graph(rank, world, n_loc, e_loc, nr)
+    bounds = np.arange(world + 1, dtype=np.int64) * n_loc
+    sg = ShardedGraph(ei, et, bounds, rank, already_local=True)
+    del ei, et
+    torch.manual_seed(7)                                              # identical replicated parameters on every rank
+    largs = types.SimpleNamespace(leaky_relu_w=0.05, comp_op="sub")
+    layers = [ShardedRelationAwareLayer(RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=largs).to(device))
+              for _ in range(2)]
+    rel = torch.nn.Parameter(torch.randn(nr, d, device=device) * (2.0 / (nr + d)) ** 0.5)
+    gen = torch.Generator(device=device).manual_seed(100 + rank)
+    x = torch.nn.Parameter(torch.randn(n_loc, d, device=device, generator=gen) * (2.0 / (n_loc * world + d)) ** 0.5)
+    target = torch.randn(n_loc, d, device=device, generator=gen)
+    shared = [p for l in layers for p in l.parameters()] + [rel]
+    opt = torch.optim.Adam(shared + [x], lr=1e-3, fused=True)
+    for l in layers:
+        l.train()
+    sg.rel_graph(device, nr + 1).ensure_backward_views()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        h = x
+        for l in layers:
+            h = l(h, rel, sg)
+        loss = (h * target).mean()
+        loss.backward()
+        allreduce_grads(shared)
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = tt.item()
+    e_total = e_loc * world
+    value = 2 * e_total * a.steps / el
+
+    # per-kernel timing of the rank-local aggregation (HIP events on the launch stream), rank 0
+    ops.PROFILE = []
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    rec, ops.PROFILE = ops.PROFILE, None
+    fwd = [e0.elapsed_time(e1) for n, e0, e1 in rec if n == "rel_attn_fwd"]
+    bwd = [e0.elapsed_time(e1) for n, e0, e1 in rec if n == "rel_attn_bwd"]
+    fb = synth.fwd_algorithmic_bytes(n_loc, e_loc, d) - n_loc * d * 4     # no fused self term: Z[i] is not read
+    bb = synth.bwd_algorithmic_bytes(n_loc, e_loc, d)
+    fms, bms = float(np.mean(fwd)), float(np.mean(bwd))
+    line = {"metric": "gnn_layer_edges_per_s", "value": value, "unit": "edges/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config 4 weak-scaled: per GPU %d entities / %d triples / %d relations (power-law "
+                                   "in-degree), d=%d; 2 stacked RelationAwareLayers fwd+bwd + grad all-reduce + Adam; "
+                                   "destination-sharded, all-gather of [Q|Z] per layer" % (n_loc, e_loc, nr, d),
+                       "global_entities": n_loc * world, "global_triples": e_total, "parallelism": "dst-shard x%d" % world,
+                       "edges_counted_per_step": 2 * e_total},
+            "roofline": {"bound": "hbm", "kernel": "rel_attn_fwd_kernel (rank 0, local rows)", "achieved": fb / (fms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": fb, "avg_launch_ms": fms, "launches": len(fwd)},
+            "roofline_bwd": {"bound": "hbm", "achieved": bb / (bms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": bb / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": bms},
+            "cpu_baseline": None}
+    return line

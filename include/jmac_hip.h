@@ -88,6 +88,9 @@ int jmac_items_build(const int32_t* ptr, int64_t S, int32_t chunk, jmac_item_t* 
  * for edges e = (i <- j, type t).  Tables: P [N,d] (ldp); QZ [N,2d] = Q|Z per node (ldqz);
  * RR [nr+1,2d] = Rq|Rz per relation (ldrr); a_att [d].  loop_rel < 0 drops the bracketed self term.
  * seg_max/seg_den [N] receive the per-destination softmax max / denominator for the backward.
+ * Destinations (rows of P / out, N of them) and sources (rows of QZ, Nsrc >= max(col)+1 of them) may be
+ * different index spaces (destination-sharded multi-GPU: P holds the rank's rows, QZ the all-gathered
+ * table); the fused self term (loop_rel >= 0) reads QZ[i] and therefore needs the two spaces to coincide.
  * --------------------------------------------------------------------------------------------- */
 size_t jmac_rel_attn_fwd_workspace_bytes(int64_t n_parts_max, int64_t d);
 
@@ -126,8 +129,8 @@ int jmac_rel_attn_aggregate_bwd_f32(
     const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR, int64_t ldrr,
     const float* a_att, const int32_t* col, const int32_t* etype, const int32_t* dst_of_slot,
     const jmac_view_t* by_dst, const jmac_view_t* by_src, const jmac_view_t* by_rel,
-    int64_t N, int64_t E, int64_t nrel, int64_t d, float slope, int32_t loop_rel, float out_scale,
-    const float* out, int64_t ldo, const float* seg_max, const float* seg_den,
+    int64_t N, int64_t Nsrc, int64_t E, int64_t nrel, int64_t d, float slope, int32_t loop_rel,
+    float out_scale, const float* out, int64_t ldo, const float* seg_max, const float* seg_den,
     const float* G, int64_t ldg,
     float* dP, int64_t lddp, float* dQZ, int64_t lddqz, float* dRR, int64_t lddrr, float* da,
     int32_t mode, void* ws, size_t ws_bytes, jmac_stream_t stream);

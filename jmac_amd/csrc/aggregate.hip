@@ -735,12 +735,13 @@ size_t jmac_rel_attn_bwd_workspace_bytes(int64_t N, int64_t E, int64_t nrel, int
 int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR,
                                     int64_t ldrr, const float* a_att, const int32_t* col, const int32_t* etype,
                                     const int32_t* dst_of_slot, const jmac_view_t* by_dst, const jmac_view_t* by_src,
-                                    const jmac_view_t* by_rel, int64_t N, int64_t E, int64_t nrel, int64_t d,
+                                    const jmac_view_t* by_rel, int64_t N, int64_t Nsrc, int64_t E, int64_t nrel, int64_t d,
                                     float slope, int32_t loop_rel, float out_scale, const float* out, int64_t ldo,
                                     const float* seg_max, const float* seg_den, const float* G, int64_t ldg, float* dP,
                                     int64_t lddp, float* dQZ, int64_t lddqz, float* dRR, int64_t lddrr, float* da,
                                     int32_t mode, void* ws, size_t ws_bytes, jmac_stream_t stream) {
-    if (N < 0 || E < 0 || nrel <= 0) return JMAC_EINVAL;
+    if (N < 0 || Nsrc < 0 || E < 0 || nrel <= 0) return JMAC_EINVAL;
+    if (loop_rel >= 0 && Nsrc != N) return JMAC_EINVAL;   // the fused self term indexes QZ by destination
     if (!P || !QZ || !RR || !a_att || !by_dst || !out || !seg_max || !seg_den || !G || !dP || !dQZ || !dRR || !da)
         return JMAC_EINVAL;
     if (mode != 0 && (!by_src || !by_rel || !dst_of_slot)) return JMAC_EINVAL;
@@ -774,7 +775,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
     const bool slope01 = slope >= 0.f && slope <= 1.f;
     if (mode == 0) {
         // dQZ / dRR are accumulated with atomics: initialise them (dZ half of dQZ starts at the self term)
-        hipLaunchKernelGGL(init_dqz_kernel, dim3((unsigned)((N * 2 * d + T - 1) / T)), dim3(T), 0, st, dQZ, lddqz, N, d, G, ldg,
+        hipLaunchKernelGGL(init_dqz_kernel, dim3((unsigned)((Nsrc * 2 * d + T - 1) / T)), dim3(T), 0, st, dQZ, lddqz, Nsrc, d, G, ldg,
                            out_scale, loop_rel >= 0 ? 1 : 0);
         hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((nrel * 2 * d + T - 1) / T)), dim3(T), 0, st, dRR, nrel, 2 * d, lddrr, 0.f);
         JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 0, D4T>), dim3(gridA), dim3(kBlock), 0, st, a));

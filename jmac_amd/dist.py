@@ -1,0 +1,236 @@
+"""Destination-sharded RelationAwareLayer over several GPUs (BASELINE config 4).
+
+The per-destination softmax and sum (modules/helper/message_passing.py:24,28 both index on
+``edge_index[0]``) make destination rows the natural shard: a rank that owns a contiguous row range owns
+every incoming edge of those rows, needs no cross-GPU softmax and writes a disjoint output slab.
+
+Per layer and rank:   x_loc [n_r, d]  --GEMM-->  [P|Q|Z]_loc  --all-gather [Q|Z] over xGMI-->  QZ [world*n_max, 2d]
+                      aggregate own rows (HIP kernels)  -->  + self term  -->  BN with all-reduced [2,d] stats
+Backward: reduce-scatter of d[Q|Z] (adjoint of the all-gather), all-reduce of the tiny parameter grads
+(done by the caller / DDP-style helper ``allreduce_grads``).
+
+One process per GPU, ``torch.distributed`` backend "nccl" (= RCCL).  The direct all-gather uses all seven
+xGMI links of a GPU at once, unlike a ring all-reduce which is bound by one link.  Graphs of DBP-5L scale
+are too small to shard profitably: run replicas instead.
+
+The rank-local compute is pluggable (``local_aggregate``) only so that the CPU test-suite can exercise the
+partitioning and the collectives under ``gloo`` with a stand-in; the default is the HIP op and nothing in
+this module falls back to it silently.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------
+# partitioning
+# ------------------------------------------------------------------------------------------------
+def partition_rows(in_degree: np.ndarray, world: int, node_weight: float = 1.0) -> np.ndarray:
+    """Contiguous destination ranges balanced by work = edges + node_weight * rows.
+    Returns boundaries b[0..world] with b[0] = 0, b[world] = N."""
+    n = int(in_degree.shape[0])
+    work = np.cumsum(in_degree.astype(np.float64) + node_weight)
+    total = work[-1] if n else 0.0
+    b = [0]
+    for r in range(1, world):
+        b.append(int(np.searchsorted(work, total * r / world, side="left")) if n else 0)
+    b.append(n)
+    b = np.maximum.accumulate(np.asarray(b, dtype=np.int64))
+    return b
+
+
+class ShardedGraph:
+    """Rank-local part of a typed edge list: edges whose destination lies in [lo, hi).
+
+    Destinations are re-indexed locally (dst - lo); sources are re-indexed into the PADDED all-gather
+    layout, position = owner_rank * n_max + (src - bounds[owner]), so the gathered [world*n_max, 2d] table
+    is used as it arrives."""
+
+    def __init__(self, edge_index: np.ndarray, edge_type: np.ndarray, bounds: Sequence[int], rank: int,
+                 already_local: bool = False):
+        bounds = np.asarray(bounds, dtype=np.int64)
+        self.bounds, self.rank, self.world = bounds, rank, len(bounds) - 1
+        self.lo, self.hi = int(bounds[rank]), int(bounds[rank + 1])
+        self.n_local = self.hi - self.lo
+        self.n_max = int(np.max(bounds[1:] - bounds[:-1])) if self.world else 0
+        self.n_global = int(bounds[-1])
+        dst, src = np.asarray(edge_index[0]), np.asarray(edge_index[1])
+        if not already_local:
+            keep = (dst >= self.lo) & (dst < self.hi)
+            dst, src, edge_type = dst[keep], src[keep], np.asarray(edge_type)[keep]
+        owner = np.searchsorted(bounds, src, side="right") - 1
+        self.dst_local = (dst - self.lo).astype(np.int64)
+        self.src_padded = (owner * self.n_max + (src - bounds[owner])).astype(np.int64)
+        self.edge_type = np.asarray(edge_type).astype(np.int64)
+        self.E_local = int(self.dst_local.shape[0])
+        self._rel_graph = None
+
+    def coo(self, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        ei = torch.from_numpy(np.stack([self.dst_local, self.src_padded])).to(device)
+        return ei, torch.from_numpy(self.edge_type).to(device)
+
+    def rel_graph(self, device, num_rel: int):
+        """CSR + schedules on the HIP device (cached)."""
+        if self._rel_graph is None:
+            from .graph import RelGraph
+            ei, et = self.coo(device)
+            self._rel_graph = RelGraph(ei, et, self.n_local, num_rel, None, num_src=self.world * self.n_max)
+        return self._rel_graph
+
+
+# ------------------------------------------------------------------------------------------------
+# differentiable collectives
+# ------------------------------------------------------------------------------------------------
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def _all_reduce(t: torch.Tensor, group=None) -> None:
+    """In-place sum. RCCL for device tensors; under gloo (tests) device tensors are staged through the host."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """[n_max, w] per rank -> [world*n_max, w]; backward = reduce-scatter (sum) of the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        world = _world(group)
+        if world == 1:
+            return x
+        x = x.contiguous()
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        if x.is_cuda and dist.get_backend(group) == "gloo":           # tests only: stage through the host
+            h = torch.empty(out.shape, dtype=x.dtype)
+            dist.all_gather_into_tensor(h, x.cpu(), group=group)
+            out.copy_(h)
+        else:
+            dist.all_gather_into_tensor(out, x, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        world = _world(ctx.group)
+        if world == 1:
+            return g, None
+        g = g.contiguous()
+        n = g.shape[0] // world
+        if dist.get_backend(ctx.group) == "gloo":          # gloo has no reduce_scatter: all-reduce + slice
+            _all_reduce(g, ctx.group)
+            r = dist.get_rank(ctx.group)
+            return g[r * n:(r + 1) * n].clone(), None
+        out = torch.empty((n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        dist.reduce_scatter_tensor(out, g, group=ctx.group)
+        return out, None
+
+
+class _AllReduceSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        if _world(group) == 1:
+            return x
+        y = x.clone()
+        _all_reduce(y, group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if _world(ctx.group) == 1:
+            return g, None
+        g = g.clone()
+        _all_reduce(g, ctx.group)
+        return g, None
+
+
+def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
+    return _AllGatherRows.apply(x, group)
+
+
+def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
+    return _AllReduceSum.apply(x, group)
+
+
+def allreduce_grads(params, group=None) -> None:
+    """Sum the (replicated) parameters' gradients over ranks, one flat bucket."""
+    if _world(group) == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    _all_reduce(flat, group)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+def sync_batch_norm(x: torch.Tensor, n_global: int, bn: nn.BatchNorm1d, group=None) -> torch.Tensor:
+    """BatchNorm1d(x) with batch statistics over the rows of ALL ranks (the bn of src/jmac_model.py:52):
+    the [2,d] column sums are all-reduced; running statistics are updated like nn.BatchNorm1d."""
+    if not (bn.training or not bn.track_running_stats):
+        return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+    sums = torch.stack([x.sum(0), (x * x).sum(0)])
+    sums = all_reduce_sum(sums, group)
+    mean = sums[0] / n_global
+    var = (sums[1] / n_global - mean * mean).clamp_min(0)
+    if bn.track_running_stats:
+        with torch.no_grad():
+            m = bn.momentum if bn.momentum is not None else 0.1
+            bn.running_mean.mul_(1 - m).add_(mean.detach(), alpha=m)
+            unb = var.detach() * (n_global / max(n_global - 1, 1))
+            bn.running_var.mul_(1 - m).add_(unb, alpha=m)
+            bn.num_batches_tracked.add_(1)
+    return (x - mean) * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias
+
+
+# ------------------------------------------------------------------------------------------------
+# the sharded layer
+# ------------------------------------------------------------------------------------------------
+def hip_local_aggregate(P, QZ, RR, a, sg: ShardedGraph, slope: float) -> torch.Tensor:
+    """nb[i] = sqrt(deg_i) * sum_e alpha_e (Z[j]-Rz[t]) for the rank's rows, on the HIP kernels."""
+    from . import ops
+    return ops.rel_attn_aggregate_split(P, QZ, RR, a, sg.rel_graph(P.device, RR.shape[0]), slope, 1.0)
+
+
+class ShardedRelationAwareLayer(nn.Module):
+    """RelationAwareLayer (src/jmac_model.py:10-53) on a destination-sharded graph.
+
+    ``forward(x_local [n_r, d], rel_emb [nr, d], sg)`` returns the rank's [n_r, d] output slab; parameters
+    are replicated (same names as the reference layer), their gradients summed with ``allreduce_grads``."""
+
+    def __init__(self, layer: nn.Module, group=None, local_aggregate: Optional[Callable] = None):
+        super().__init__()
+        self.layer = layer                       # a jmac_amd.layer.RelationAwareLayer (holds the parameters)
+        self.group = group
+        self.local_aggregate = local_aggregate or hip_local_aggregate
+
+    def forward(self, x_local: torch.Tensor, rel_emb: torch.Tensor, sg: ShardedGraph) -> torch.Tensor:
+        L = self.layer
+        if L.comp_op != "sub":
+            raise NotImplementedError("the sharded path covers comp_op='sub' (the factorised form)")
+        d = L.out_channels
+        if d % 4:
+            raise NotImplementedError("sharded path needs out_channels % 4 == 0")
+        rel = L.transform_relations(rel_emb)
+        PQZ, RR, a, _ = L._tables(x_local, rel)                      # own rows only: 1/world of the GEMM
+        P, QZ_loc, Z_loc = PQZ[:, :d], PQZ[:, d:], PQZ[:, 2 * d:]
+        if sg.n_local < sg.n_max:                                    # pad to the common slab height
+            QZ_loc = F.pad(QZ_loc, (0, 0, 0, sg.n_max - sg.n_local))
+        QZ = all_gather_rows(QZ_loc.contiguous(), self.group)        # [world*n_max, 2d]
+        nb = self.local_aggregate(P.contiguous(), QZ, RR, a, sg, L.atv_mlp.negative_slope)
+        pre = (nb + Z_loc - RR[-1, d:]) * 0.5                        # self loop: softmax over a singleton
+        return L.layer_act(sync_batch_norm(pre, sg.n_global, L.bn, self.group))

@@ -67,7 +67,7 @@ class RelGraph:
     """
 
     def __init__(self, edge_index: torch.Tensor, edge_type: torch.Tensor, num_nodes: int, num_rel: int,
-                 chunk: Optional[int] = DEFAULT_CHUNK):
+                 chunk: Optional[int] = DEFAULT_CHUNK, num_src: Optional[int] = None):
         require_device(edge_index, edge_type)
         if chunk is None:
             chunk = auto_chunk(int(edge_index.shape[1]))
@@ -78,6 +78,8 @@ class RelGraph:
         L = lib()
         dev = edge_index.device
         self.N, self.E, self.num_rel, self.chunk = int(num_nodes), int(edge_index.shape[1]), int(num_rel), int(chunk)
+        # sources may live in another index space than destinations (destination-sharded multi-GPU)
+        self.num_src = int(num_src) if num_src is not None else self.N
         self.device = dev
         ei = edge_index.contiguous().to(torch.int64)
         et = edge_type.contiguous().to(torch.int64)
@@ -117,7 +119,7 @@ class RelGraph:
                   "jmac_group_build")
             return _Schedule(seg_ptr, n_seg, E, self.chunk, order)
 
-        self.by_src = group(self.col, N)
+        self.by_src = group(self.col, self.num_src)
         self.by_rel = group(self.etype, self.num_rel)
         self._ei = None
         self._bwd_ready = True

@@ -101,7 +101,7 @@ class _RelAttnAggregate(torch.autograd.Function):
             ptr(PQZ), d3, PQZ.data_ptr() + d * esz, d3, ptr(RR), RR.shape[1], ptr(a),
             ptr(graph.col), ptr(graph.etype), ptr(graph.dst_of_slot) if mode else None,
             C.byref(vd), C.byref(vs) if mode else None, C.byref(vr) if mode else None,
-            N, graph.E, nrel, d, float(ctx.slope), int(ctx.loop_rel), float(ctx.out_scale),
+            N, N, graph.E, nrel, d, float(ctx.slope), int(ctx.loop_rel), float(ctx.out_scale),
             ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(G), d,
             ptr(dPQZ), d3, dPQZ.data_ptr() + d * esz, d3, ptr(dRR), dRR.shape[1], ptr(da),
             mode, ptr(ws), ws_bytes, stream()), "jmac_rel_attn_aggregate_bwd_f32")
@@ -114,6 +114,69 @@ def rel_attn_aggregate(PQZ: torch.Tensor, RR: torch.Tensor, a: torch.Tensor, gra
                        loop_rel: int = -1, out_scale: float = 1.0,
                        bwd_mode: int = BWD_MODE_DETERMINISTIC) -> torch.Tensor:
     return _RelAttnAggregate.apply(PQZ, RR, a, graph, float(slope), int(loop_rel), float(out_scale), int(bwd_mode))
+
+
+class _RelAttnAggregateSplit(torch.autograd.Function):
+    """Same op with P [N_dst, d] and QZ [N_src, 2d] as separate tables (destination-sharded multi-GPU: P holds
+    the rank's rows, QZ the all-gathered table).  No fused self term (the two index spaces differ)."""
+
+    @staticmethod
+    def forward(ctx, P, QZ, RR, a, graph: RelGraph, slope: float, out_scale: float):
+        require_device(P, QZ, RR, a)
+        P, QZ, RR, a = _f32c(P).contiguous(), _f32c(QZ).contiguous(), _f32c(RR).contiguous(), _f32c(a).contiguous()
+        N, d = P.shape
+        if graph.N != N or graph.num_src != QZ.shape[0] or QZ.shape[1] != 2 * d:
+            raise ValueError("graph / table shapes disagree")
+        L = lib()
+        dev = P.device
+        out = torch.empty((N, d), dtype=torch.float32, device=dev)
+        seg_max = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+        seg_den = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+        s = graph.by_dst
+        ws_bytes = int(L.jmac_rel_attn_fwd_workspace_bytes(s.n_parts_max, d))
+        ws = _ws(ws_bytes, dev)
+        ev0 = _ev() if PROFILE is not None else None
+        check(L.jmac_rel_attn_aggregate_fwd_f32(
+            ptr(P), d, ptr(QZ), 2 * d, ptr(RR), RR.shape[1], ptr(a),
+            ptr(graph.rowptr), ptr(graph.col), ptr(graph.etype), ptr(s.items), ptr(s.splits), ptr(s.counts),
+            s.n_items_max, s.n_splits_max, s.n_parts_max, N, d, float(slope), -1, float(out_scale),
+            ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(ws), ws_bytes, stream()), "jmac_rel_attn_aggregate_fwd_f32")
+        if ev0 is not None:
+            PROFILE.append(("rel_attn_fwd", ev0, _ev()))
+        ctx.save_for_backward(P, QZ, RR, a, out, seg_max, seg_den)
+        ctx.graph, ctx.slope, ctx.out_scale = graph, slope, out_scale
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        P, QZ, RR, a, out, seg_max, seg_den = ctx.saved_tensors
+        graph: RelGraph = ctx.graph
+        L = lib()
+        dev = P.device
+        N, d = P.shape
+        nsrc, nrel = QZ.shape[0], RR.shape[0]
+        G = _f32c(G).contiguous()
+        graph.ensure_backward_views()
+        dP, dQZ, dRR, da = torch.empty_like(P), torch.empty_like(QZ), torch.empty_like(RR), torch.empty_like(a)
+        vd, vs, vr = graph.by_dst.view(), graph.by_src.view(), graph.by_rel.view()
+        ws_bytes = int(L.jmac_rel_attn_bwd_workspace_bytes(N, graph.E, nrel, d, graph.by_dst.n_parts_max,
+                                                           graph.by_src.n_parts_max, graph.by_rel.n_parts_max, 1))
+        ws = _ws(ws_bytes, dev)
+        ev0 = _ev() if PROFILE is not None else None
+        check(L.jmac_rel_attn_aggregate_bwd_f32(
+            ptr(P), d, ptr(QZ), 2 * d, ptr(RR), RR.shape[1], ptr(a),
+            ptr(graph.col), ptr(graph.etype), ptr(graph.dst_of_slot), C.byref(vd), C.byref(vs), C.byref(vr),
+            N, nsrc, graph.E, nrel, d, float(ctx.slope), -1, float(ctx.out_scale),
+            ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(G), d,
+            ptr(dP), d, ptr(dQZ), 2 * d, ptr(dRR), dRR.shape[1], ptr(da), 1, ptr(ws), ws_bytes, stream()),
+            "jmac_rel_attn_aggregate_bwd_f32")
+        if ev0 is not None:
+            PROFILE.append(("rel_attn_bwd", ev0, _ev()))
+        return dP, dQZ, dRR, da, None, None, None
+
+
+def rel_attn_aggregate_split(P, QZ, RR, a, graph: RelGraph, slope: float, out_scale: float = 1.0) -> torch.Tensor:
+    return _RelAttnAggregateSplit.apply(P, QZ, RR, a, graph, float(slope), float(out_scale))
 
 
 class _BnTanh(torch.autograd.Function):

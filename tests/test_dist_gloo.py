@@ -1,0 +1,118 @@
+"""CPU, world_size 2, gloo: the destination-sharded layer (jmac_amd/dist.py) -- partitioning, padded
+all-gather layout, reduce-scatter adjoint, synchronised BN statistics, gradient all-reduce -- reproduces the
+single-process oracle.  The rank-local aggregation is a torch stand-in INJECTED by this test (the product's
+default is the HIP op; there is no CPU fallback in jmac_amd)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle.jmac_oracle as orc
+from util import make_args, random_graph
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _standin_aggregate(P, QZ, RR, a, sg, slope):
+    """Test double for the HIP kernel: the factorised edge formula with the oracle's scatter ops."""
+    d = P.shape[1]
+    dst, src, typ = torch.from_numpy(sg.dst_local), torch.from_numpy(sg.src_padded), torch.from_numpy(sg.edge_type)
+    diff = QZ[src] - RR[typ]
+    h = P[dst] + diff[:, :d]
+    s = torch.nn.functional.leaky_relu(h, slope) @ a.view(-1, 1)
+    alpha = orc.scatter_softmax(s, dst, sg.n_local)
+    deg = orc.scatter_sum(torch.ones(dst.shape[0]), dst, sg.n_local)
+    return orc.scatter_sum(alpha * diff[:, d:], dst, sg.n_local) * deg.sqrt().view(-1, 1)
+
+
+def _case(seed=3, n=90, nr=7, d=16, e=700):
+    rng = np.random.default_rng(seed)
+    ei, et = random_graph(rng, n, nr, e, hub=120)
+    gen = torch.Generator().manual_seed(seed)
+    X = torch.randn(n, d, generator=gen) * 0.8
+    R = torch.randn(nr, d, generator=gen) * 0.8
+    G = torch.randn(n, d, generator=gen)
+    return ei, et, X, R, G, n, nr, d
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from jmac_amd.dist import ShardedGraph, ShardedRelationAwareLayer, allreduce_grads, partition_rows
+        from jmac_amd.layer import RelationAwareLayer
+        ei, et, X, R, G, n, nr, d = _case()
+        bounds = partition_rows(np.bincount(ei[0], minlength=n), world)
+        sg = ShardedGraph(ei, et, bounds, rank)
+        torch.manual_seed(11)
+        base = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())
+        lay = ShardedRelationAwareLayer(base, local_aggregate=_standin_aggregate).train()
+        x = X[sg.lo:sg.hi].clone().requires_grad_(True)
+        r = R.clone().requires_grad_(True)
+        out = lay(x, r, sg)
+        (out * G[sg.lo:sg.hi]).sum().backward()
+        params = list(base.parameters()) + [r]
+        allreduce_grads(params)
+        ret[rank] = dict(lo=sg.lo, hi=sg.hi, out=out.detach(), gx=x.grad, gr=r.grad,
+                         grads={k: v.grad.clone() for k, v in base.named_parameters()},
+                         rm=base.bn.running_mean.clone(), rv=base.bn.running_var.clone(),
+                         e_local=sg.E_local, n_max=sg.n_max)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_layer_equals_single_process_oracle():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    ei, et, X, R, G, n, nr, d = _case()
+    from jmac_amd.layer import RelationAwareLayer
+    torch.manual_seed(11)
+    base = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in base.named_parameters()}
+    Xc, Rc = X.clone().requires_grad_(True), R.clone().requires_grad_(True)
+    rm, rv = torch.zeros(d), torch.ones(d)
+    ref = orc.layer_forward(p, Xc, Rc, torch.from_numpy(ei), torch.from_numpy(et), 0.05, "sub", "leaky_relu", True, rm, rv)
+    (ref * G).sum().backward()
+    assert sum(ret[r]["e_local"] for r in range(world)) == ei.shape[1]
+    assert ret[0]["hi"] == ret[1]["lo"] and ret[0]["lo"] == 0 and ret[1]["hi"] == n
+    for r in range(world):
+        o = ret[r]
+        lo, hi = o["lo"], o["hi"]
+        assert torch.allclose(o["out"], ref[lo:hi].detach(), atol=2e-5), r
+        assert torch.allclose(o["gx"], Xc.grad[lo:hi], atol=2e-4, rtol=1e-3), r
+        assert torch.allclose(o["gr"], Rc.grad, atol=2e-4, rtol=1e-3)
+        for k, g in o["grads"].items():
+            assert torch.allclose(g, p[k].grad, atol=5e-4, rtol=1e-3), k
+        assert torch.allclose(o["rm"], rm, atol=1e-6) and torch.allclose(o["rv"], rv, atol=1e-6)
+
+
+def test_partition_rows_balances_edges():
+    from jmac_amd.dist import ShardedGraph, partition_rows
+    rng = np.random.default_rng(0)
+    deg = rng.zipf(2.0, 5000).clip(max=800)
+    for world in (1, 2, 4, 8):
+        b = partition_rows(deg, world)
+        assert b[0] == 0 and b[-1] == 5000 and (np.diff(b) >= 0).all()
+        work = np.array([deg[b[i]:b[i + 1]].sum() + (b[i + 1] - b[i]) for i in range(world)])
+        assert work.max() <= work.mean() + deg.max() + 1
+    # padded source index space
+    ei = np.stack([rng.integers(0, 100, 400), rng.integers(0, 100, 400)])
+    b = np.array([0, 30, 100])
+    sg = ShardedGraph(ei, rng.integers(0, 5, 400), b, 1)
+    assert sg.n_max == 70 and sg.n_local == 70
+    owner = (ei[1][(ei[0] >= 30)] >= 30).astype(int)
+    src = ei[1][ei[0] >= 30]
+    assert (sg.src_padded == owner * 70 + (src - b[owner])).all()

@@ -1,0 +1,87 @@
+"""GPU: the destination-sharded layer with the HIP kernels as the rank-local op.  Two ranks share the one
+GPU of the test box and talk over gloo (RCCL refuses two ranks on one device); the collectives' RCCL path is
+exercised by the driver's multi-GPU bench.  Result must equal the single-process float64 oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+import oracle.jmac_oracle as orc
+from util import assert_close, make_args, random_graph
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _case(seed=5, n=700, nr=11, d=300, e=9000):
+    rng = np.random.default_rng(seed)
+    ei, et = random_graph(rng, n, nr, e, hub=900)
+    gen = torch.Generator().manual_seed(seed)
+    X = torch.randn(n, d, generator=gen) * (4 / np.sqrt(d))
+    R = torch.randn(nr, d, generator=gen) * (4 / np.sqrt(d))
+    G = torch.randn(n, d, generator=gen)
+    return ei, et, X, R, G, n, nr, d
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from jmac_amd.dist import ShardedGraph, ShardedRelationAwareLayer, allreduce_grads, partition_rows
+        from jmac_amd.layer import RelationAwareLayer
+        dev = torch.device("cuda", 0)
+        ei, et, X, R, G, n, nr, d = _case()
+        bounds = partition_rows(np.bincount(ei[0], minlength=n), world)
+        sg = ShardedGraph(ei, et, bounds, rank)
+        torch.manual_seed(11)
+        base = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args()).to(dev)
+        lay = ShardedRelationAwareLayer(base).train()                   # default local op = HIP kernels
+        x = X[sg.lo:sg.hi].to(dev).requires_grad_(True)
+        r = R.to(dev).requires_grad_(True)
+        out = lay(x, r, sg)
+        (out * G[sg.lo:sg.hi].to(dev)).sum().backward()
+        allreduce_grads(list(base.parameters()) + [r])
+        torch.cuda.synchronize()
+        ret[rank] = dict(lo=sg.lo, hi=sg.hi, out=out.detach().cpu(), gx=x.grad.cpu(), gr=r.grad.cpu(),
+                         grads={k: v.grad.cpu() for k, v in base.named_parameters()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_hip_layer_two_ranks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    ei, et, X, R, G, n, nr, d = _case()
+    from jmac_amd.layer import RelationAwareLayer
+    torch.manual_seed(11)
+    base = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())
+    f64 = torch.float64
+    p = {k: v.detach().clone().to(f64).requires_grad_(True) for k, v in base.named_parameters()}
+    Xc, Rc = X.to(f64).requires_grad_(True), R.to(f64).requires_grad_(True)
+    ref = orc.layer_forward(p, Xc, Rc, torch.from_numpy(ei), torch.from_numpy(et), 0.05, "sub", "leaky_relu", True,
+                            torch.zeros(d, dtype=f64), torch.ones(d, dtype=f64))
+    (ref * G.to(f64)).sum().backward()
+    gscale = Rc.grad.abs().max().item()
+    for r in range(world):
+        o = ret[r]
+        lo, hi = o["lo"], o["hi"]
+        assert_close(o["out"], ref[lo:hi], 1e-4, 1e-6, "out")
+        assert_close(o["gx"], Xc.grad[lo:hi], 1e-4, 1e-6, "grad_X")
+        assert_close(o["gr"], Rc.grad, 1e-4, 1e-6, "grad_R")
+        for k, g in o["grads"].items():
+            atol = 1e-4 * gscale + 1e-6 if k == "loop_rel" else 1e-6
+            assert_close(g, p[k].grad, 1e-4, atol, "grad " + k)
