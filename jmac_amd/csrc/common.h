@@ -80,6 +80,12 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[U]) {
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// non-temporal (streaming) 16-byte load: for rows that are read once, so they do not evict the relation table
+typedef float jmac_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+    const jmac_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const jmac_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
