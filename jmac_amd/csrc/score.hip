@@ -23,6 +23,15 @@ constexpr int kBlock = 256;
 // ------------------------------------------------------------------------------------------------
 constexpr int L1_T = 64, L1_K = 16, L1_LD = L1_T + 4;
 
+// acc + |a - b| in two full-rate VALU ops (v_sub_f32, v_add_f32 with the |.| source modifier).  Left to the
+// compiler, fabsf() becomes v_and_b32 and the adds are SLP-packed into half-rate v_pk_add_f32: 3 issue slots.
+__device__ __forceinline__ float add_absdiff(float acc, float a, float b) {
+    float d, r;
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    asm("v_add_f32_e64 %0, %1, |%2|" : "=v"(r) : "v"(acc), "v"(d));
+    return r;
+}
+
 __global__ __launch_bounds__(kBlock) void l1_score_kernel(const float* __restrict__ er, int64_t lder,
                                                           const float* __restrict__ tab, int64_t ldt, int B, int N, int d,
                                                           float* __restrict__ out, int64_t ldout, int accumulate) {
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void l1_score_kernel(const float* __restric
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += fabsf(av[i] - bv[j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = add_absdiff(acc[i][j], av[i], bv[j]);
         }
         if (kt + 1 < nk) {
             sstore(As[cur ^ 1], ra);
