@@ -13,6 +13,7 @@
 // max / denominator), so each edge row is read exactly once.  The relation table [Rq|Rz] stays
 // L2-resident.  HBM-bound by design: see DESIGN.md for the byte model.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -27,6 +28,14 @@ constexpr int kPersistBlocks = 2048;   // 256 CUs x 8
 #define JMAC_NT_GATHER 0   // measured: nt gathers 13.4 vs 12.3 ms on config 4, 36 vs 26 us on ja -> off
 #endif
 constexpr bool kNtGather = JMAC_NT_GATHER != 0;
+
+// IGroupLP pipeline for the machine scheduler: first the group's n vector-memory reads, then the vector ALU work.
+// (A plain sched_barrier does not do it: instruction selection already linearises the arithmetic ahead of it.)
+#define JMAC_LOADS_FIRST(n)                                         \
+    do {                                                            \
+        __builtin_amdgcn_sched_group_barrier(0x020, (n), 0);        \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4096, 0);       \
+    } while (0)
 
 struct FwdArgs {
     const float *P, *QZ, *RR, *a_att;
@@ -104,8 +113,29 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
     const bool has_loop = a.loop_rel >= 0;
     const float* rloop = a.RR + (int64_t)(has_loop ? a.loop_rel : 0) * a.ldrr;
 
-    for (int it = blockIdx.x * kWavesPerBlock + wave; it < n_items; it += nwaves) {
-        const jmac_item_t item = a.items[it];
+    // Items are software-pipelined: while item k computes, the header of item k+2 and the first col/type
+    // batch of item k+1 are already in flight, so a wave's critical path per item is one gather round trip
+    // instead of header -> col/type -> gather (measured: 65k rows of degree 1 took 114 us serialised).
+    int it = blockIdx.x * kWavesPerBlock + wave;
+    if (it >= n_items) return;
+    jmac_item_t item = a.items[it];
+    jmac_item_t nitem = a.items[min(it + nwaves, n_items - 1)];
+    int ccol, ctyp;
+    {
+        const int cnb = min(64, item.end - item.beg);
+        const int idx = cnb > 0 ? item.beg + min(lane, cnb - 1) : 0;
+        ccol = a.col[idx];
+        ctyp = a.etype[idx];
+    }
+    for (;;) {
+        const jmac_item_t nnitem = a.items[min(it + 2 * nwaves, n_items - 1)];
+        int ncol, ntyp;
+        {
+            const int nnb = min(64, nitem.end - nitem.beg);
+            const int idx = nnb > 0 ? nitem.beg + min(lane, nnb - 1) : 0;
+            ncol = a.col[idx];
+            ntyp = a.etype[idx];
+        }
         const int i = item.seg;
         float4 pv[NCH], acc[NCH];
         const float* prow = a.P + (int64_t)i * a.ldp;
@@ -119,19 +149,24 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
         for (int k = 0; k < NCH; ++k)
             if (L.any_h(k) && L.any_v(k)) pv[k] = sel4(L.is_h[k], pv[k]);
         float m = -INFINITY, l = 0.f;
+        int my_col = ccol, my_typ = ctyp;
         for (int e0 = item.beg; e0 < item.end; e0 += 64) {
             const int nb = min(64, item.end - e0);
-            const int le = min(lane, nb - 1);
-            const int my_col = a.col[e0 + le];
-            const int my_typ = a.etype[e0 + le];
-            for (int u0 = 0; u0 < nb; u0 += U) {
-                float4 q[U][NCH], r[U][NCH];
-                // 1) issue every gather of the group (edges past the end re-read the last edge, weight 0)
+            if (e0 != item.beg) {
+                const int le = min(lane, nb - 1);
+                my_col = a.col[e0 + le];
+                my_typ = a.etype[e0 + le];
+            }
+            // group body for UU edges that are all valid; dispatched on the edges left (4 / 2 / 1) so that a
+            // degree-1 destination does not pay the instruction count of a full 4-edge group
+            auto group = [&](auto uu_c, const int u0) {
+                constexpr int UU = decltype(uu_c)::value;
+                float4 q[UU][NCH], r[UU][NCH];
+                // 1) issue every gather of the group before any arithmetic
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int idx = min(u0 + u, nb - 1);
-                    const int j = bcast_i(my_col, idx);
-                    const int t = bcast_i(my_typ, idx);
+                for (int u = 0; u < UU; ++u) {
+                    const int j = bcast_i(my_col, u0 + u);
+                    const int t = bcast_i(my_typ, u0 + u);
                     const float* qrow = a.QZ + (int64_t)j * a.ldqz;
                     const float* rrow = a.RR + (int64_t)t * a.ldrr;
 #pragma unroll
@@ -140,10 +175,11 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
                         r[u][k] = ld4(rrow + L.coffc[k]);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);   // measured: 11.6 ms vs 13.3 ms with the IGroupLP form (config 4)
                 // 2) logits
-                float s[U];
+                float s[UU];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
+                for (int u = 0; u < UU; ++u) {
                     float part = 0.f;
 #pragma unroll
                     for (int k = 0; k < NCH; ++k) {
@@ -153,19 +189,16 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
                     }
                     s[u] = part;
                 }
-                wave_sum_n<U>(s);
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (!((u0 + u) < nb)) s[u] = -INFINITY;
+                wave_sum_n<UU>(s);
                 // 3) online softmax update
                 float gmax = s[0];
 #pragma unroll
-                for (int u = 1; u < U; ++u) gmax = fmaxf(gmax, s[u]);
+                for (int u = 1; u < UU; ++u) gmax = fmaxf(gmax, s[u]);
                 const float mn = fmaxf(m, gmax);
                 const float sc = fast_exp(m - mn);
-                float w[U], wsum = 0.f;
+                float w[UU], wsum = 0.f;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
+                for (int u = 0; u < UU; ++u) {
                     w[u] = fast_exp(s[u] - mn);
                     wsum += w[u];
                 }
@@ -175,11 +208,21 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
                     if (!L.any_v(k)) continue;
                     float4 x = mul4(acc[k], sc);
 #pragma unroll
-                    for (int u = 0; u < U; ++u) x = fma4(q[u][k], w[u], x);
+                    for (int u = 0; u < UU; ++u) x = fma4(q[u][k], w[u], x);
                     acc[k] = x;
                 }
                 m = mn;
+            };
+            int u0 = 0;
+            if (U >= 4)
+                for (; u0 + 4 <= nb; u0 += 4) group(std::integral_constant<int, 4>{}, u0);
+            if (u0 + 2 <= nb) {
+                group(std::integral_constant<int, 2>{}, u0);
+                u0 += 2;
+                if (U < 4)
+                    for (; u0 + 2 <= nb; u0 += 2) group(std::integral_constant<int, 2>{}, u0);
             }
+            if (u0 < nb) group(std::integral_constant<int, 1>{}, u0);
         }
         if (item.pslot < 0) {
             const int deg = item.end - item.beg;
@@ -208,6 +251,12 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
                 a.part_ml[2 * item.pslot + 1] = l;
             }
         }
+        it += nwaves;
+        if (it >= n_items) break;
+        item = nitem;
+        nitem = nnitem;
+        ccol = ncol;
+        ctyp = ntyp;
     }
 }
 
@@ -344,40 +393,46 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
             const int my_col = a.col[e0 + le];
             const int my_typ = a.etype[e0 + le];
             float my_w = 0.f, my_ds = 0.f;
-            for (int u0 = 0; u0 < nb; u0 += U) {
-                float4 q[U][NCH], r[U][NCH];
+            auto group = [&](auto uu_c, const int u0) {
+                constexpr int UU = decltype(uu_c)::value;
+                float4 q[UU][NCH], r[UU][NCH];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int idx = min(u0 + u, nb - 1);
-                    const int j = bcast_i(my_col, idx);
-                    const int t = bcast_i(my_typ, idx);
+                for (int u = 0; u < UU; ++u) {
+                    const int j = bcast_i(my_col, u0 + u);
+                    const int t = bcast_i(my_typ, u0 + u);
                     const float* qrow = a.QZ + (int64_t)j * a.ldqz;
                     const float* rrow = a.RR + (int64_t)t * a.ldrr;
 #pragma unroll
                     for (int k = 0; k < NCH; ++k) {
-                        q[u][k] = kNtGather ? ld4_nt(qrow + L.coffc[k]) : ld4(qrow + L.coffc[k]);
+                        q[u][k] = ld4(qrow + L.coffc[k]);
                         r[u][k] = ld4(rrow + L.coffc[k]);
                     }
                 }
+                JMAC_LOADS_FIRST(UU * NCH * 2);
+                float4 hv[UU][NCH_H];
+                float sp[UU], up[UU];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (!((u0 + u) < nb)) continue;   // wave-uniform
-                    float4 hv[NCH_H];
+                for (int u = 0; u < UU; ++u) {
                     float spart = 0.f, upart = 0.f;
 #pragma unroll
                     for (int k = 0; k < NCH; ++k) {
                         q[u][k] = sub4(q[u][k], r[u][k]);
                         if (k < NCH_H) {
-                            hv[k] = add4(pv[k], q[u][k]);
-                            if (L.any_h(k)) spart += dot4(av[k], leaky4<D4T != 0>(hv[k], a.slope));
+                            hv[u][k] = add4(pv[k], q[u][k]);
+                            if (L.any_h(k)) spart += dot4(av[k], leaky4<D4T != 0>(hv[u][k], a.slope));
                         }
                         if (L.any_v(k)) upart += dot4(gv[k], q[u][k]);   // gv is zero off the v-role lanes
                     }
-                    const float s = wave_sum(spart);
-                    const float uu = wave_sum(upart);
-                    const float alpha = fast_exp(s - m_i) * inv_l;
+                    sp[u] = spart;
+                    up[u] = upart;
+                }
+                wave_sum_n<UU>(sp);
+                wave_sum_n<UU>(up);
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    const float alpha = fast_exp(sp[u] - m_i) * inv_l;
                     const float w = c_i * alpha;
-                    const float ds = w * uu - alpha * t_i;
+                    const float ds = w * up[u] - alpha * t_i;
                     if (lane == u0 + u) {
                         my_w = w;
                         my_ds = ds;
@@ -386,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
                     float4 dh[NCH_H];
 #pragma unroll
                     for (int k = 0; k < NCH_H; ++k) {
-                        const float4 h = hv[k];
+                        const float4 h = hv[u][k];
                         const float4 g = make_float4(h.x > 0.f ? 1.f : a.slope, h.y > 0.f ? 1.f : a.slope,
                                                      h.z > 0.f ? 1.f : a.slope, h.w > 0.f ? 1.f : a.slope);
                         dh[k] = make_float4(ds * av[k].x * g.x, ds * av[k].y * g.y, ds * av[k].z * g.z, ds * av[k].w * g.w);
@@ -419,7 +474,10 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
                         }
                     }
                 }
-            }
+            };
+            int u0 = 0;
+            for (; u0 + 2 <= nb; u0 += 2) group(std::integral_constant<int, 2>{}, u0);
+            if (u0 < nb) group(std::integral_constant<int, 1>{}, u0);
             if (MODE == 1 && lane < nb) a.wds[e0 + lane] = make_float2(my_w, my_ds);
         }
         // dP row (h-role chunks)
@@ -478,26 +536,26 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs a, 
             const int my_slot = a.order[x0 + le];
             const int my_dst = a.dst_of_slot[my_slot];
             const float2 my_wd = a.wds[my_slot];
-            for (int u0 = 0; u0 < nb; u0 += U) {
-                float4 gq[U][NCH];
-                unsigned bw[U];
-                float w[U], ds[U];
+            auto group = [&](auto uu_c, const int u0) {
+                constexpr int UU = decltype(uu_c)::value;
+                float4 gq[UU][NCH];
+                unsigned bw[UU];
+                float w[UU], ds[UU];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int idx = min(u0 + u, nb - 1);
-                    const bool ev = (u0 + u) < nb;
-                    const int slot = bcast_i(my_slot, idx);
-                    const int i = bcast_i(my_dst, idx);
-                    w[u] = ev ? bcast_f(my_wd.x, idx) * kappa : 0.f;
-                    ds[u] = ev ? bcast_f(my_wd.y, idx) : 0.f;
+                for (int u = 0; u < UU; ++u) {
+                    const int slot = bcast_i(my_slot, u0 + u);
+                    const int i = bcast_i(my_dst, u0 + u);
+                    w[u] = bcast_f(my_wd.x, u0 + u) * kappa;
+                    ds[u] = bcast_f(my_wd.y, u0 + u);
                     const float* grow = a.G + (int64_t)i * a.ldg;
 #pragma unroll
                     for (int k = 0; k < NCH; ++k)
                         if (L.any_v(k)) gq[u][k] = ld4(grow + goff[k]);
                     bw[u] = a.bits[(int64_t)slot * 64 + lane];
                 }
+                JMAC_LOADS_FIRST(UU * (NCH + 1));
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
+                for (int u = 0; u < UU; ++u) {
 #pragma unroll
                     for (int k = 0; k < NCH; ++k) {
                         float4 hpart = f4zero();
@@ -518,7 +576,14 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs a, 
                         }
                     }
                 }
+            };
+            int u0 = 0;
+            for (; u0 + 4 <= nb; u0 += 4) group(std::integral_constant<int, 4>{}, u0);
+            if (u0 + 2 <= nb) {
+                group(std::integral_constant<int, 2>{}, u0);
+                u0 += 2;
             }
+            if (u0 < nb) group(std::integral_constant<int, 1>{}, u0);
         }
         const bool direct = item.pslot < 0;
         // the fused self loop contributes g_j to dZ[j]; it is added once, by the finalising item or
