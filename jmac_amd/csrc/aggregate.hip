@@ -260,26 +260,29 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
     }
 }
 
-// merges the partial (max, denominator, accumulator) triples of destinations that were split
+// merges the partial (max, denominator, accumulator) triples of destinations that were split: one BLOCK per split
+// destination, wave w takes chunks w, w+4, ..., the four wave results are combined through LDS in wave order
 template <int NCH>
 __global__ __launch_bounds__(kBlock) void rel_attn_fwd_combine_kernel(FwdArgs a) {
+    __shared__ float4 red[kWavesPerBlock][NCH][64];
+    __shared__ float redl[kWavesPerBlock];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nwaves = gridDim.x * kWavesPerBlock;
     const int n_splits = a.counts[1];
     Lanes<NCH, 0> L;
     L.init(lane, a.D4);
     const int voff = 4 * a.D4;
-    for (int sp = blockIdx.x * kWavesPerBlock + wave; sp < n_splits; sp += nwaves) {
+    for (int sp = blockIdx.x; sp < n_splits; sp += gridDim.x) {
         const jmac_split_t s = a.splits[sp];
         const int i = s.seg;
         float M = -INFINITY;
-        for (int c = 0; c < s.nchunks; ++c) M = fmaxf(M, a.part_ml[2 * (s.pslot0 + c)]);
+        for (int c = lane; c < s.nchunks; c += 64) M = fmaxf(M, a.part_ml[2 * (s.pslot0 + c)]);
+        M = wave_max(M);
         float lsum = 0.f;
         float4 acc[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) acc[k] = f4zero();
-        for (int c = 0; c < s.nchunks; ++c) {
+        for (int c = wave; c < s.nchunks; c += kWavesPerBlock) {
             const int ps = s.pslot0 + c;
             const float f = fast_exp(a.part_ml[2 * ps] - M);
             lsum += a.part_ml[2 * ps + 1] * f;
@@ -289,24 +292,33 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_combine_kernel(FwdArgs a)
                 acc[k] = fma4(ld4(a.part_acc + (int64_t)ps * voff + o), f, acc[k]);
             }
         }
-        const int deg = a.rowptr[i + 1] - a.rowptr[i];
-        const float scale = lsum > 0.f ? sqrtf((float)deg) / lsum : 0.f;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            if (L.is_v(k)) {
-                float4 o = mul4(acc[k], scale);
-                if (a.loop_rel >= 0) {
-                    float4 z = ld4(a.QZ + (int64_t)i * a.ldqz + L.coff[k]);
-                    float4 rz = ld4(a.RR + (int64_t)a.loop_rel * a.ldrr + L.coff[k]);
-                    o = add4(o, sub4(z, rz));
+        for (int k = 0; k < NCH; ++k) red[wave][k][lane] = acc[k];
+        if (lane == 0) redl[wave] = lsum;
+        __syncthreads();
+        if (wave == 0) {
+            lsum = (redl[0] + redl[1]) + (redl[2] + redl[3]);
+            const int deg = a.rowptr[i + 1] - a.rowptr[i];
+            const float scale = lsum > 0.f ? sqrtf((float)deg) / lsum : 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                if (L.is_v(k)) {
+                    float4 o = add4(add4(red[0][k][lane], red[1][k][lane]), add4(red[2][k][lane], red[3][k][lane]));
+                    o = mul4(o, scale);
+                    if (a.loop_rel >= 0) {
+                        float4 z = ld4(a.QZ + (int64_t)i * a.ldqz + L.coff[k]);
+                        float4 rz = ld4(a.RR + (int64_t)a.loop_rel * a.ldrr + L.coff[k]);
+                        o = add4(o, sub4(z, rz));
+                    }
+                    st4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff), mul4(o, a.out_scale));
                 }
-                st4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff), mul4(o, a.out_scale));
+            }
+            if (lane == 0) {
+                a.seg_max[i] = M;
+                a.seg_den[i] = lsum;
             }
         }
-        if (lane == 0) {
-            a.seg_max[i] = M;
-            a.seg_den[i] = lsum;
-        }
+        __syncthreads();
     }
 }
 
@@ -607,27 +619,36 @@ __global__ __launch_bounds__(kBlock) void sum_parts_kernel(const jmac_split_t* _
                                                            float* __restrict__ outp, int64_t ldout,
                                                            const float* __restrict__ G, int64_t ldg, int D4, float kappa,
                                                            int add_self) {
+    // one BLOCK per split segment: wave w sums partial rows w, w+4, w+8, ... (two rows in flight per lane), the four
+    // wave sums are combined through LDS in wave order -> fixed summation order, and the hottest relation's thousands
+    // of partial rows are no longer one wave's serial chain
+    __shared__ float4 red[kWavesPerBlock][64];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nwaves = gridDim.x * kWavesPerBlock;
     const int n_splits = counts[1];
-    for (int sp = blockIdx.x * kWavesPerBlock + wave; sp < n_splits; sp += nwaves) {
+    for (int sp = blockIdx.x; sp < n_splits; sp += gridDim.x) {
         const jmac_split_t s = splits[sp];
-        for (int c4 = lane; c4 < W4; c4 += 64) {
-            // fixed summation order (4 interleaved partial sums), 4 rows in flight per lane
-            float4 a0 = f4zero(), a1 = f4zero(), a2 = f4zero(), a3 = f4zero();
-            const float* base = part + ((int64_t)s.pslot0 * W4 + c4) * 4;
-            int c = 0;
-            for (; c + 3 < s.nchunks; c += 4) {
-                a0 = add4(a0, ld4(base + (int64_t)(c + 0) * W4 * 4));
-                a1 = add4(a1, ld4(base + (int64_t)(c + 1) * W4 * 4));
-                a2 = add4(a2, ld4(base + (int64_t)(c + 2) * W4 * 4));
-                a3 = add4(a3, ld4(base + (int64_t)(c + 3) * W4 * 4));
+        for (int c0 = 0; c0 < W4; c0 += 64) {
+            const int c4 = c0 + lane;
+            float4 a0 = f4zero(), a1 = f4zero();
+            if (c4 < W4) {
+                const float* base = part + ((int64_t)s.pslot0 * W4 + c4) * 4;
+                int c = wave;
+                for (; c + kWavesPerBlock < s.nchunks; c += 2 * kWavesPerBlock) {
+                    a0 = add4(a0, ld4(base + (int64_t)c * W4 * 4));
+                    a1 = add4(a1, ld4(base + (int64_t)(c + kWavesPerBlock) * W4 * 4));
+                }
+                if (c < s.nchunks) a0 = add4(a0, ld4(base + (int64_t)c * W4 * 4));
             }
-            for (; c < s.nchunks; ++c) a0 = add4(a0, ld4(base + (int64_t)c * W4 * 4));
-            float4 acc = mul4(add4(add4(a0, a1), add4(a2, a3)), sign);
-            if (add_self && c4 >= D4) acc = fma4(ld4(G + (int64_t)s.seg * ldg + (c4 - D4) * 4), kappa, acc);
-            st4(outp + (int64_t)s.seg * ldout + c4 * 4, acc);
+            red[wave][lane] = add4(a0, a1);
+            __syncthreads();
+            if (wave == 0 && c4 < W4) {
+                float4 acc = add4(add4(red[0][lane], red[1][lane]), add4(red[2][lane], red[3][lane]));
+                acc = mul4(acc, sign);
+                if (add_self && c4 >= D4) acc = fma4(ld4(G + (int64_t)s.seg * ldg + (c4 - D4) * 4), kappa, acc);
+                st4(outp + (int64_t)s.seg * ldout + c4 * 4, acc);
+            }
+            __syncthreads();
         }
     }
 }
@@ -635,12 +656,36 @@ __global__ __launch_bounds__(kBlock) void sum_parts_kernel(const jmac_split_t* _
 // column sums of a [R, 4*W4] matrix in two deterministic steps: per-block partials, then one block.
 __global__ __launch_bounds__(kBlock) void colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int64_t R,
                                                                 int W4, float* __restrict__ partial) {
-    // thread t owns float4 column c4 = t % W4s ... simple strided layout: each thread loops rows
+    // rpb = kBlock / W4 rows are in flight per block (thread = (row lane, float4 column)), 2 loads in flight per thread;
+    // the row lanes are combined through LDS in a fixed order
+    __shared__ float4 red[kBlock];
     const int tid = threadIdx.x;
-    for (int c4 = tid; c4 < W4; c4 += kBlock) {
-        float4 acc = f4zero();
-        for (int64_t r = blockIdx.x; r < R; r += gridDim.x) acc = add4(acc, ld4(X + r * ldx + c4 * 4));
-        st4(partial + ((int64_t)blockIdx.x * W4 + c4) * 4, acc);
+    if (W4 > kBlock) {   // wide rows: one thread per float4 column, looped
+        for (int c4 = tid; c4 < W4; c4 += kBlock) {
+            float4 acc = f4zero();
+            for (int64_t r = blockIdx.x; r < R; r += gridDim.x) acc = add4(acc, ld4(X + r * ldx + c4 * 4));
+            st4(partial + ((int64_t)blockIdx.x * W4 + c4) * 4, acc);
+        }
+        return;
+    }
+    const int rpb = kBlock / W4;
+    const int rl = tid / W4, c4 = tid % W4;
+    float4 a0 = f4zero(), a1 = f4zero();
+    if (rl < rpb) {
+        const int64_t stride = (int64_t)gridDim.x * rpb;
+        int64_t r = (int64_t)blockIdx.x * rpb + rl;
+        for (; r + stride < R; r += 2 * stride) {
+            a0 = add4(a0, ld4(X + r * ldx + c4 * 4));
+            a1 = add4(a1, ld4(X + (r + stride) * ldx + c4 * 4));
+        }
+        if (r < R) a0 = add4(a0, ld4(X + r * ldx + c4 * 4));
+    }
+    red[tid] = add4(a0, a1);
+    __syncthreads();
+    if (tid < W4) {
+        float4 acc = red[tid];
+        for (int q = 1; q < rpb; ++q) acc = add4(acc, red[q * W4 + tid]);
+        st4(partial + ((int64_t)blockIdx.x * W4 + tid) * 4, acc);
     }
 }
 
@@ -702,6 +747,11 @@ inline unsigned persist_grid(int64_t n_items_max) {
     int64_t need = (n_items_max + kWavesPerBlock - 1) / kWavesPerBlock;
     if (need < 1) need = 1;
     return (unsigned)(need < cap ? need : cap);
+}
+
+inline unsigned split_grid(int64_t n_splits_max) {
+    if (n_splits_max < 1) n_splits_max = 1;
+    return (unsigned)(n_splits_max < 4 * kPersistBlocks ? n_splits_max : 4 * kPersistBlocks);
 }
 
 #define JMAC_DISPATCH_NCH(nch, ...)                       \
@@ -769,7 +819,7 @@ int jmac_rel_attn_aggregate_fwd_f32(const float* P, int64_t ldp, const float* QZ
         JMAC_DISPATCH_D(a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 4, D4T>), dim3(grid), dim3(kBlock), 0, st, a));
     }
     if (n_splits_max > 0) {
-        const unsigned g2 = persist_grid(n_splits_max);
+        const unsigned g2 = split_grid(n_splits_max);
         JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_fwd_combine_kernel<NCH>), dim3(g2), dim3(kBlock), 0, st, a));
     }
     return (int)hipGetLastError();
@@ -854,7 +904,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
     // a_att gradient: deterministic reduction of the per-block partial rows
     launch_reduce_rows(a.da_part, (int)gridA, (int)d, 1.f, da, st);
     if (by_dst->n_splits_max > 0)
-        hipLaunchKernelGGL(sum_parts_kernel, dim3(persist_grid(by_dst->n_splits_max)), dim3(kBlock), 0, st, by_dst->splits,
+        hipLaunchKernelGGL(sum_parts_kernel, dim3(split_grid(by_dst->n_splits_max)), dim3(kBlock), 0, st, by_dst->splits,
                            by_dst->counts, a.part, D4, 1.f, dP, lddp, nullptr, (int64_t)0, 0, 0.f, 0);
 
     // column sum of G for the fused self loop:  dRz[loop] -= kappa * sum_i G[i]
@@ -873,7 +923,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
         JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_gather_kernel<NCH, 4, D4T>), dim3(persist_grid(by_src->n_items_max)),
                                                   dim3(kBlock), 0, st, b, dQZ, lddqz));
         if (by_src->n_splits_max > 0)
-            hipLaunchKernelGGL(sum_parts_kernel, dim3(persist_grid(by_src->n_splits_max)), dim3(kBlock), 0, st, by_src->splits,
+            hipLaunchKernelGGL(sum_parts_kernel, dim3(split_grid(by_src->n_splits_max)), dim3(kBlock), 0, st, by_src->splits,
                                by_src->counts, b.part, 2 * D4, 1.f, dQZ, lddqz, G, ldg, D4, out_scale, b.add_self);
         BwdArgs c = a;
         c.items = by_rel->items; c.splits = by_rel->splits; c.counts = by_rel->counts; c.order = by_rel->order;
@@ -882,7 +932,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
         JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_gather_kernel<NCH, 4, D4T>), dim3(persist_grid(by_rel->n_items_max)),
                                                   dim3(kBlock), 0, st, c, dRR, lddrr));
         if (by_rel->n_splits_max > 0)
-            hipLaunchKernelGGL(sum_parts_kernel, dim3(persist_grid(by_rel->n_splits_max)), dim3(kBlock), 0, st, by_rel->splits,
+            hipLaunchKernelGGL(sum_parts_kernel, dim3(split_grid(by_rel->n_splits_max)), dim3(kBlock), 0, st, by_rel->splits,
                                by_rel->counts, c.part, 2 * D4, 1.f, dRR, lddrr, nullptr, (int64_t)0, 0, 0.f, 0);
     }
     if (loop_rel >= 0 && N > 0) {
