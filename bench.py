@@ -285,12 +285,17 @@ def main():
     dist_on = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if os.environ.get("JMAC_BENCH_SHARE_GPU"):        # debugging aid: several ranks on one device
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        except TypeError:                                  # older signature without device_id
+            dist.init_process_group("nccl", rank=rank, world_size=world)
 
     if a.workload == "synth-1m" or dist_on:
         from bench_dist import run_sharded          # destination-sharded synthetic graph, RCCL all-gather

@@ -87,8 +87,17 @@ class ShardedGraph:
 # ------------------------------------------------------------------------------------------------
 # differentiable collectives
 # ------------------------------------------------------------------------------------------------
+# tests set this to run the collectives even when the group has one rank (exercises the RCCL entry points on a
+# single-GPU box); the product leaves it False and short-circuits world == 1
+FORCE_COLLECTIVES = False
+
+
 def _world(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def _skip(group=None) -> bool:
+    return _world(group) == 1 and not (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
 
 
 def _all_reduce(t: torch.Tensor, group=None) -> None:
@@ -108,7 +117,7 @@ class _AllGatherRows(torch.autograd.Function):
     def forward(ctx, x, group):
         ctx.group = group
         world = _world(group)
-        if world == 1:
+        if _skip(group):
             return x
         x = x.contiguous()
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
@@ -123,7 +132,7 @@ class _AllGatherRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         world = _world(ctx.group)
-        if world == 1:
+        if _skip(ctx.group):
             return g, None
         g = g.contiguous()
         n = g.shape[0] // world
@@ -140,7 +149,7 @@ class _AllReduceSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, group):
         ctx.group = group
-        if _world(group) == 1:
+        if _skip(group):
             return x
         y = x.clone()
         _all_reduce(y, group)
@@ -148,7 +157,7 @@ class _AllReduceSum(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        if _world(ctx.group) == 1:
+        if _skip(ctx.group):
             return g, None
         g = g.clone()
         _all_reduce(g, ctx.group)
@@ -165,7 +174,7 @@ def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
 
 def allreduce_grads(params, group=None) -> None:
     """Sum the (replicated) parameters' gradients over ranks, one flat bucket."""
-    if _world(group) == 1:
+    if _skip(group):
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:

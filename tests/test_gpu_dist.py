@@ -85,3 +85,49 @@ def test_sharded_hip_layer_two_ranks():
         for k, g in o["grads"].items():
             atol = 1e-4 * gscale + 1e-6 if k == "loop_rel" else 1e-6
             assert_close(g, p[k].grad, 1e-4, atol, "grad " + k)
+
+
+def _rccl_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        import jmac_amd.dist as jd
+        from jmac_amd.layer import RelationAwareLayer
+        jd.FORCE_COLLECTIVES = True                                      # real RCCL calls although world == 1
+        dev = torch.device("cuda", 0)
+        ei, et, X, R, G, n, nr, d = _case()
+        sg = jd.ShardedGraph(ei, et, jd.partition_rows(np.bincount(ei[0], minlength=n), 1), 0)
+        torch.manual_seed(11)
+        base = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args()).to(dev)
+        lay = jd.ShardedRelationAwareLayer(base).train()
+        x = X.to(dev).requires_grad_(True)
+        r = R.to(dev).requires_grad_(True)
+        out = lay(x, r, sg)
+        (out * G.to(dev)).sum().backward()
+        jd.allreduce_grads(list(base.parameters()) + [r])
+        torch.cuda.synchronize()
+        ret[0] = dict(out=out.detach().cpu(), gx=x.grad.cpu(), gw=base.w_att.grad.cpu())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_entry_points_world1():
+    """all_gather_into_tensor / reduce_scatter_tensor / all_reduce through RCCL on device tensors."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    ei, et, X, R, G, n, nr, d = _case()
+    from jmac_amd.layer import RelationAwareLayer
+    torch.manual_seed(11)
+    base = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())
+    f64 = torch.float64
+    p = {k: v.detach().clone().to(f64).requires_grad_(True) for k, v in base.named_parameters()}
+    Xc, Rc = X.to(f64).requires_grad_(True), R.to(f64).requires_grad_(True)
+    ref = orc.layer_forward(p, Xc, Rc, torch.from_numpy(ei), torch.from_numpy(et), 0.05, "sub", "leaky_relu", True,
+                            torch.zeros(d, dtype=f64), torch.ones(d, dtype=f64))
+    (ref * G.to(f64)).sum().backward()
+    assert_close(ret[0]["out"], ref, 1e-4, 1e-6, "out")
+    assert_close(ret[0]["gx"], Xc.grad, 1e-4, 1e-6, "grad_X")
+    assert_close(ret[0]["gw"], p["w_att"].grad, 1e-4, 1e-6, "grad w_att")
