@@ -198,6 +198,11 @@ int jmac_masked_row_softmax_f32(const float* S, int64_t lds, int64_t n1, int64_t
                                 const uint8_t* row_mask, const uint8_t* col_mask, float fill,
                                 float scale, float* out, int64_t ldo, jmac_stream_t stream);
 
+/* CSLS rescoring (replaces csls_sim, modules/finding/similarity.py:58-78):
+ * out[i,j] = 2*S[i,j] - r1[i] - r2[j], r1/r2 = mean of the k largest entries of row i / column j. */
+int jmac_csls_apply_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, const float* r1,
+                        const float* r2, float* out, int64_t ldo, jmac_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * torch_scatter-compatible primitives (replace the third-party calls at src/jmac_model.py:105 and
  * modules/helper/message_passing.py:24,28) so the UNMODIFIED reference layer can run on this library.

@@ -366,6 +366,17 @@ __global__ __launch_bounds__(kBlock) void masked_row_softmax_kernel(const float*
     for (int n = threadIdx.x; n < N; n += kBlock) orow[n] = expf(val(n) - m) * iz;
 }
 
+// out[i][j] = 2*S[i][j] - r1[i] - r2[j]   (CSLS, modules/finding/similarity.py:58-78)
+__global__ __launch_bounds__(kBlock) void csls_apply_kernel(const float* __restrict__ S, int64_t lds, int64_t n1, int64_t n2,
+                                                            const float* __restrict__ r1, const float* __restrict__ r2,
+                                                            float* __restrict__ out, int64_t ldo) {
+    const int64_t total = n1 * n2;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / n2, c = i % n2;
+        out[r * ldo + c] = 2.f * S[r * lds + c] - r1[r] - r2[c];
+    }
+}
+
 int launch_sim(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t d, float* C, int64_t ldc,
                hipStream_t st) {
     if (M == 0 || N == 0) return 0;
@@ -465,6 +476,18 @@ int jmac_softmax_entropy_f32(const float* A, int64_t lda, const float* B, int64_
     if (int rc = launch_sim(B, ldb, A, lda, n2, n1, d, St, n1, st)) return rc;
     hipLaunchKernelGGL(row_entropy_kernel, dim3((unsigned)n1), dim3(kBlock), 0, st, S, n2, (int)n2, scale, ent_rows);
     hipLaunchKernelGGL(row_entropy_kernel, dim3((unsigned)n2), dim3(kBlock), 0, st, St, n1, (int)n1, scale, ent_cols);
+    return (int)hipGetLastError();
+}
+
+int jmac_csls_apply_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, const float* r1, const float* r2, float* out,
+                        int64_t ldo, jmac_stream_t stream) {
+    if (n1 < 0 || n2 < 0) return JMAC_EINVAL;
+    if (n1 == 0 || n2 == 0) return JMAC_OK;
+    if (!S || !r1 || !r2 || !out) return JMAC_EINVAL;
+    int64_t blocks = (n1 * n2 + kBlock - 1) / kBlock;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(csls_apply_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, S, lds, n1, n2, r1, r2, out,
+                       ldo);
     return (int)hipGetLastError();
 }
 

@@ -166,3 +166,41 @@ def alignment_quality(emb1: torch.Tensor, emb2: torch.Tensor, list1, list2, scal
     simi = sim_matrix(emb1, emb2)
     simi_t = sim_matrix(emb2, emb1)
     return entropy, masked_row_softmax(simi, m1, m2, -1.0, scale), masked_row_softmax(simi_t, m2, m1, -1.0, scale)
+
+
+# ---- alignment evaluation (next row f1: modules/finding/similarity.py:13-84, alignment.py:10-112) -------------
+def csls_sim(sim: torch.Tensor, k: int) -> torch.Tensor:
+    """csls_sim, similarity.py:58-78, with calculate_nearest_k defined as the exact mean of the k largest entries
+    (the reference's np.partition(-sim, k+1)[:, :k] returns *some* k of the top k+1)."""
+    require_device(sim)
+    sim = sim.contiguous()
+    n1, n2 = sim.shape
+    r1 = row_topk(sim, k)[0].mean(1)
+    r2 = row_topk(sim.t().contiguous(), k)[0].mean(1)
+    out = torch.empty_like(sim)
+    check(lib().jmac_csls_apply_f32(ptr(sim), n2, n1, n2, ptr(r1), ptr(r2), ptr(out), n2, stream()), "jmac_csls_apply_f32")
+    return out
+
+
+def alignment_sim(embed1: torch.Tensor, embed2: torch.Tensor, metric: str = "cosine", normalize: bool = False,
+                  csls_k: int = 0) -> torch.Tensor:
+    """sim(), similarity.py:13-55, for the metrics train.py uses ('cosine', 'inner')."""
+    if normalize or metric == "cosine":
+        embed1 = torch.nn.functional.normalize(embed1, 2, -1)
+        embed2 = torch.nn.functional.normalize(embed2, 2, -1)
+    elif metric != "inner":
+        raise NotImplementedError("metric %r (train.py:105-113 uses 'cosine')" % metric)
+    s = sim_matrix(embed1, embed2)
+    return csls_sim(s, csls_k) if csls_k > 0 else s
+
+
+def alignment_test(embeds1: torch.Tensor, embeds2: torch.Tensor, top_k=(1, 5, 10), metric: str = "cosine",
+                   normalize: bool = False, csls_k: int = 10):
+    """test() / greedy_alignment() / calculate_rank(accurate=True), evaluation.py:20-28, alignment.py:10-112:
+    row i of embeds1 is aligned with row i of embeds2.  Returns (top_k, hits [%], mr, mrr)."""
+    s = alignment_sim(embeds1, embeds2, metric, normalize, csls_k)
+    n = s.shape[0]
+    gold = torch.arange(n, device=s.device, dtype=torch.int32)
+    rank = filtered_rank(-s, gold).to(torch.float64)                  # 1-based; ascending "distance" = descending sim
+    hits = [float((rank <= k).double().mean().item() * 100.0) for k in top_k]
+    return list(top_k), [round(h, 3) for h in hits], float(rank.mean().item()), float((1.0 / rank).mean().item())

@@ -419,3 +419,31 @@ def factorised_pre_bn(p: Dict[str, Tensor], ent_emb: Tensor, rel_emb: Tensor, ed
     deg = scatter_sum(torch.ones(dst.shape[0]), dst, n)
     nb = scatter_sum(alpha * (Z[src] - Rz[edge_type]), dst, n) * deg.sqrt().view(-1, 1)
     return (nb + Z - Rz[-1]) / 2
+
+
+# --------------------------------------------------------------------------------------------
+# Alignment evaluation (next row f1): modules/finding/similarity.py:13-84, alignment.py:10-112
+# --------------------------------------------------------------------------------------------
+def csls_sim(sim: Tensor, k: int) -> Tensor:
+    """csls_sim, similarity.py:58-78.  calculate_nearest_k (:81-84) takes np.partition(-sim, k+1)[:, :k], i.e.
+    *some* k of the k+1 largest entries; this restatement uses the exact k largest (stated policy)."""
+    r1 = sim.topk(k, dim=1).values.mean(1)
+    r2 = sim.t().topk(k, dim=1).values.mean(1)
+    return 2 * sim - r1.view(-1, 1) - r2.view(1, -1)
+
+
+def alignment_test(e1: Tensor, e2: Tensor, top_k=(1, 5, 10), csls_k: int = 10):
+    """test -> greedy_alignment -> calculate_rank(accurate=True) with metric='cosine', normalize=False
+    (train.py:105-113): gold of row i is column i; rank = position in the descending similarity order
+    (ties: lower index first)."""
+    s = F.normalize(e1.double(), 2, -1) @ F.normalize(e2.double(), 2, -1).t()   # scipy cdist path is float64
+    s = s.float()
+    if csls_k > 0:
+        s = csls_sim(s, csls_k)
+    n = s.shape[0]
+    g = s.diag().view(-1, 1)
+    ar = torch.arange(n).view(1, -1)
+    rank = ((s > g) | ((s == g) & (ar < torch.arange(n).view(-1, 1)))).sum(1) + 1
+    rank = rank.double()
+    hits = [round(float((rank <= k).double().mean() * 100), 3) for k in top_k]
+    return list(top_k), hits, float(rank.mean()), float((1.0 / rank).mean()), s

@@ -309,6 +309,27 @@ def gen_root():
     _save("model_small", **arrays)
 
 
+def gen_aligneval():
+    """modules.finding.evaluation.test on the model_small embeddings (train.py:105-113 settings)."""
+    from modules.finding.evaluation import test
+    from modules.finding.similarity import sim
+    g = dict(np.load(os.path.join(HERE, "model_small.npz")))
+    rng = np.random.default_rng(33)
+    n = 100
+    e1 = g["emb1_align"][:n].astype(np.float32)
+    # a noisy copy of e1 plus the other KG's embedding: a non-trivial but learnable alignment
+    e2 = (0.6 * e1 + 0.4 * g["emb2_align"][:n] + 0.05 * rng.standard_normal(e1.shape)).astype(np.float32)
+    lg = logging.getLogger("golden"); lg.setLevel(logging.ERROR)
+    out = {"e1": e1, "e2": e2}
+    for k in (0, 10):
+        top_k, hits, mr, mrr = test(e1, e2, None, [1, 5, 10], 1, metric="cosine", normalize=False, csls_k=k, accurate=True, logger=lg)
+        out["hits_csls%d" % k] = np.asarray(hits, dtype=np.float64)
+        out["mr_csls%d" % k] = np.float64(mr)
+        out["mrr_csls%d" % k] = np.float64(mrr)
+        out["sim_csls%d" % k] = sim(e1, e2, metric="cosine", normalize=False, csls_k=k).astype(np.float32)
+    _save("align_eval", **out)
+
+
 def gen_dbpv1():
     from models.jmac_model import RelationalAwareLayer
     args = types.SimpleNamespace(leaky_relu_w=0.05, opn="sub")
@@ -321,12 +342,12 @@ def gen_dbpv1():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variant", default="all", choices=["all", "root", "dbpv1"])
+    ap.add_argument("--variant", default="all", choices=["all", "root", "dbpv1", "aligneval"])
     a = ap.parse_args()
     if a.variant == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for v in ("root", "dbpv1"):
+        for v in ("root", "dbpv1", "aligneval"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--variant", v], env=env)
     else:
         _paths(a.variant)
-        {"root": gen_root, "dbpv1": gen_dbpv1}[a.variant]()
+        {"root": gen_root, "dbpv1": gen_dbpv1, "aligneval": gen_aligneval}[a.variant]()

@@ -137,3 +137,22 @@ def test_scatter_trio_matches_oracle():
     assert_close(sg.grad, so.grad, 1e-4, 1e-7)
     deg = js.scatter_add(torch.ones(E).cuda(), idx.cuda(), dim=0, dim_size=N)
     assert torch.equal(deg.cpu(), torch.bincount(idx, minlength=N).float())
+
+
+def test_alignment_eval_matches_reference_golden():
+    from jmac_amd import scoring
+    g = load_golden("align_eval")
+    e1, e2 = t(g["e1"], "cuda"), t(g["e2"], "cuda")
+    for k in (0, 10):
+        top_k, hits, mr, mrr = scoring.alignment_test(e1, e2, (1, 5, 10), "cosine", False, k)
+        assert np.allclose(hits, g["hits_csls%d" % k], atol=1e-9)
+        assert abs(mr - float(g["mr_csls%d" % k])) < 1e-9 and abs(mrr - float(g["mrr_csls%d" % k])) < 1e-9
+        s = scoring.alignment_sim(e1, e2, "cosine", False, k)
+        _, _, _, _, so = orc.alignment_test(e1.cpu(), e2.cpu(), (1, 5, 10), k)
+        assert_close(s, so, 1e-5, 1e-6)
+    gen = torch.Generator().manual_seed(12)
+    a = torch.randn(2600, 300, generator=gen)
+    b = a + 0.8 * torch.randn(2600, 300, generator=gen)
+    got = scoring.alignment_test(a.cuda(), b.cuda(), (1, 5, 10), "cosine", False, 10)
+    want = orc.alignment_test(a, b, (1, 5, 10), 10)
+    assert got[1] == want[1] and abs(got[2] - want[2]) < 1e-9 and abs(got[3] - want[3]) < 1e-12
