@@ -282,14 +282,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or bool(os.environ.get("JMAC_BENCH_FORCE_DIST"))   # env: exercise the N>1 path on one GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     if os.environ.get("JMAC_BENCH_SHARE_GPU"):        # debugging aid: several ranks on one device
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if dist_on:
+    def init_dist():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         try:
@@ -297,7 +297,9 @@ def main():
         except TypeError:                                  # older signature without device_id
             dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    if a.workload == "synth-1m" or dist_on:
+    if a.workload == "synth-1m":
+        if dist_on:
+            init_dist()
         from bench_dist import run_sharded          # destination-sharded synthetic graph, RCCL all-gather
         line = run_sharded(a, rank, world, device)
         if rank == 0:
@@ -307,7 +309,11 @@ def main():
             dist.destroy_process_group()
         return
 
-    w = JaWorkload(a, device)
+    # Default workload at any N: one DBP-5L-ja-shaped KG per GPU.  Graphs of this size do not shard
+    # profitably ("replicas only"), so ranks run independent replicas with no data-path collective
+    # (weak scaling: the units all ranks processed / the slowest rank's time).  The destination-sharded RCCL
+    # path is measured on config 4 and reported beside it ("sharded").
+    w = JaWorkload(a, device, seed=1234 + rank)
     exec_mode = "eager"
     fn = w.step
     if not a.no_graph:
@@ -318,10 +324,45 @@ def main():
         except Exception as ex:                      # pragma: no cover
             sys.stderr.write("hipGraph capture failed (%s); running eager\n" % (ex,))
             torch.cuda.synchronize()
-    el = time_steps(fn, a.steps, a.warmup, False)
+    if dist_on:
+        init_dist()          # after the capture: no RCCL watchdog activity while the stream is capturing
+    el = time_steps(fn, a.steps, a.warmup, dist_on)
     ms = el / a.steps * 1e3
     layer_calls = 3
-    value = layer_calls * w.E * a.steps / el
+    value = world * layer_calls * w.E * a.steps / el
+    if dist_on:
+        import torch.distributed as dist
+        sharded = None
+        if not a.no_synth:
+            from bench_dist import run_sharded
+            sa = argparse.Namespace(**vars(a))
+            sa.steps, sa.warmup = max(3, min(a.steps, 10)), 2
+            try:
+                sl = run_sharded(sa, rank, world, device)
+                sharded = {k: sl[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "roofline_bwd")}
+            except Exception as ex:                  # pragma: no cover
+                sharded = {"error": str(ex)}
+        if rank == 0:
+            line = {"metric": "gnn_layer_edges_per_s", "value": value, "unit": "edges/s", "n_gpus": world, "steps": a.steps,
+                    "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": "one DBP-5L ja-shaped KG per GPU (replicas, no collective): N=%d E=%d nr=%d d=%d; "
+                                           "forward_base fwd+bwd + Adam, batch %dx(1+%d)" % (w.N, w.E, w.nr, w.d, a.batch, a.negatives),
+                               "exec": exec_mode, "parallelism": "replicas x%d" % world,
+                               "edges_counted_per_step": world * layer_calls * w.E},
+                    "roofline": None, "cpu_baseline": None, "sharded": sharded}
+            prof = kernel_profile(w, 5)
+            from jmac_amd import synth as _synth
+            fb = _synth.fwd_algorithmic_bytes(w.N, w.E, w.d)
+            fms = prof["rel_attn_fwd"][0]
+            line["roofline"] = {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<3,4,75> (rank 0)", "achieved": fb / (fms * 1e-3) / 1e9,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "traffic": pmc_traffic("ja", "rel_attn_fwd_kernel") if w.d == 300 else None,
+                                "algorithmic_bytes_per_launch": fb, "avg_launch_ms": fms}
+            print(json.dumps(line))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
     from jmac_amd import synth
     prof = kernel_profile(w, max(5, min(a.steps, 20)))
