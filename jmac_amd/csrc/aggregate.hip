@@ -44,7 +44,7 @@ struct FwdArgs {
     const jmac_item_t* items;
     const jmac_split_t* splits;
     const int32_t* counts;
-    int32_t N, D4, loop_rel;
+    int32_t N, D4, loop_rel, n_items_max;
     float slope, out_scale;
     float *out, *seg_max, *seg_den;
     float *part_acc, *part_ml;
@@ -116,9 +116,14 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
     // Items are software-pipelined: while item k computes, the header of item k+2 and the first col/type
     // batch of item k+1 are already in flight, so a wave's critical path per item is one gather round trip
     // instead of header -> col/type -> gather (measured: 65k rows of degree 1 took 114 us serialised).
+    // The first header is fetched at a clamped index so that it does not wait for the device-side item count.
     int it = blockIdx.x * kWavesPerBlock + wave;
+    jmac_item_t item = a.items[min(it, a.n_items_max - 1)];
+    // the loop relation's Rz row is the same for every destination: one read per wave
+    float4 rl[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) rl[k] = (L.any_v(k) && has_loop) ? ld4(rloop + L.coffc[k]) : f4zero();
     if (it >= n_items) return;
-    jmac_item_t item = a.items[it];
     jmac_item_t nitem = a.items[min(it + nwaves, n_items - 1)];
     int ccol, ctyp;
     {
@@ -137,12 +142,15 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
             ntyp = a.etype[idx];
         }
         const int i = item.seg;
-        float4 pv[NCH], acc[NCH];
-        const float* prow = a.P + (int64_t)i * a.ldp;
+        float4 pv[NCH], acc[NCH], zs[NCH];
+        // a destination without in-edges needs no P row: re-read row 0 (cache hit) instead of its own
+        const float* prow = a.P + (int64_t)(item.end > item.beg ? i : 0) * a.ldp;
         const float* zrow = a.QZ + (int64_t)i * a.ldqz;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             pv[k] = L.any_h(k) ? ld4(prow + (L.is_h[k] ? L.coff[k] : 0)) : f4zero();
+            // self-loop term Z[i] (v-role lanes), fetched with the header-dependent loads rather than after the edges
+            zs[k] = (L.any_v(k) && has_loop) ? ld4(zrow + L.coffc[k]) : f4zero();
             acc[k] = f4zero();
         }
 #pragma unroll
@@ -227,14 +235,10 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
         if (item.pslot < 0) {
             const int deg = item.end - item.beg;
             const float scale = l > 0.f ? sqrtf((float)deg) / l : 0.f;
-            float4 zs[NCH];
-#pragma unroll
-            for (int k = 0; k < NCH; ++k)   // self-loop term Z[i] - Rz[loop] (v-role lanes)
-                zs[k] = (L.any_v(k) && has_loop) ? sub4(ld4(zrow + L.coffc[k]), ld4(rloop + L.coffc[k])) : f4zero();
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 if (L.any_v(k) && L.is_v(k)) {
-                    const float4 o = add4(mul4(acc[k], scale), zs[k]);
+                    const float4 o = add4(mul4(acc[k], scale), sub4(zs[k], rl[k]));   // + Z[i] - Rz[loop]
                     st4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff), mul4(o, a.out_scale));
                 }
             }
@@ -749,6 +753,16 @@ inline unsigned persist_grid(int64_t n_items_max) {
     return (unsigned)(need < cap ? need : cap);
 }
 
+// forward: graphs of up to 16k items get one wave per item (measured on the DBP-5L ja shape: 21 us against 24 us
+// with the persistent 2048-block grid -- at that size the kernel is a chain of dependent round trips, not a stream)
+inline unsigned fwd_grid(int64_t n_items_max) {
+    static const int cap = env_int("JMAC_GRID", 0);
+    if (cap > 0) return persist_grid(n_items_max);
+    const int64_t need = (n_items_max + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (need <= 2 * kPersistBlocks) return (unsigned)(need < 1 ? 1 : need);
+    return kPersistBlocks;
+}
+
 inline unsigned split_grid(int64_t n_splits_max) {
     if (n_splits_max < 1) n_splits_max = 1;
     return (unsigned)(n_splits_max < 4 * kPersistBlocks ? n_splits_max : 4 * kPersistBlocks);
@@ -801,6 +815,7 @@ int jmac_rel_attn_aggregate_fwd_f32(const float* P, int64_t ldp, const float* QZ
     a.rowptr = rowptr; a.col = col; a.etype = etype;
     a.items = items; a.splits = splits; a.counts = counts;
     a.N = (int32_t)N; a.D4 = (int32_t)(d / 4); a.loop_rel = loop_rel;
+    a.n_items_max = (int32_t)(n_items_max > 0 ? n_items_max : 1);
     a.slope = slope; a.out_scale = out_scale;
     a.out = out; a.seg_max = seg_max; a.seg_den = seg_den;
     // ws layout: [part_ml: 2 floats per slot][part_acc: d floats per slot]
@@ -810,8 +825,11 @@ int jmac_rel_attn_aggregate_fwd_f32(const float* P, int64_t ldp, const float* QZ
     a.part_acc = ws ? (float*)((char*)ws + align_up((size_t)n_parts_max * 8)) : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const int nch = (int)((2 * (d / 4) + 63) / 64);
-    const unsigned grid = persist_grid(n_items_max);
-    static const int fwd_u = env_int("JMAC_FWD_U", 4);             // tuning knob (debug)
+    const unsigned grid = fwd_grid(n_items_max);
+    // small graphs (one wave per item) are bound by round trips, not by gathers in flight: the 2-edge group
+    // has fewer VGPRs, i.e. one more wave per SIMD (DBP-5L ja: 20.4 us against 22.6 us)
+    static const int fwd_u_env = env_int("JMAC_FWD_U", 0);         // tuning knob (debug)
+    const int fwd_u = fwd_u_env ? fwd_u_env : (n_items_max <= 8 * kPersistBlocks ? 2 : 4);
     const bool slope01 = slope >= 0.f && slope <= 1.f;
     if (fwd_u == 2) {
         JMAC_DISPATCH_D(a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 2, D4T>), dim3(grid), dim3(kBlock), 0, st, a));
