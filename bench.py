@@ -87,17 +87,26 @@ class JaWorkload:
         self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True, capturable=True)
         self.model.train()
 
-    def loss_fn(self, align_out, comp, rel, h, r, t, pairs, margin):
+    # the product's fused loss gathers; the CPU baseline swaps in the reference's torch formulation
+    def l1(self, ent, rl, h, r, t):
+        from jmac_amd import losses
+        return losses.triple_l1_score(ent, rl, h, r, t, period=self.a.batch)   # as JMAC.completion_loss passes it
+
+    @staticmethod
+    def cos(e1, i1, e2, i2):
+        from jmac_amd import losses
+        return losses.pair_cosine_distance(e1, i1, e2, i2)
+
+    def loss_fn(self, align_out, comp, rel, h, r, t, pairs, margin, l1=None, cos=None):
+        l1, cos = l1 or self.l1, cos or self.cos
         B = self.a.batch
         loss = 0
         for ent, rl in zip(comp, rel):                                   # src/jmac_model.py:331-378
-            score = torch.norm(ent.index_select(0, h) + rl.index_select(0, r) - ent.index_select(0, t), 1, -1)
+            score = l1(ent, rl, h, r, t)
             pos = score[:B].view(-1, B).permute(1, 0)
             neg = score[B:].view(-1, B).permute(1, 0)
             loss = loss + torch.max(pos - neg, -margin).mean() + margin
-        a = torch.nn.functional.normalize(align_out.index_select(0, pairs[:, 0]), 2, -1)   # :271-273
-        b = torch.nn.functional.normalize(align_out.index_select(0, pairs[:, 1]), 2, -1)
-        return loss + (1 - (a * b).sum(1)).mean()
+        return loss + cos(align_out, pairs[:, 0], align_out, pairs[:, 1]).mean()          # :271-273
 
     def step(self):
         m = self.model
@@ -124,7 +133,7 @@ class JaWorkload:
                 v.grad = None
             align_out, comp, rel = orc.forward_name(st, self.name_emb, ei, et, [0, self.N], [0, self.nr], 2, 0.05, "sub",
                                                     True, bn)
-            loss = self.loss_fn(align_out, comp, rel, h, r, t, pairs, margin)
+            loss = self.loss_fn(align_out, comp, rel, h, r, t, pairs, margin, orc.triple_l1_score, orc.pair_cosine_distance)
             loss.backward()
             return loss
         return step

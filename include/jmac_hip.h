@@ -204,6 +204,42 @@ int jmac_csls_apply_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, con
                         const float* r2, float* out, int64_t ldo, jmac_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Loss gathers.  Indices are the reference's int64 tensors (batch_h /
+ * batch_r / batch_t, links, neg_left ...), values in range; rows may have any d (16-byte aligned rows
+ * with d % 4 == 0 take the vector path).
+ * --------------------------------------------------------------------------------------------- */
+
+/* score[x] = || ent[h[x]] + rel[r[x]] - ent[t[x]] ||_1   (replaces the three gathers, the sum and
+ * torch.norm(score, 1, -1) of completion_loss, src/jmac_model.py:345-350).  d <= 512.
+ * period: a HINT that triples x, x+period, x+2*period ... share (h, r) -- the reference's batch is
+ * sub.repeat(K+1), rel.repeat(K+1), cat(obj, negatives) with period = batch size (train.py:347-352) --
+ * so that one wavefront reads E[h]+R[r] once per run.  Any input is correct (a triple of the run with
+ * another (h, r) is handled on its own); period <= 0 or >= T: no grouping. */
+int jmac_triple_l1_fwd_f32(const float* ent, int64_t lde, const float* rel, int64_t ldr,
+                           const int64_t* h, const int64_t* r, const int64_t* t, int64_t T,
+                           int64_t period, int64_t d, float* score, jmac_stream_t stream);
+/* Adjoint: dent[h[x]] += g s, drel[r[x]] += g s, dent[t[x]] -= g s with s = sign(ent[h]+rel[r]-ent[t])
+ * (sign(0) = 0, as torch's norm backward).  dent [N,d] / drel [nrel,d] must be ZEROED by the caller (or
+ * hold a gradient to accumulate into); float atomics; with `period` the run's dent[h] / drel[r] terms are
+ * summed in registers and added once. */
+int jmac_triple_l1_bwd_f32(const float* ent, int64_t lde, const float* rel, int64_t ldr,
+                           const int64_t* h, const int64_t* r, const int64_t* t, int64_t T,
+                           int64_t period, int64_t d, const float* gscore, float* dent, int64_t ldde, float* drel, int64_t lddr,
+                           jmac_stream_t stream);
+
+/* dist[x] = 1 - <u, v>, u = e1[i1[x]] / max(||.||, 1e-12), v = e2[i2[x]] / max(||.||, 1e-12)
+ * (replaces F.normalize(E[idx]) x2 + sum of alignment_loss / alignment_loss_simple,
+ * src/jmac_model.py:245-247, 271-291). */
+int jmac_pair_cosine_fwd_f32(const float* e1, int64_t ld1, const float* e2, int64_t ld2,
+                             const int64_t* i1, const int64_t* i2, int64_t L, int64_t d, float* dist,
+                             jmac_stream_t stream);
+/* Adjoint into de1 [N1,d] / de2 [N2,d] (zeroed by the caller); float atomics. */
+int jmac_pair_cosine_bwd_f32(const float* e1, int64_t ld1, const float* e2, int64_t ld2,
+                             const int64_t* i1, const int64_t* i2, int64_t L, int64_t d,
+                             const float* gdist, float* de1, int64_t ldd1, float* de2, int64_t ldd2,
+                             jmac_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * torch_scatter-compatible primitives (replace the third-party calls at src/jmac_model.py:105 and
  * modules/helper/message_passing.py:24,28) so the UNMODIFIED reference layer can run on this library.
  * index need not be sorted.  out must be pre-zeroed by the caller for scatter_sum.

@@ -64,6 +64,10 @@ _SIGS = {
     "jmac_softmax_entropy_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, f32, vp, vp, vp, sz, vp]),
     "jmac_masked_row_softmax_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, f32, f32, vp, i64, vp]),
     "jmac_csls_apply_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, i64, vp]),
+    "jmac_triple_l1_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp]),
+    "jmac_triple_l1_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp, i64, vp, i64, vp]),
+    "jmac_pair_cosine_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp]),
+    "jmac_pair_cosine_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp]),
     "jmac_scatter_sum_f32": (C.c_int, [vp, vp, i64, i64, i64, vp, vp]),
     "jmac_scatter_softmax_workspace_bytes": (sz, [i64, i64]),
     "jmac_scatter_softmax_f32": (C.c_int, [vp, vp, i64, i64, i64, vp, vp, sz, vp]),

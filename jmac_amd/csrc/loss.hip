@@ -1,0 +1,302 @@
+// loss.hip -- fused gathers of the completion / alignment losses for gfx950.
+//
+//  * jmac_triple_l1_{fwd,bwd}_f32    score_t = || E[h_t] + R[r_t] - E[t_t] ||_1      src/jmac_model.py:345-350
+//  * jmac_pair_cosine_{fwd,bwd}_f32  dist_p  = 1 - cos(E1[i_p], E2[j_p])             src/jmac_model.py:245-247,271-291
+//
+// The reference materialises three (two) gathered [T,d] copies, the sum, the norm and -- in the backward --
+// three (two) index_add passes per call.  Here one wavefront owns a triple (pair): the rows are read once with
+// 16 B per lane, reduced across the wave, and the backward re-reads them, rebuilds the sign (the normalised
+// rows) in registers and adds straight into the gradient tables with hardware float atomics
+// (global_atomic_add_f32; same accumulation-order freedom as torch's index_add_ that it replaces).
+// Indices are the reference's int64 tensors, used as they are.  HBM/L2-bound: 3 (2) row reads per unit.
+#include "common.h"
+
+using namespace jmac;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+
+__device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+// ---- triple L1 ---------------------------------------------------------------------------------------
+// Lane layout: element c = lane + 64k (a wave instruction covers 256 contiguous bytes: the shape float atomics
+// run at full rate with; 16 B per lane would spread one instruction over sixteen 64-B atomic requests).
+//
+// `period` is a HINT about the batch layout of the reference (train.py:347-352: sub.repeat(K+1), rel.repeat(K+1),
+// cat(obj, negatives)): triples x, x+period, x+2*period ... are expected to share (h, r).  One wave takes such a
+// run: the E[h] + R[r] row is read once, and in the backward the run's contributions to dE[h] / dR[r] are summed
+// in registers and added once (28 atomic rows per positive instead of 78, and K+1 times fewer adds into the few
+// hot relation rows).  A triple of the run whose (h, r) differs is handled on its own: any input is correct.
+template <int NK>
+__global__ __launch_bounds__(kBlock) void triple_l1_fwd_kernel(const float* __restrict__ ent, int64_t lde,
+                                                               const float* __restrict__ rel, int64_t ldr,
+                                                               const int64_t* __restrict__ h, const int64_t* __restrict__ r,
+                                                               const int64_t* __restrict__ t, int64_t T, int64_t period, int d,
+                                                               float* __restrict__ score) {
+    const int lane = lane_id();
+    const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t nrun = period < T ? period : T;
+    for (int64_t b = w0; b < nrun; b += nw) {
+        int64_t ch = -1, cr = -1;
+        float hr[NK];
+        for (int64_t x = b; x < T; x += period) {
+            const int64_t ih = h[x], ir = r[x];
+            if (ih != ch || ir != cr) {          // wave-uniform
+                ch = ih;
+                cr = ir;
+                const float* ph = ent + ih * lde;
+                const float* pr = rel + ir * ldr;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int c = lane + 64 * k;
+                    hr[k] = c < d ? ph[c] + pr[c] : 0.f;
+                }
+            }
+            const float* pt = ent + t[x] * lde;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int c = lane + 64 * k;
+                if (c < d) acc += fabsf(hr[k] - pt[c]);
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) score[x] = acc;
+        }
+    }
+}
+
+template <int NK>
+__global__ __launch_bounds__(kBlock) void triple_l1_bwd_kernel(const float* __restrict__ ent, int64_t lde,
+                                                               const float* __restrict__ rel, int64_t ldr,
+                                                               const int64_t* __restrict__ h, const int64_t* __restrict__ r,
+                                                               const int64_t* __restrict__ t, int64_t T, int64_t period, int d,
+                                                               const float* __restrict__ gscore, float* __restrict__ dent,
+                                                               int64_t ldde, float* __restrict__ drel, int64_t lddr) {
+    const int lane = lane_id();
+    const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t nrun = period < T ? period : T;
+    for (int64_t b = w0; b < nrun; b += nw) {
+        int64_t ch = -1, cr = -1;
+        float hr[NK], acc[NK];
+        auto flush = [&]() {
+            if (ch < 0) return;
+            float* qh = dent + ch * ldde;
+            float* qr = drel + cr * lddr;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int c = lane + 64 * k;
+                if (c < d && acc[k] != 0.f) {
+                    atomicAdd(qh + c, acc[k]);
+                    atomicAdd(qr + c, acc[k]);
+                }
+            }
+        };
+        for (int64_t x = b; x < T; x += period) {
+            const int64_t ih = h[x], ir = r[x], it = t[x];
+            if (ih != ch || ir != cr) {          // wave-uniform
+                flush();
+                ch = ih;
+                cr = ir;
+                const float* ph = ent + ih * lde;
+                const float* pr = rel + ir * ldr;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int c = lane + 64 * k;
+                    hr[k] = c < d ? ph[c] + pr[c] : 0.f;
+                    acc[k] = 0.f;
+                }
+            }
+            const float g = gscore[x];
+            const float* pt = ent + it * lde;
+            float* qt = dent + it * ldde;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int c = lane + 64 * k;
+                if (c < d) {
+                    const float v = g * sgn(hr[k] - pt[c]);
+                    acc[k] += v;
+                    if (v != 0.f) atomicAdd(qt + c, -v);
+                }
+            }
+        }
+        flush();
+    }
+}
+
+// ---- pair cosine distance ----------------------------------------------------------------------------
+// F.normalize(x, 2, -1) = x / max(||x||, eps), eps = 1e-12 (torch default, src/jmac_model.py:245-246)
+constexpr float kNormEps = 1e-12f;
+
+template <bool VEC>
+__device__ __forceinline__ void pair_dots(const float* __restrict__ pa, const float* __restrict__ pb, int d, int lane,
+                                          float& ab, float& aa, float& bb) {
+    float s_ab = 0.f, s_aa = 0.f, s_bb = 0.f;
+    if (VEC) {
+        const int D4 = d >> 2;
+#pragma unroll 2
+        for (int c = lane; c < D4; c += 64) {
+            const float4 a = ld4(pa + 4 * c), b = ld4(pb + 4 * c);
+            s_ab += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            s_aa += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            s_bb += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+        }
+    } else {
+        for (int c = lane; c < d; c += 64) {
+            const float a = pa[c], b = pb[c];
+            s_ab += a * b;
+            s_aa += a * a;
+            s_bb += b * b;
+        }
+    }
+    float v[3] = {s_ab, s_aa, s_bb};
+    wave_sum_n<3>(v);
+    ab = v[0];
+    aa = v[1];
+    bb = v[2];
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void pair_cosine_fwd_kernel(const float* __restrict__ e1, int64_t ld1,
+                                                                 const float* __restrict__ e2, int64_t ld2,
+                                                                 const int64_t* __restrict__ i1, const int64_t* __restrict__ i2,
+                                                                 int64_t L, int d, float* __restrict__ dist) {
+    const int lane = lane_id();
+    const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * kWavesPerBlock;
+    for (int64_t x = w0; x < L; x += nw) {
+        float ab, aa, bb;
+        pair_dots<VEC>(e1 + i1[x] * ld1, e2 + i2[x] * ld2, d, lane, ab, aa, bb);
+        const float na = fmaxf(sqrtf(aa), kNormEps), nb = fmaxf(sqrtf(bb), kNormEps);
+        if (lane == 0) dist[x] = 1.f - ab / (na * nb);
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void pair_cosine_bwd_kernel(const float* __restrict__ e1, int64_t ld1,
+                                                                 const float* __restrict__ e2, int64_t ld2,
+                                                                 const int64_t* __restrict__ i1, const int64_t* __restrict__ i2,
+                                                                 int64_t L, int d, const float* __restrict__ gdist,
+                                                                 float* __restrict__ de1, int64_t ldd1, float* __restrict__ de2,
+                                                                 int64_t ldd2) {
+    const int lane = lane_id();
+    const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * kWavesPerBlock;
+    for (int64_t x = w0; x < L; x += nw) {
+        const int64_t ia = i1[x], ib = i2[x];
+        const float* pa = e1 + ia * ld1;
+        const float* pb = e2 + ib * ld2;
+        float ab, aa, bb;
+        pair_dots<VEC>(pa, pb, d, lane, ab, aa, bb);
+        const float ra = sqrtf(aa), rb = sqrtf(bb);
+        const float na = fmaxf(ra, kNormEps), nb = fmaxf(rb, kNormEps);
+        // dist = 1 - (a.b)/(na nb);  with u = a/na, v = b/nb:  d dist/d a = -(v - (u.v) u)/na  (0 below eps)
+        const float g = -gdist[x];
+        const float inv = 1.f / (na * nb);
+        const float c = ab * inv;
+        const float ka = ra > kNormEps ? c / (na * na) : 0.f;   // clamped norm is constant: no radial term
+        const float kb = rb > kNormEps ? c / (nb * nb) : 0.f;
+        float* qa = de1 + ia * ldd1;
+        float* qb = de2 + ib * ldd2;
+        // scalar lane layout for the atomics (256 contiguous bytes per wave instruction)
+        for (int cidx = lane; cidx < d; cidx += 64) {
+            const float a = pa[cidx], b = pb[cidx];
+            atomicAdd(qa + cidx, g * (b * inv - ka * a));
+            atomicAdd(qb + cidx, g * (a * inv - kb * b));
+        }
+    }
+}
+
+inline unsigned wave_grid(int64_t units) {
+    int64_t b = (units + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (b < 1) b = 1;
+    return (unsigned)(b < 8192 ? b : 8192);
+}
+
+inline bool vec_ok(int64_t d, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
+    if (d % 4) return false;
+    for (int64_t l : lds)
+        if (l % 4) return false;
+    for (const void* p : ptrs)
+        if ((uintptr_t)p % 16) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+#define JMAC_DISPATCH_NK(nk, ...)                          \
+    switch (nk) {                                          \
+        case 1: { constexpr int NK = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int NK = 2; __VA_ARGS__; } break; \
+        case 3: { constexpr int NK = 3; __VA_ARGS__; } break; \
+        case 4: { constexpr int NK = 4; __VA_ARGS__; } break; \
+        case 5: { constexpr int NK = 5; __VA_ARGS__; } break; \
+        case 6: { constexpr int NK = 6; __VA_ARGS__; } break; \
+        case 7: { constexpr int NK = 7; __VA_ARGS__; } break; \
+        default: { constexpr int NK = 8; __VA_ARGS__; } break; \
+    }
+
+int jmac_triple_l1_fwd_f32(const float* ent, int64_t lde, const float* rel, int64_t ldr, const int64_t* h, const int64_t* r,
+                           const int64_t* t, int64_t T, int64_t period, int64_t d, float* score, jmac_stream_t stream) {
+    if (T < 0 || d <= 0) return JMAC_EINVAL;
+    if (d > 512) return JMAC_EDIM;
+    if (T == 0) return JMAC_OK;
+    if (!ent || !rel || !h || !r || !t || !score) return JMAC_EINVAL;
+    if (period <= 0 || period > T) period = T;
+    hipStream_t st = (hipStream_t)stream;
+    const int nk = (int)((d + 63) / 64);
+    JMAC_DISPATCH_NK(nk, hipLaunchKernelGGL((triple_l1_fwd_kernel<NK>), dim3(wave_grid(period)), dim3(kBlock), 0, st, ent, lde, rel,
+                                            ldr, h, r, t, T, period, (int)d, score));
+    return (int)hipGetLastError();
+}
+
+int jmac_triple_l1_bwd_f32(const float* ent, int64_t lde, const float* rel, int64_t ldr, const int64_t* h, const int64_t* r,
+                           const int64_t* t, int64_t T, int64_t period, int64_t d, const float* gscore, float* dent,
+                           int64_t ldde, float* drel, int64_t lddr, jmac_stream_t stream) {
+    if (T < 0 || d <= 0) return JMAC_EINVAL;
+    if (d > 512) return JMAC_EDIM;
+    if (T == 0) return JMAC_OK;
+    if (!ent || !rel || !h || !r || !t || !gscore || !dent || !drel) return JMAC_EINVAL;
+    if (period <= 0 || period > T) period = T;
+    hipStream_t st = (hipStream_t)stream;
+    const int nk = (int)((d + 63) / 64);
+    JMAC_DISPATCH_NK(nk, hipLaunchKernelGGL((triple_l1_bwd_kernel<NK>), dim3(wave_grid(period)), dim3(kBlock), 0, st, ent, lde, rel,
+                                            ldr, h, r, t, T, period, (int)d, gscore, dent, ldde, drel, lddr));
+    return (int)hipGetLastError();
+}
+
+int jmac_pair_cosine_fwd_f32(const float* e1, int64_t ld1, const float* e2, int64_t ld2, const int64_t* i1, const int64_t* i2,
+                             int64_t L, int64_t d, float* dist, jmac_stream_t stream) {
+    if (L < 0 || d <= 0 || d >= INT32_MAX) return JMAC_EINVAL;
+    if (L == 0) return JMAC_OK;
+    if (!e1 || !e2 || !i1 || !i2 || !dist) return JMAC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (vec_ok(d, {ld1, ld2}, {e1, e2}))
+        hipLaunchKernelGGL(pair_cosine_fwd_kernel<true>, dim3(wave_grid(L)), dim3(kBlock), 0, st, e1, ld1, e2, ld2, i1, i2, L, (int)d, dist);
+    else
+        hipLaunchKernelGGL(pair_cosine_fwd_kernel<false>, dim3(wave_grid(L)), dim3(kBlock), 0, st, e1, ld1, e2, ld2, i1, i2, L, (int)d, dist);
+    return (int)hipGetLastError();
+}
+
+int jmac_pair_cosine_bwd_f32(const float* e1, int64_t ld1, const float* e2, int64_t ld2, const int64_t* i1, const int64_t* i2,
+                             int64_t L, int64_t d, const float* gdist, float* de1, int64_t ldd1, float* de2, int64_t ldd2,
+                             jmac_stream_t stream) {
+    if (L < 0 || d <= 0 || d >= INT32_MAX) return JMAC_EINVAL;
+    if (L == 0) return JMAC_OK;
+    if (!e1 || !e2 || !i1 || !i2 || !gdist || !de1 || !de2) return JMAC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (vec_ok(d, {ld1, ld2}, {e1, e2}))
+        hipLaunchKernelGGL(pair_cosine_bwd_kernel<true>, dim3(wave_grid(L)), dim3(kBlock), 0, st, e1, ld1, e2, ld2, i1, i2, L, (int)d,
+                           gdist, de1, ldd1, de2, ldd2);
+    else
+        hipLaunchKernelGGL(pair_cosine_bwd_kernel<false>, dim3(wave_grid(L)), dim3(kBlock), 0, st, e1, ld1, e2, ld2, i1, i2, L, (int)d,
+                           gdist, de1, ldd1, de2, ldd2);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+"""Fused gathers of the completion / alignment losses.
+
+``triple_l1_score`` is ``torch.norm(E[h] + R[r] - E[t], 1, -1)`` of ``JMAC.completion_loss``
+(src/jmac_model.py:345-350); ``pair_cosine_distance`` is ``1 - sum(normalize(E1[i]) * normalize(E2[j]), 1)``
+of ``alignment_loss`` / ``alignment_loss_simple`` (src/jmac_model.py:245-247, 271-291).  One kernel each
+way instead of three (two) gathers, the elementwise chain and three (two) index_add passes.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import check, lib, ptr, require_device, stream
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError("jmac_amd losses compute in fp32 (got %s)" % t.dtype)
+    return t if t.stride(-1) == 1 and t.dim() == 2 else t.contiguous()
+
+
+def _index(i: torch.Tensor, n: int, device) -> torch.Tensor:
+    i = i.reshape(-1)
+    if i.dtype != torch.int64 or i.device != device:
+        i = i.to(device=device, dtype=torch.int64)
+    return i.contiguous()
+
+
+class _TripleL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ent, rel, h, r, t, period):
+        require_device(ent, rel, h, r, t)
+        ent, rel = _rows(ent), _rows(rel)
+        T, d = h.numel(), ent.shape[1]
+        if rel.shape[1] != d or r.numel() != T or t.numel() != T:
+            raise ValueError("triple_l1_score: shapes disagree")
+        score = torch.empty(T, dtype=torch.float32, device=ent.device)
+        check(lib().jmac_triple_l1_fwd_f32(ptr(ent), ent.stride(0), ptr(rel), rel.stride(0), ptr(h), ptr(r), ptr(t), T,
+                                           int(period), d, ptr(score), stream()), "jmac_triple_l1_fwd_f32")
+        ctx.save_for_backward(ent, rel, h, r, t)
+        ctx.period = int(period)
+        return score
+
+    @staticmethod
+    def backward(ctx, g):
+        ent, rel, h, r, t = ctx.saved_tensors
+        T, d = h.numel(), ent.shape[1]
+        g = g.contiguous()
+        dent = torch.zeros((ent.shape[0], d), dtype=torch.float32, device=ent.device)
+        drel = torch.zeros((rel.shape[0], d), dtype=torch.float32, device=ent.device)
+        check(lib().jmac_triple_l1_bwd_f32(ptr(ent), ent.stride(0), ptr(rel), rel.stride(0), ptr(h), ptr(r), ptr(t), T,
+                                           ctx.period, d, ptr(g), ptr(dent), d, ptr(drel), d, stream()), "jmac_triple_l1_bwd_f32")
+        return dent, drel, None, None, None, None
+
+
+def triple_l1_score(ent: torch.Tensor, rel: torch.Tensor, h: torch.Tensor, r: torch.Tensor, t: torch.Tensor,
+                    period: int = 0) -> torch.Tensor:
+    """``torch.norm(ent[h] + rel[r] - ent[t], 1, -1)`` -> [T] (src/jmac_model.py:345-350).
+
+    ``period``: hint that triples x, x+period, ... share (h, r), as in the reference's batches
+    (train.py:347-352, period = batch size); results do not depend on it."""
+    dev = ent.device
+    return _TripleL1.apply(ent, rel, _index(h, ent.shape[0], dev), _index(r, rel.shape[0], dev), _index(t, ent.shape[0], dev),
+                           int(period))
+
+
+class _PairCosine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e1, e2, i1, i2):
+        require_device(e1, e2, i1, i2)
+        e1, e2 = _rows(e1), _rows(e2)
+        L, d = i1.numel(), e1.shape[1]
+        if e2.shape[1] != d or i2.numel() != L:
+            raise ValueError("pair_cosine_distance: shapes disagree")
+        dist = torch.empty(L, dtype=torch.float32, device=e1.device)
+        check(lib().jmac_pair_cosine_fwd_f32(ptr(e1), e1.stride(0), ptr(e2), e2.stride(0), ptr(i1), ptr(i2), L, d, ptr(dist),
+                                             stream()), "jmac_pair_cosine_fwd_f32")
+        ctx.save_for_backward(e1, e2, i1, i2)
+        return dist
+
+    @staticmethod
+    def backward(ctx, g):
+        e1, e2, i1, i2 = ctx.saved_tensors
+        L, d = i1.numel(), e1.shape[1]
+        g = g.contiguous()
+        de1 = torch.zeros((e1.shape[0], d), dtype=torch.float32, device=e1.device)
+        de2 = torch.zeros((e2.shape[0], d), dtype=torch.float32, device=e1.device)
+        check(lib().jmac_pair_cosine_bwd_f32(ptr(e1), e1.stride(0), ptr(e2), e2.stride(0), ptr(i1), ptr(i2), L, d, ptr(g),
+                                             ptr(de1), d, ptr(de2), d, stream()), "jmac_pair_cosine_bwd_f32")
+        return de1, de2, None, None
+
+
+def pair_cosine_distance(e1: torch.Tensor, i1: torch.Tensor, e2: torch.Tensor, i2: torch.Tensor) -> torch.Tensor:
+    """``1 - sum(F.normalize(e1[i1], 2, -1) * F.normalize(e2[i2], 2, -1), 1)`` -> [L]."""
+    dev = e1.device
+    return _PairCosine.apply(e1, e2, _index(i1, e1.shape[0], dev), _index(i2, e2.shape[0], dev))

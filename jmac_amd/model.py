@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import scoring
+from . import losses, scoring
 from .layer import RelationAwareLayer, get_param
 
 
@@ -121,10 +121,11 @@ class JMAC(nn.Module):
         return scoring.linkpred_dist([comp_layers[l] for l in layers], [comp_rel_layers[l] for l in layers],
                                      e_index, r_index, pred_head)
 
-    # ---- losses (torch; src/jmac_model.py:237-292, :316-380) ---------------------------------------
+    # ---- losses (src/jmac_model.py:237-292, :316-380): gathers + L1 / cosine fused in HIP (jmac_amd.losses),
+    # the margin arithmetic on the resulting [T] / [L] vectors stays in torch ----------------------------
     @staticmethod
     def _cos_dist(e1, i1, e2, i2):
-        return 1 - torch.sum(F.normalize(e1.index_select(0, i1), 2, -1) * F.normalize(e2.index_select(0, i2), 2, -1), dim=1)
+        return losses.pair_cosine_distance(e1, i1, e2, i2)
 
     def alignment_loss_simple(self, links, ent_embeddings1, ent_embeddings2):
         if not len(links):
@@ -157,9 +158,7 @@ class JMAC(nn.Module):
         loss = 0
         for layer in range(self.args.num_gcn_layer):
             ent, rel = (comp1[layer], rel1[layer]) if source else (comp2[layer], rel2[layer])
-            # index_select == ent[h] (src/jmac_model.py:345-347); its backward is one index_add pass instead
-            # of advanced indexing's sort-based index_put
-            score = torch.norm(ent.index_select(0, h) + rel.index_select(0, r) - ent.index_select(0, t), 1, -1).flatten()
+            score = losses.triple_l1_score(ent, rel, h, r, t, period=bs)    # src/jmac_model.py:345-350
             pos, neg = score[:bs], score[bs:]
             # the reference consumes the b-major negative block as n-major (view(-1, B).permute): kept as is
             pos = pos.view(-1, min(bs, len(pos))).permute(1, 0)

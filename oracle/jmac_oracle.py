@@ -352,6 +352,16 @@ def alignment_quality(emb1: Tensor, emb2: Tensor, list1: Sequence[int], list2: S
 # Losses (jmac_model.py:237-292, :316-380) -- stay in torch in the product too; restated for the
 # harness-level parity tests.
 # --------------------------------------------------------------------------------------------
+def triple_l1_score(ent: Tensor, rel: Tensor, h: Tensor, r: Tensor, t: Tensor) -> Tensor:
+    """jmac_model.py:345-350: h = E[batch_h]; t = E[batch_t]; r = R[batch_r]; norm((h + r) - t, 1, -1)."""
+    return torch.norm((ent[h] + rel[r]) - ent[t], 1, -1).flatten()
+
+
+def pair_cosine_distance(e1: Tensor, i1: Tensor, e2: Tensor, i2: Tensor) -> Tensor:
+    """jmac_model.py:245-247 / :271-273 / :276-279: 1 - sum(normalize(E1[i]) * normalize(E2[j]), dim=1)."""
+    return 1 - torch.sum(F.normalize(e1[i1], 2, -1) * F.normalize(e2[i2], 2, -1), dim=1)
+
+
 def alignment_loss_simple(links, emb1: Tensor, emb2: Tensor):
     """jmac_model.py:237-249."""
     if not len(links):

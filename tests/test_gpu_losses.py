@@ -1,0 +1,111 @@
+"""GPU parity: fused loss gathers (row f3) against the oracle's restatement of src/jmac_model.py:245-247,
+271-291, 345-350 evaluated in float64, forward and backward, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle.jmac_oracle as orc
+from util import assert_close, load_golden, t
+
+
+@pytest.mark.parametrize("period", [0, 100, 7])
+@pytest.mark.parametrize("N,nr,d,T", [(50, 7, 300, 400), (301, 20, 256, 2600), (64, 5, 7, 33), (11, 3, 30, 1), (40, 4, 512, 999)])
+def test_triple_l1_score_fwd_bwd(N, nr, d, T, period):
+    from jmac_amd import losses
+    gen = torch.Generator().manual_seed(N + T)
+    ent = torch.randn(N, d, generator=gen)
+    rel = torch.randn(nr, d, generator=gen)
+    h = torch.randint(0, N, (T,), generator=gen)
+    r = torch.randint(0, nr, (T,), generator=gen)
+    tl = torch.randint(0, N, (T,), generator=gen)
+    if T > 4:
+        tl[:3] = h[:3]                                # h == t: the row receives +g s and -g s
+    if period == 100 and T > 100:                     # the reference's batch layout: (h, r) repeat with the period ...
+        h, r = h[:100].repeat(T // 100 + 1)[:T].clone(), r[:100].repeat(T // 100 + 1)[:T].clone()
+        h[150], r[250] = (h[150] + 1) % N, (r[250] + 1) % nr      # ... except where the hint is wrong
+    w = torch.randn(T, generator=gen)
+    e64, r64 = ent.double().requires_grad_(True), rel.double().requires_grad_(True)
+    ref = orc.triple_l1_score(e64, r64, h, r, tl)
+    (ref * w.double()).sum().backward()
+    eg, rg = ent.cuda().requires_grad_(True), rel.cuda().requires_grad_(True)
+    out = losses.triple_l1_score(eg, rg, h.cuda(), r.cuda(), tl.cuda(), period=period)
+    (out * w.cuda()).sum().backward()
+    assert_close(out, ref, 1e-5, what="score")
+    assert_close(eg.grad, e64.grad, 1e-5, what="d ent")     # atomics: order free, fp32 rounding only
+    assert_close(rg.grad, r64.grad, 1e-5, what="d rel")
+
+
+def test_triple_l1_sign_of_zero_and_strided_rows():
+    from jmac_amd import losses
+    ent = torch.zeros(4, 8)
+    rel = torch.zeros(2, 8)
+    ent[1, :4] = 1.0
+    big = torch.randn(6, 24)                            # column slice: row stride 24, 16-byte aligned
+    idx = torch.tensor([0, 1, 2])
+    eg = ent.cuda().requires_grad_(True)
+    rg = rel.cuda().requires_grad_(True)
+    out = losses.triple_l1_score(eg, rg, torch.tensor([0, 1]).cuda(), torch.tensor([0, 1]).cuda(), torch.tensor([2, 3]).cuda())
+    out.sum().backward()
+    assert out.cpu().tolist() == [0.0, 4.0]
+    assert eg.grad.cpu()[0].abs().sum().item() == 0.0   # sign(0) = 0, as torch.norm's backward
+    assert eg.grad.cpu()[1].tolist() == [1, 1, 1, 1, 0, 0, 0, 0]
+    sl = big.cuda()[:, 8:16]
+    ref = orc.triple_l1_score(big[:, 8:16].double(), big[:2, 8:16].double(), idx, torch.tensor([0, 1, 0]), idx.flip(0))
+    got = losses.triple_l1_score(sl, sl[:2], idx.cuda(), torch.tensor([0, 1, 0]).cuda(), idx.flip(0).cuda())
+    assert_close(got, ref, 1e-6)
+
+
+@pytest.mark.parametrize("N1,N2,d,L", [(50, 60, 300, 500), (300, 200, 256, 5000), (9, 9, 5, 17), (30, 30, 64, 1)])
+def test_pair_cosine_distance_fwd_bwd(N1, N2, d, L):
+    from jmac_amd import losses
+    gen = torch.Generator().manual_seed(N1 + L)
+    e1, e2 = torch.randn(N1, d, generator=gen), torch.randn(N2, d, generator=gen) * 3
+    i1 = torch.randint(0, N1, (L,), generator=gen)
+    i2 = torch.randint(0, N2, (L,), generator=gen)
+    w = torch.randn(L, generator=gen)
+    a64, b64 = e1.double().requires_grad_(True), e2.double().requires_grad_(True)
+    ref = orc.pair_cosine_distance(a64, i1, b64, i2)
+    (ref * w.double()).sum().backward()
+    ag, bg = e1.cuda().requires_grad_(True), e2.cuda().requires_grad_(True)
+    out = losses.pair_cosine_distance(ag, i1.cuda(), bg, i2.cuda())
+    (out * w.cuda()).sum().backward()
+    assert_close(out, ref, 1e-5, atol=2e-6, what="dist")
+    assert_close(ag.grad, a64.grad, 2e-5, what="d e1")
+    assert_close(bg.grad, b64.grad, 2e-5, what="d e2")
+
+
+def test_pair_cosine_same_table_and_zero_row():
+    from jmac_amd import losses
+    gen = torch.Generator().manual_seed(3)
+    e = torch.randn(20, 16, generator=gen)
+    e[5] = 0                                             # F.normalize clamps the norm at 1e-12: distance 1, finite grads
+    i1, i2 = torch.tensor([0, 5, 7, 7]), torch.tensor([1, 2, 7, 5])
+    e64 = e.double().requires_grad_(True)
+    ref = orc.pair_cosine_distance(e64, i1, e64, i2)
+    ref.sum().backward()
+    eg = e.cuda().requires_grad_(True)
+    out = losses.pair_cosine_distance(eg, i1.cuda(), eg, i2.cuda())
+    out.sum().backward()
+    assert_close(out, ref, 1e-5, atol=2e-6)
+    assert torch.isfinite(eg.grad).all()
+    keep = torch.ones(20, dtype=torch.bool)
+    keep[5] = False                                      # the zero row's gradient is 1/eps-scaled in both; compare the rest
+    assert_close(eg.grad.cpu()[keep], e64.grad[keep], 2e-5, atol=1e-6)
+
+
+def test_losses_on_reference_golden_model():
+    """completion_loss / alignment_loss pieces on the reference's captured embeddings (model_small.npz)."""
+    from jmac_amd import losses
+    g = load_golden("model_small")
+    comp, rel = t(g["comp1_l1"]), t(g["rel1_l1"])
+    h, r = t(g["lp_h"]).long(), t(g["lp_r"]).long()
+    tl = t(g["lp_t"]).long()
+    ref = orc.triple_l1_score(comp.double(), rel.double(), h, r, tl)
+    got = losses.triple_l1_score(comp.cuda(), rel.cuda(), h.cuda(), r.cuda(), tl.cuda())
+    assert_close(got, ref, 1e-5)
+    # the same numbers are the gold column of the reference's link-prediction distances, layer by layer summed
+    d0 = orc.triple_l1_score(t(g["comp1_l0"]).double(), t(g["rel1_l0"]).double(), h, r, tl)
+    lp = torch.from_numpy(g["lp_dist"])[torch.arange(len(h)), tl]
+    assert_close(ref + d0, lp, 1e-5)
