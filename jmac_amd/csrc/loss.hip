@@ -33,16 +33,18 @@ template <int NK>
 __global__ __launch_bounds__(kBlock) void triple_l1_fwd_kernel(const float* __restrict__ ent, int64_t lde,
                                                                const float* __restrict__ rel, int64_t ldr,
                                                                const int64_t* __restrict__ h, const int64_t* __restrict__ r,
-                                                               const int64_t* __restrict__ t, int64_t T, int64_t period, int d,
-                                                               float* __restrict__ score) {
+                                                               const int64_t* __restrict__ t, int64_t T, int64_t period, int parts,
+                                                               int d, float* __restrict__ score) {
     const int lane = lane_id();
     const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * kWavesPerBlock;
-    const int64_t nrun = period < T ? period : T;
-    for (int64_t b = w0; b < nrun; b += nw) {
+    const int64_t nrun = (period < T ? period : T) * parts;
+    const int64_t stride = period * parts;
+    for (int64_t u = w0; u < nrun; u += nw) {     // unit = (run b, part p): triples b + (p + parts*j) * period
+        const int64_t b = u / parts, p = u % parts;
         int64_t ch = -1, cr = -1;
         float hr[NK];
-        for (int64_t x = b; x < T; x += period) {
+        for (int64_t x = b + p * period; x < T; x += stride) {
             const int64_t ih = h[x], ir = r[x];
             if (ih != ch || ir != cr) {          // wave-uniform
                 ch = ih;
@@ -72,14 +74,16 @@ template <int NK>
 __global__ __launch_bounds__(kBlock) void triple_l1_bwd_kernel(const float* __restrict__ ent, int64_t lde,
                                                                const float* __restrict__ rel, int64_t ldr,
                                                                const int64_t* __restrict__ h, const int64_t* __restrict__ r,
-                                                               const int64_t* __restrict__ t, int64_t T, int64_t period, int d,
-                                                               const float* __restrict__ gscore, float* __restrict__ dent,
+                                                               const int64_t* __restrict__ t, int64_t T, int64_t period, int parts,
+                                                               int d, const float* __restrict__ gscore, float* __restrict__ dent,
                                                                int64_t ldde, float* __restrict__ drel, int64_t lddr) {
     const int lane = lane_id();
     const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * kWavesPerBlock;
-    const int64_t nrun = period < T ? period : T;
-    for (int64_t b = w0; b < nrun; b += nw) {
+    const int64_t nrun = (period < T ? period : T) * parts;
+    const int64_t stride = period * parts;
+    for (int64_t u = w0; u < nrun; u += nw) {
+        const int64_t b = u / parts, p = u % parts;
         int64_t ch = -1, cr = -1;
         float hr[NK], acc[NK];
         auto flush = [&]() {
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void triple_l1_bwd_kernel(const float* __re
                 }
             }
         };
-        for (int64_t x = b; x < T; x += period) {
+        for (int64_t x = b + p * period; x < T; x += stride) {
             const int64_t ih = h[x], ir = r[x], it = t[x];
             if (ih != ch || ir != cr) {          // wave-uniform
                 flush();
@@ -216,6 +220,16 @@ inline unsigned wave_grid(int64_t units) {
     return (unsigned)(b < 8192 ? b : 8192);
 }
 
+// a run of T/period triples is cut into `parts` interleaved sub-runs so that at least ~8k wavefronts exist
+// (1000 runs of 26 left three quarters of the chip idle and each wave on a 26-deep dependent chain)
+inline int run_parts(int64_t T, int64_t period) {
+    const int64_t len = (T + period - 1) / period;
+    int64_t p = (8192 + period - 1) / period;
+    if (p > len) p = len;
+    if (p < 1) p = 1;
+    return (int)p;
+}
+
 inline bool vec_ok(int64_t d, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
     if (d % 4) return false;
     for (int64_t l : lds)
@@ -250,8 +264,9 @@ int jmac_triple_l1_fwd_f32(const float* ent, int64_t lde, const float* rel, int6
     if (period <= 0 || period > T) period = T;
     hipStream_t st = (hipStream_t)stream;
     const int nk = (int)((d + 63) / 64);
-    JMAC_DISPATCH_NK(nk, hipLaunchKernelGGL((triple_l1_fwd_kernel<NK>), dim3(wave_grid(period)), dim3(kBlock), 0, st, ent, lde, rel,
-                                            ldr, h, r, t, T, period, (int)d, score));
+    const int parts = run_parts(T, period);
+    JMAC_DISPATCH_NK(nk, hipLaunchKernelGGL((triple_l1_fwd_kernel<NK>), dim3(wave_grid(period * parts)), dim3(kBlock), 0, st, ent, lde,
+                                            rel, ldr, h, r, t, T, period, parts, (int)d, score));
     return (int)hipGetLastError();
 }
 
@@ -265,8 +280,9 @@ int jmac_triple_l1_bwd_f32(const float* ent, int64_t lde, const float* rel, int6
     if (period <= 0 || period > T) period = T;
     hipStream_t st = (hipStream_t)stream;
     const int nk = (int)((d + 63) / 64);
-    JMAC_DISPATCH_NK(nk, hipLaunchKernelGGL((triple_l1_bwd_kernel<NK>), dim3(wave_grid(period)), dim3(kBlock), 0, st, ent, lde, rel,
-                                            ldr, h, r, t, T, period, (int)d, gscore, dent, ldde, drel, lddr));
+    const int parts = run_parts(T, period);
+    JMAC_DISPATCH_NK(nk, hipLaunchKernelGGL((triple_l1_bwd_kernel<NK>), dim3(wave_grid(period * parts)), dim3(kBlock), 0, st, ent, lde,
+                                            rel, ldr, h, r, t, T, period, parts, (int)d, gscore, dent, ldde, drel, lddr));
     return (int)hipGetLastError();
 }
 
