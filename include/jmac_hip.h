@@ -103,6 +103,19 @@ int jmac_rel_attn_aggregate_fwd_f32(
     float* seg_den,
     void* ws, size_t ws_bytes, jmac_stream_t stream);
 
+/* Same op with bf16 TABLES (P, QZ, RR: raw bf16 bits, rows 8-byte aligned: ld % 4 == 0, d % 4 == 0);
+ * a_att, the logits, the softmax, the accumulators and every output stay fp32 ("keep
+ * P/Q/Z tables bf16 but logits, softmax, accumulators ... in fp32").  Halves the gathered bytes of
+ * the HBM-bound kernel; forward only (BASELINE config 3: bf16 union-graph scoring is inference). */
+int jmac_rel_attn_aggregate_fwd_bf16(
+    const uint16_t* P, int64_t ldp, const uint16_t* QZ, int64_t ldqz, const uint16_t* RR, int64_t ldrr,
+    const float* a_att, const int32_t* rowptr, const int32_t* col, const int32_t* etype,
+    const jmac_item_t* items, const jmac_split_t* splits, const int32_t* counts,
+    int64_t n_items_max, int64_t n_splits_max, int64_t n_parts_max, int64_t N, int64_t d,
+    float slope, int32_t loop_rel, float out_scale, float* out, int64_t ldo, float* seg_max,
+    float* seg_den,
+    void* ws, size_t ws_bytes, jmac_stream_t stream);
+
 /* Backward of the op above (replaces autograd through the same reference lines).
  *   G [N,d] (ldg) = dL/dout;  outputs: dP [N,d] (lddp), dQZ [N,2d] (lddqz), dRR [nr+1,2d] (lddrr),
  *   da [d].  All outputs are fully written (no pre-zeroing needed).
@@ -159,6 +172,11 @@ int jmac_bn_tanh_bwd_f32(const float* x, int64_t ldx, const float* y, int64_t ld
 int jmac_l1_score_f32(const float* er, int64_t lder, const float* table, int64_t ldt, int64_t B,
                       int64_t N, int64_t d, float* out, int64_t ldout, int32_t accumulate,
                       jmac_stream_t stream);
+/* Same with bf16 operands (raw bits; rows 8-byte aligned), fp32 accumulation and output
+ * (BASELINE config 3: bf16 entity tables scored against all entities of the union graph). */
+int jmac_l1_score_bf16(const uint16_t* er, int64_t lder, const uint16_t* table, int64_t ldt, int64_t B,
+                       int64_t N, int64_t d, float* out, int64_t ldout, int32_t accumulate,
+                       jmac_stream_t stream);
 
 /* rank[b] = 1 + #{n : score[b,n] < score[b,gold] or (== and n < gold[b])}, where entries listed in
  * the filter CSR (filt_ptr [B+1], filt_idx) other than the gold are skipped.  `score` is a DISTANCE

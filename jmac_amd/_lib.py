@@ -44,6 +44,9 @@ _SIGS = {
     "jmac_rel_attn_aggregate_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp,
                                                   i64, i64, i64, i64, i64, f32, i32, f32, vp, i64, vp, vp,
                                                   vp, sz, vp]),
+    "jmac_rel_attn_aggregate_fwd_bf16": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp,
+                                                   i64, i64, i64, i64, i64, f32, i32, f32, vp, i64, vp, vp,
+                                                   vp, sz, vp]),
     "jmac_rel_attn_bwd_workspace_bytes": (sz, [i64, i64, i64, i64, i64, i64, i64, i32]),
     "jmac_rel_attn_aggregate_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp,
                                                   C.POINTER(View), C.POINTER(View), C.POINTER(View),
@@ -55,6 +58,7 @@ _SIGS = {
     "jmac_bn_tanh_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, vp, vp, vp, i32, vp, i64, vp, vp,
                                        vp, sz, vp]),
     "jmac_l1_score_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, vp]),
+    "jmac_l1_score_bf16": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, vp]),
     "jmac_filtered_rank_f32": (C.c_int, [vp, i64, vp, vp, vp, i64, i64, vp, vp]),
     "jmac_sim_matrix_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, vp]),
     "jmac_sim_topk_workspace_bytes": (sz, [i64, i64]),

@@ -24,10 +24,7 @@ namespace {
 constexpr int kBlock = 256;            // 4 waves
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kPersistBlocks = 2048;   // 256 CUs x 8
-#ifndef JMAC_NT_GATHER
-#define JMAC_NT_GATHER 0   // measured: nt gathers 13.4 vs 12.3 ms on config 4, 36 vs 26 us on ja -> off
-#endif
-constexpr bool kNtGather = JMAC_NT_GATHER != 0;
+// (non-temporal gathers were measured and rejected: 13.4 vs 12.3 ms on config 4, 36 vs 26 us on ja)
 
 // IGroupLP pipeline for the machine scheduler: first the group's n vector-memory reads, then the vector ALU work.
 // (A plain sched_barrier does not do it: instruction selection already linearises the arithmetic ahead of it.)
@@ -38,7 +35,8 @@ constexpr bool kNtGather = JMAC_NT_GATHER != 0;
     } while (0)
 
 struct FwdArgs {
-    const float *P, *QZ, *RR, *a_att;
+    const void *P, *QZ, *RR;     // tables of element type TT (float or bf16_t)
+    const float* a_att;
     int64_t ldp, ldqz, ldrr, ldo;
     const int32_t *rowptr, *col, *etype;
     const jmac_item_t* items;
@@ -98,8 +96,12 @@ __device__ __forceinline__ float4 sel4(bool c, float4 a) { return c ? a : f4zero
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int NCH, int U, int D4T>
+template <int NCH, int U, int D4T, typename TT>
 __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
+    typedef typename RawOf<TT>::type raw_t;
+    const TT* const tP = static_cast<const TT*>(a.P);
+    const TT* const tQZ = static_cast<const TT*>(a.QZ);
+    const TT* const tRR = static_cast<const TT*>(a.RR);
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = gridDim.x * kWavesPerBlock;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
 #pragma unroll
     for (int k = 0; k < NCH; ++k) av[k] = L.any_h(k) ? sel4(L.is_h[k], ld4(a.a_att + (L.is_h[k] ? L.coff[k] : 0))) : f4zero();
     const bool has_loop = a.loop_rel >= 0;
-    const float* rloop = a.RR + (int64_t)(has_loop ? a.loop_rel : 0) * a.ldrr;
+    const TT* rloop = tRR + (int64_t)(has_loop ? a.loop_rel : 0) * a.ldrr;
 
     // Items are software-pipelined: while item k computes, the header of item k+2 and the first col/type
     // batch of item k+1 are already in flight, so a wave's critical path per item is one gather round trip
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
     // the loop relation's Rz row is the same for every destination: one read per wave
     float4 rl[NCH];
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) rl[k] = (L.any_v(k) && has_loop) ? ld4(rloop + L.coffc[k]) : f4zero();
+    for (int k = 0; k < NCH; ++k) rl[k] = (L.any_v(k) && has_loop) ? cvt4(ldraw(rloop + L.coffc[k])) : f4zero();
     if (it >= n_items) return;
     jmac_item_t nitem = a.items[min(it + nwaves, n_items - 1)];
     int ccol, ctyp;
@@ -144,13 +146,13 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
         const int i = item.seg;
         float4 pv[NCH], acc[NCH], zs[NCH];
         // a destination without in-edges needs no P row: re-read row 0 (cache hit) instead of its own
-        const float* prow = a.P + (int64_t)(item.end > item.beg ? i : 0) * a.ldp;
-        const float* zrow = a.QZ + (int64_t)i * a.ldqz;
+        const TT* prow = tP + (int64_t)(item.end > item.beg ? i : 0) * a.ldp;
+        const TT* zrow = tQZ + (int64_t)i * a.ldqz;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            pv[k] = L.any_h(k) ? ld4(prow + (L.is_h[k] ? L.coff[k] : 0)) : f4zero();
+            pv[k] = L.any_h(k) ? cvt4(ldraw(prow + (L.is_h[k] ? L.coff[k] : 0))) : f4zero();
             // self-loop term Z[i] (v-role lanes), fetched with the header-dependent loads rather than after the edges
-            zs[k] = (L.any_v(k) && has_loop) ? ld4(zrow + L.coffc[k]) : f4zero();
+            zs[k] = (L.any_v(k) && has_loop) ? cvt4(ldraw(zrow + L.coffc[k])) : f4zero();
             acc[k] = f4zero();
         }
 #pragma unroll
@@ -169,18 +171,19 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
             // degree-1 destination does not pay the instruction count of a full 4-edge group
             auto group = [&](auto uu_c, const int u0) {
                 constexpr int UU = decltype(uu_c)::value;
-                float4 q[UU][NCH], r[UU][NCH];
+                raw_t qraw[UU][NCH], rraw[UU][NCH];
+                float4 q[UU][NCH];
                 // 1) issue every gather of the group before any arithmetic
 #pragma unroll
                 for (int u = 0; u < UU; ++u) {
                     const int j = bcast_i(my_col, u0 + u);
                     const int t = bcast_i(my_typ, u0 + u);
-                    const float* qrow = a.QZ + (int64_t)j * a.ldqz;
-                    const float* rrow = a.RR + (int64_t)t * a.ldrr;
+                    const TT* qrow = tQZ + (int64_t)j * a.ldqz;
+                    const TT* rrow = tRR + (int64_t)t * a.ldrr;
 #pragma unroll
                     for (int k = 0; k < NCH; ++k) {
-                        q[u][k] = kNtGather ? ld4_nt(qrow + L.coffc[k]) : ld4(qrow + L.coffc[k]);
-                        r[u][k] = ld4(rrow + L.coffc[k]);
+                        qraw[u][k] = ldraw(qrow + L.coffc[k]);
+                        rraw[u][k] = ldraw(rrow + L.coffc[k]);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);   // measured: 11.6 ms vs 13.3 ms with the IGroupLP form (config 4)
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
                     float part = 0.f;
 #pragma unroll
                     for (int k = 0; k < NCH; ++k) {
-                        q[u][k] = sub4(q[u][k], r[u][k]);
+                        q[u][k] = sub4(cvt4(qraw[u][k]), cvt4(rraw[u][k]));
                         if (!L.all_valid(k)) q[u][k] = sel4(L.valid[k], q[u][k]);
                         if (L.any_h(k)) part += dot4(av[k], leaky4<D4T != 0>(add4(pv[k], q[u][k]), a.slope));
                     }
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
 
 // merges the partial (max, denominator, accumulator) triples of destinations that were split: one BLOCK per split
 // destination, wave w takes chunks w, w+4, ..., the four wave results are combined through LDS in wave order
-template <int NCH>
+template <int NCH, typename TT>
 __global__ __launch_bounds__(kBlock) void rel_attn_fwd_combine_kernel(FwdArgs a) {
     __shared__ float4 red[kWavesPerBlock][NCH][64];
     __shared__ float redl[kWavesPerBlock];
@@ -310,8 +313,8 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_combine_kernel(FwdArgs a)
                     float4 o = add4(add4(red[0][k][lane], red[1][k][lane]), add4(red[2][k][lane], red[3][k][lane]));
                     o = mul4(o, scale);
                     if (a.loop_rel >= 0) {
-                        float4 z = ld4(a.QZ + (int64_t)i * a.ldqz + L.coff[k]);
-                        float4 rz = ld4(a.RR + (int64_t)a.loop_rel * a.ldrr + L.coff[k]);
+                        float4 z = cvt4(ldraw(static_cast<const TT*>(a.QZ) + (int64_t)i * a.ldqz + L.coff[k]));
+                        float4 rz = cvt4(ldraw(static_cast<const TT*>(a.RR) + (int64_t)a.loop_rel * a.ldrr + L.coff[k]));
                         o = add4(o, sub4(z, rz));
                     }
                     st4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff), mul4(o, a.out_scale));
@@ -790,19 +793,12 @@ void launch_reduce_rows(const float* partial, int nparts, int W, float scale, fl
 }
 }  // namespace jmac
 
-extern "C" {
-
-size_t jmac_rel_attn_fwd_workspace_bytes(int64_t n_parts_max, int64_t d) {
-    if (n_parts_max < 0) n_parts_max = 0;
-    return align_up((size_t)n_parts_max * 8) + align_up((size_t)n_parts_max * d * 4) + 256;
-}
-
-int jmac_rel_attn_aggregate_fwd_f32(const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR,
-                                    int64_t ldrr, const float* a_att, const int32_t* rowptr, const int32_t* col,
-                                    const int32_t* etype, const jmac_item_t* items, const jmac_split_t* splits,
-                                    const int32_t* counts, int64_t n_items_max, int64_t n_splits_max,
-                                    int64_t n_parts_max, int64_t N, int64_t d, float slope, int32_t loop_rel, float out_scale, float* out, int64_t ldo,
-                                    float* seg_max, float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+template <typename TT>
+static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t ldqz, const TT* RR, int64_t ldrr, const float* a_att,
+                               const int32_t* rowptr, const int32_t* col, const int32_t* etype, const jmac_item_t* items,
+                               const jmac_split_t* splits, const int32_t* counts, int64_t n_items_max, int64_t n_splits_max,
+                               int64_t n_parts_max, int64_t N, int64_t d, float slope, int32_t loop_rel, float out_scale, float* out,
+                               int64_t ldo, float* seg_max, float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
     if (N < 0 || n_items_max < 0 || n_splits_max < 0) return JMAC_EINVAL;
     if (N == 0) return JMAC_OK;
     if (!P || !QZ || !RR || !a_att || !rowptr || !items || !counts || !out || !seg_max || !seg_den) return JMAC_EINVAL;
@@ -832,15 +828,44 @@ int jmac_rel_attn_aggregate_fwd_f32(const float* P, int64_t ldp, const float* QZ
     const int fwd_u = fwd_u_env ? fwd_u_env : (n_items_max <= 8 * kPersistBlocks ? 2 : 4);
     const bool slope01 = slope >= 0.f && slope <= 1.f;
     if (fwd_u == 2) {
-        JMAC_DISPATCH_D(a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 2, D4T>), dim3(grid), dim3(kBlock), 0, st, a));
+        JMAC_DISPATCH_D(a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 2, D4T, TT>), dim3(grid), dim3(kBlock), 0, st, a));
     } else {
-        JMAC_DISPATCH_D(a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 4, D4T>), dim3(grid), dim3(kBlock), 0, st, a));
+        JMAC_DISPATCH_D(a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 4, D4T, TT>), dim3(grid), dim3(kBlock), 0, st, a));
     }
     if (n_splits_max > 0) {
         const unsigned g2 = split_grid(n_splits_max);
-        JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_fwd_combine_kernel<NCH>), dim3(g2), dim3(kBlock), 0, st, a));
+        JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_fwd_combine_kernel<NCH, TT>), dim3(g2), dim3(kBlock), 0, st, a));
     }
     return (int)hipGetLastError();
+}
+
+extern "C" {
+
+size_t jmac_rel_attn_fwd_workspace_bytes(int64_t n_parts_max, int64_t d) {
+    if (n_parts_max < 0) n_parts_max = 0;
+    return align_up((size_t)n_parts_max * 8) + align_up((size_t)n_parts_max * d * 4) + 256;
+}
+
+int jmac_rel_attn_aggregate_fwd_f32(const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR,
+                                    int64_t ldrr, const float* a_att, const int32_t* rowptr, const int32_t* col,
+                                    const int32_t* etype, const jmac_item_t* items, const jmac_split_t* splits,
+                                    const int32_t* counts, int64_t n_items_max, int64_t n_splits_max,
+                                    int64_t n_parts_max, int64_t N, int64_t d, float slope, int32_t loop_rel, float out_scale, float* out, int64_t ldo,
+                                    float* seg_max, float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    return launch_rel_attn_fwd<float>(P, ldp, QZ, ldqz, RR, ldrr, a_att, rowptr, col, etype, items, splits, counts, n_items_max,
+                                      n_splits_max, n_parts_max, N, d, slope, loop_rel, out_scale, out, ldo, seg_max, seg_den, ws,
+                                      ws_bytes, stream);
+}
+
+int jmac_rel_attn_aggregate_fwd_bf16(const uint16_t* P, int64_t ldp, const uint16_t* QZ, int64_t ldqz, const uint16_t* RR,
+                                     int64_t ldrr, const float* a_att, const int32_t* rowptr, const int32_t* col,
+                                     const int32_t* etype, const jmac_item_t* items, const jmac_split_t* splits,
+                                     const int32_t* counts, int64_t n_items_max, int64_t n_splits_max,
+                                     int64_t n_parts_max, int64_t N, int64_t d, float slope, int32_t loop_rel, float out_scale, float* out, int64_t ldo,
+                                     float* seg_max, float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    return launch_rel_attn_fwd<bf16_t>(P, ldp, QZ, ldqz, RR, ldrr, a_att, rowptr, col, etype, items, splits, counts, n_items_max,
+                                       n_splits_max, n_parts_max, N, d, slope, loop_rel, out_scale, out, ldo, seg_max, seg_den, ws,
+                                       ws_bytes, stream);
 }
 
 // ---- backward workspace carving (shared by the size query and the launcher) ----

@@ -86,6 +86,20 @@ __device__ __forceinline__ float4 ld4_nt(const float* p) {
     const jmac_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const jmac_f32x4*>(p));
     return make_float4(v.x, v.y, v.z, v.w);
 }
+// ---- table element types: float, or bf16 stored as uint16_t (inference tables; arithmetic stays fp32) -------
+// A lane's chunk is 4 consecutive elements either way: 16 B of fp32 or 8 B of bf16, so both table types share one
+// lane -> element map.  Gathered chunks stay in their raw form (4 or 2 VGPRs) until the arithmetic needs them.
+typedef uint16_t bf16_t;
+__device__ __forceinline__ float4 ldraw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ uint2 ldraw(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ float4 cvt4(float4 r) { return r; }
+__device__ __forceinline__ float4 cvt4(uint2 r) {   // bf16 -> fp32 is a 16-bit shift: exact
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+}
+template <typename TT> struct RawOf { typedef float4 type; };
+template <> struct RawOf<bf16_t> { typedef uint2 type; };
+
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 

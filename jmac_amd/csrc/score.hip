@@ -32,8 +32,14 @@ __device__ __forceinline__ float add_absdiff(float acc, float a, float b) {
     return r;
 }
 
-__global__ __launch_bounds__(kBlock) void l1_score_kernel(const float* __restrict__ er, int64_t lder,
-                                                          const float* __restrict__ tab, int64_t ldt, int B, int N, int d,
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((uint32_t)(*p) << 16); }
+
+// TT = float or bf16_t (raw bits): bf16 operands are widened when they are staged into LDS, the |a-b| accumulation
+// is fp32 either way (the kernel is VALU-bound, so the narrower tables change the bytes, not the time)
+template <typename TT>
+__global__ __launch_bounds__(kBlock) void l1_score_kernel(const TT* __restrict__ er, int64_t lder,
+                                                          const TT* __restrict__ tab, int64_t ldt, int B, int N, int d,
                                                           float* __restrict__ out, int64_t ldout, int accumulate) {
     __shared__ __attribute__((aligned(16))) float As[2][L1_K][L1_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][L1_K][L1_LD];
@@ -49,16 +55,16 @@ __global__ __launch_bounds__(kBlock) void l1_score_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
-    auto gload = [&](const float* base, int64_t ld, int64_t row, int64_t nrows, int k0) -> float4 {
+    auto gload = [&](const TT* base, int64_t ld, int64_t row, int64_t nrows, int k0) -> float4 {
         float4 v = f4zero();
         if (row < nrows) {
             const int k = k0 + lk;
-            if (k + 3 < d) v = ld4(base + row * ld + k);
+            if (k + 3 < d) v = cvt4(ldraw(base + row * ld + k));
             else {
-                const float* p = base + row * ld;
-                if (k + 0 < d) v.x = p[k + 0];
-                if (k + 1 < d) v.y = p[k + 1];
-                if (k + 2 < d) v.z = p[k + 2];
+                const TT* p = base + row * ld;
+                if (k + 0 < d) v.x = ld1(p + k + 0);
+                if (k + 1 < d) v.y = ld1(p + k + 1);
+                if (k + 2 < d) v.z = ld1(p + k + 2);
             }
         }
         return v;
@@ -406,8 +412,21 @@ int jmac_l1_score_f32(const float* er, int64_t lder, const float* table, int64_t
     if (lder % 4 || ldt % 4) return JMAC_EDIM;
     if (B >= INT32_MAX || N >= INT32_MAX) return JMAC_ERANGE;
     dim3 grid((unsigned)((N + L1_T - 1) / L1_T), (unsigned)((B + L1_T - 1) / L1_T));
-    hipLaunchKernelGGL(l1_score_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, er, lder, table, ldt, (int)B, (int)N, (int)d,
+    hipLaunchKernelGGL(l1_score_kernel<float>, grid, dim3(kBlock), 0, (hipStream_t)stream, er, lder, table, ldt, (int)B, (int)N, (int)d,
                        out, ldout, accumulate);
+    return (int)hipGetLastError();
+}
+
+int jmac_l1_score_bf16(const uint16_t* er, int64_t lder, const uint16_t* table, int64_t ldt, int64_t B, int64_t N, int64_t d,
+                       float* out, int64_t ldout, int32_t accumulate, jmac_stream_t stream) {
+    if (B < 0 || N < 0 || d <= 0) return JMAC_EINVAL;
+    if (B == 0 || N == 0) return JMAC_OK;
+    if (!er || !table || !out) return JMAC_EINVAL;
+    if (lder % 4 || ldt % 4) return JMAC_EDIM;
+    if (B >= INT32_MAX || N >= INT32_MAX) return JMAC_ERANGE;
+    dim3 grid((unsigned)((N + L1_T - 1) / L1_T), (unsigned)((B + L1_T - 1) / L1_T));
+    hipLaunchKernelGGL(l1_score_kernel<bf16_t>, grid, dim3(kBlock), 0, (hipStream_t)stream, er, lder, table, ldt, (int)B, (int)N,
+                       (int)d, out, ldout, accumulate);
     return (int)hipGetLastError();
 }
 

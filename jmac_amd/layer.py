@@ -53,6 +53,9 @@ class RelationAwareLayer(nn.Module):
         self.in_channels, self.out_channels = in_channels, out_channels
         self.bwd_mode = ops.BWD_MODE_DETERMINISTIC
         self.chunk = DEFAULT_CHUNK
+        # torch.bfloat16: inference form -- the [P|Q|Z] / [Rq|Rz] tables are produced by bf16 GEMMs and gathered as
+        # bf16 (half the bytes of the HBM-bound kernel); logits, softmax, sums, BN stay fp32.  Needs no_grad.
+        self.table_dtype = torch.float32
 
     # -- pieces ---------------------------------------------------------------------------------
     def transform_relations(self, rel_emb):
@@ -71,9 +74,13 @@ class RelationAwareLayer(nn.Module):
             pad = lambda w: F.pad(w, (0, dp - d))
             wt, wb, wg, a = pad(wt), pad(wb), pad(wg), F.pad(a, (0, dp - d))
         wcat = torch.cat([wt, wb, wg], dim=1)                             # [d_in, 3dp]
+        if self.table_dtype == torch.bfloat16:
+            if torch.is_grad_enabled() and (ent_emb.requires_grad or wcat.requires_grad):
+                raise RuntimeError("table_dtype=bfloat16 is the inference form of the layer: call it under torch.no_grad()")
+            wcat, ent_emb, rel = wcat.to(torch.bfloat16), ent_emb.to(torch.bfloat16), rel.to(torch.bfloat16)
         PQZ = torch.mm(ent_emb, wcat)                                     # [N, 3dp]
         RR = torch.mm(rel, wcat[:, dp:])                                  # [nr+1, 2dp]
-        return PQZ, RR, a, dp
+        return PQZ, RR, a.float(), dp
 
     def pre_bn(self, ent_emb, rel_emb, edge_index, edge_type):
         """(message_neighbors + message_self) / 2 of src/jmac_model.py:49-52."""

@@ -54,6 +54,15 @@ class JMAC(nn.Module):
         self.all_linear_completion = get_param((d * (L + 1), d))
         self.forward_base = self.forward_no_name if args.no_name_info else self.forward_name   # :166-169
 
+    def set_table_dtype(self, dtype) -> None:
+        """torch.bfloat16: inference form (BASELINE config 3) -- the three layers gather bf16 [P|Q|Z] / [Rq|Rz]
+        tables and forward_linkpred scores bf16 entity tables; arithmetic stays fp32.  torch.float32: default."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("table dtype must be float32 or bfloat16")
+        self.table_dtype = dtype
+        for lay in (self.conv1_alignment, self.conv2_alignment, self.conv1_completion):
+            lay.table_dtype = dtype
+
     # ---- encoders -------------------------------------------------------------------------------
     def _rel_mlp(self, r, w1, w2):
         return torch.mm(self.atv_mlp(torch.mm(r, w1)), w2)
@@ -119,7 +128,7 @@ class JMAC(nn.Module):
             comp_layers = [c.index_select(0, ai) for c in comp_layers]
         layers = range(self.args.num_gcn_layer)
         return scoring.linkpred_dist([comp_layers[l] for l in layers], [comp_rel_layers[l] for l in layers],
-                                     e_index, r_index, pred_head)
+                                     e_index, r_index, pred_head, table_dtype=getattr(self, "table_dtype", torch.float32))
 
     # ---- losses (src/jmac_model.py:237-292, :316-380): gathers + L1 / cosine fused in HIP (jmac_amd.losses),
     # the margin arithmetic on the resulting [T] / [L] vectors stays in torch ----------------------------

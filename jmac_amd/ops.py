@@ -37,6 +37,21 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def _table(t: torch.Tensor) -> torch.Tensor:
+    """Gathered tables: fp32, or bf16 for the inference form (arithmetic and outputs stay fp32)."""
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("jmac_amd tables are fp32 or bf16 (got %s)" % t.dtype)
+    return t
+
+
+def L_fwd_f32():
+    return lib().jmac_rel_attn_aggregate_fwd_f32
+
+
+def L_fwd_bf16():
+    return lib().jmac_rel_attn_aggregate_fwd_bf16
+
+
 class _RelAttnAggregate(torch.autograd.Function):
     """out = out_scale * ( sqrt(deg) * softmax-weighted sum over in-edges of (Z[j]-Rz[t]) + [Z[i]-Rz[loop]] ).
 
@@ -46,7 +61,11 @@ class _RelAttnAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, PQZ, RR, a, graph: RelGraph, slope: float, loop_rel: int, out_scale: float, bwd_mode: int):
         require_device(PQZ, RR, a)
-        PQZ, RR, a = _f32c(PQZ).contiguous(), _f32c(RR).contiguous(), _f32c(a).contiguous()
+        PQZ, RR, a = _table(PQZ).contiguous(), _table(RR).contiguous(), _f32c(a).contiguous()
+        if PQZ.dtype != RR.dtype:
+            raise TypeError("PQZ and RR must share a dtype")
+        bf16 = PQZ.dtype == torch.bfloat16
+        fwd = L_fwd_bf16 if bf16 else L_fwd_f32
         N, d3 = PQZ.shape
         d = d3 // 3
         if graph.N != N:
@@ -61,13 +80,17 @@ class _RelAttnAggregate(torch.autograd.Function):
         ws = _ws(ws_bytes, dev)
         esz = PQZ.element_size()
         ev0 = _ev() if PROFILE is not None else None
-        check(L.jmac_rel_attn_aggregate_fwd_f32(
+        check(fwd()(
             ptr(PQZ), d3, PQZ.data_ptr() + d * esz, d3, ptr(RR), RR.shape[1], ptr(a),
             ptr(graph.rowptr), ptr(graph.col), ptr(graph.etype), ptr(s.items), ptr(s.splits), ptr(s.counts),
             s.n_items_max, s.n_splits_max, s.n_parts_max, N, d, float(slope), int(loop_rel), float(out_scale),
-            ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(ws), ws_bytes, stream()), "jmac_rel_attn_aggregate_fwd_f32")
+            ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(ws), ws_bytes, stream()),
+            "jmac_rel_attn_aggregate_fwd_%s" % ("bf16" if bf16 else "f32"))
         if ev0 is not None:
-            PROFILE.append(("rel_attn_fwd", ev0, _ev()))
+            PROFILE.append(("rel_attn_fwd_bf16" if bf16 else "rel_attn_fwd", ev0, _ev()))
+        if bf16:
+            ctx.mark_non_differentiable(out)
+            return out
         ctx.save_for_backward(PQZ, RR, a, out, seg_max, seg_den)
         ctx.graph, ctx.slope, ctx.loop_rel, ctx.out_scale, ctx.bwd_mode = graph, slope, loop_rel, out_scale, bwd_mode
         return out
@@ -113,6 +136,8 @@ class _RelAttnAggregate(torch.autograd.Function):
 def rel_attn_aggregate(PQZ: torch.Tensor, RR: torch.Tensor, a: torch.Tensor, graph: RelGraph, slope: float,
                        loop_rel: int = -1, out_scale: float = 1.0,
                        bwd_mode: int = BWD_MODE_DETERMINISTIC) -> torch.Tensor:
+    if PQZ.dtype == torch.bfloat16 and torch.is_grad_enabled() and (PQZ.requires_grad or RR.requires_grad or a.requires_grad):
+        raise RuntimeError("bf16 tables are the inference form of the op (no backward): run under torch.no_grad()")
     return _RelAttnAggregate.apply(PQZ, RR, a, graph, float(slope), int(loop_rel), float(out_scale), int(bwd_mode))
 
 

@@ -17,10 +17,11 @@ import torch
 from ._lib import check, lib, ptr, require_device, stream
 
 
-def _rows16(t: torch.Tensor) -> torch.Tensor:
-    """fp32, contiguous, row length padded to a multiple of 4 (16-byte rows) with zeros."""
-    if t.dtype != torch.float32:
-        raise TypeError("fp32 only")
+def _rows16(t: torch.Tensor, allow_bf16: bool = False) -> torch.Tensor:
+    """fp32 (or bf16 where the kernel has a bf16-table form), contiguous, row length padded to a multiple of 4
+    elements with zeros (16-byte fp32 rows / 8-byte bf16 rows)."""
+    if t.dtype != torch.float32 and not (allow_bf16 and t.dtype == torch.bfloat16):
+        raise TypeError("fp32%s only (got %s)" % (" / bf16" if allow_bf16 else "", t.dtype))
     d = t.shape[1]
     if d % 4:
         t = torch.nn.functional.pad(t, (0, 4 - d % 4))
@@ -29,20 +30,28 @@ def _rows16(t: torch.Tensor) -> torch.Tensor:
 
 def l1_scores(er: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] = None,
               accumulate: bool = False) -> torch.Tensor:
+    """``torch.cdist(er, table, p=1)`` -> fp32 [B, N].  A bf16 ``table`` selects the bf16-operand kernel
+    (``er`` is rounded to bf16 to match; the accumulation stays fp32) -- BASELINE config 3."""
     require_device(er, table)
-    er, table = _rows16(er), _rows16(table)       # zero padding adds |0-0| = 0
+    bf16 = table.dtype == torch.bfloat16
+    if bf16 and er.dtype != torch.bfloat16:
+        er = er.to(torch.bfloat16)
+    er, table = _rows16(er, bf16), _rows16(table, bf16)       # zero padding adds |0-0| = 0
     B, d = er.shape
     N = table.shape[0]
     if out is None:
         out = torch.empty((B, N), dtype=torch.float32, device=er.device)
         accumulate = False
-    check(lib().jmac_l1_score_f32(ptr(er), er.shape[1], ptr(table), table.shape[1], B, N, d, ptr(out), out.stride(0),
-                                  1 if accumulate else 0, stream()), "jmac_l1_score_f32")
+    fn, name = (lib().jmac_l1_score_bf16, "jmac_l1_score_bf16") if bf16 else (lib().jmac_l1_score_f32, "jmac_l1_score_f32")
+    check(fn(ptr(er), er.shape[1], ptr(table), table.shape[1], B, N, d, ptr(out), out.stride(0),
+             1 if accumulate else 0, stream()), name)
     return out
 
 
 def linkpred_dist(comp_layers: Sequence[torch.Tensor], comp_rel_layers: Sequence[torch.Tensor], e_index, r_index,
-                  pred_head: bool = False) -> torch.Tensor:
+                  pred_head: bool = False, table_dtype=torch.float32) -> torch.Tensor:
+    """sum over layers of cdist(E_l[h] +/- R_l[r], E_l, p=1) (src/jmac_model.py:302-313).  table_dtype=bfloat16
+    rounds the query rows and the candidate table to bf16 (fp32 accumulation) -- BASELINE config 3."""
     dev = comp_layers[0].device
     e_index = torch.as_tensor(e_index, dtype=torch.long, device=dev)
     r_index = torch.as_tensor(r_index, dtype=torch.long, device=dev)
@@ -50,6 +59,8 @@ def linkpred_dist(comp_layers: Sequence[torch.Tensor], comp_rel_layers: Sequence
     for ent, rel in zip(comp_layers, comp_rel_layers):
         e, r = ent[e_index], rel[r_index]
         er = e - r if pred_head else e + r                               # jmac_model.py:308-311
+        if table_dtype == torch.bfloat16:
+            er, ent = er.to(torch.bfloat16), ent.to(torch.bfloat16)
         dist = l1_scores(er, ent, out=dist, accumulate=dist is not None)
     return dist
 

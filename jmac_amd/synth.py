@@ -32,6 +32,20 @@ def dbp5l_like(lang: str = "ja", seed: int = 1234, bidirectional: bool = False):
     return np.stack([dst, src]).astype(np.int64), typ.astype(np.int64), n, NUM_REL
 
 
+def dbp5l_union(seed: int = 1234, bidirectional: bool = False):
+    """Config 3: block-diagonal union of the five DBP-5L-shaped KGs with the reference's id offsets
+    (entity_id_base / relation_id_base, src/data_loader.py:162-181): N = 56 589, 5 x 961 relation rows (+1 loop row
+    added by the layer).  Returns (edge_index, edge_type, N, nr, ent_bases, rel_bases)."""
+    eis, ets, ent_bases, rel_bases = [], [], [0], [0]
+    for k, lang in enumerate(("el", "en", "es", "fr", "ja")):
+        ei, et, n, nr = dbp5l_like(lang, seed + k, bidirectional)
+        eis.append(ei + ent_bases[-1])
+        ets.append(et + rel_bases[-1])
+        ent_bases.append(ent_bases[-1] + n)
+        rel_bases.append(rel_bases[-1] + nr)
+    return np.concatenate(eis, axis=1), np.concatenate(ets), ent_bases[-1], rel_bases[-1], ent_bases, rel_bases
+
+
 def power_law_graph(n: int, e: int, nr: int, seed: int = 1234, alpha: float = 2.1, max_deg: int = 100_000):
     """Config 4: destinations Zipf-like (exponent ~alpha, truncated), sources uniform, types Zipf over nr."""
     rng = np.random.default_rng(seed)
@@ -53,8 +67,9 @@ def power_law_graph(n: int, e: int, nr: int, seed: int = 1234, alpha: float = 2.
 
 def fwd_algorithmic_bytes(n: int, e: int, d: int, elem: int = 4) -> int:
     """E*(2*d*s + 8) + N*(2*d*s + 12): per edge the [Q|Z] row + col + type; per node
-    the P row in, the output row out, rowptr + max/den.  Relation rows (L2-resident) are excluded."""
-    return e * (2 * d * elem + 8) + n * (2 * d * elem + 12)
+    the P row in, the output row out, rowptr + max/den.  Relation rows (L2-resident) are excluded.
+    With bf16 tables (elem=2) the output row stays fp32: N*(d*2 + d*4 + 12)."""
+    return e * (2 * d * elem + 8) + n * (d * elem + d * 4 + 12)
 
 
 def bwd_algorithmic_bytes(n: int, e: int, d: int, elem: int = 4) -> int:

@@ -431,6 +431,25 @@ def factorised_pre_bn(p: Dict[str, Tensor], ent_emb: Tensor, rel_emb: Tensor, ed
     return (nb + Z - Rz[-1]) / 2
 
 
+def aggregate_from_tables(PQZ: Tensor, RR: Tensor, a: Tensor, edge_index: Tensor, edge_type: Tensor, slope: float,
+                          loop_rel: int = -1, out_scale: float = 1.0) -> Tensor:
+    """The factorised aggregation (factorised_pre_bn above; message_passing.py:4-29 + jmac_model.py:56-89 after
+    hoisting the per-edge GEMMs) on GIVEN tables PQZ [N,3d] = P|Q|Z and RR [nr,2d] = Rq|Rz, in their dtype.
+    Used to check the bf16-table kernel: pass the bf16-rounded tables widened to float64."""
+    n, d = PQZ.shape[0], PQZ.shape[1] // 3
+    P, Q, Z = PQZ[:, :d], PQZ[:, d:2 * d], PQZ[:, 2 * d:]
+    Rq, Rz = RR[:, :d], RR[:, d:]
+    dst, src = edge_index[0], edge_index[1]
+    h = P[dst] + Q[src] - Rq[edge_type]
+    s = F.leaky_relu(h, slope) @ a.reshape(-1, 1).to(h.dtype)
+    alpha = scatter_softmax(s, dst, n)
+    deg = scatter_sum(torch.ones(dst.shape[0], dtype=h.dtype), dst, n)
+    out = scatter_sum(alpha * (Z[src] - Rz[edge_type]), dst, n) * deg.sqrt().view(-1, 1)
+    if loop_rel >= 0:
+        out = out + Z - Rz[loop_rel]
+    return out * out_scale
+
+
 # --------------------------------------------------------------------------------------------
 # Alignment evaluation (next row f1): modules/finding/similarity.py:13-84, alignment.py:10-112
 # --------------------------------------------------------------------------------------------

@@ -127,3 +127,59 @@ def test_fullsize_scoring_properties():
     idx, val = scoring.sim_topk(a, a, 25, return_values=True)
     assert bool((idx[:, 0] == torch.arange(3000, device=dev)).all())                # self is the most similar
     assert bool((val[:, :-1] >= val[:, 1:]).all())                                  # sorted descending
+
+
+def test_config3_union_graph_bf16_encoder_and_scoring():
+    """BASELINE configs[2]: the block-diagonal union of the five DBP-5L-shaped KGs (N=56 589, 5x961 relations),
+    bf16 tables, completion scoring of B=1000 queries against ALL 56 589 entities over 2 layers.
+      * encoder: bf16-table aggregation at full size obeys the softmax-normalisation property exactly like fp32,
+        and block-diagonality: a KG's rows do not change when the other four KGs' tables are perturbed;
+      * scoring: bf16 distances = fp32-accumulated |a-b| of the rounded rows (checked on a slice against float64),
+        d(x,x) = 0, and the filtered ranks agree with the fp32 path except where bf16 rounding reorders near-ties
+        (Hits@10 sets within 2 %)."""
+    from jmac_amd import ops, scoring, synth
+    from jmac_amd.graph import RelGraph
+    dev = torch.device("cuda")
+    d = 300
+    ei, et, n, nr, ent_bases, rel_bases = synth.dbp5l_union(1234)
+    assert n == 56589 and nr == 5 * 961
+    g = RelGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(et).to(dev), n, nr + 1)
+    PQZ, RR, a = _tables(n, nr + 1, d, 2, dev)
+    deg = torch.from_numpy(np.bincount(ei[0], minlength=n)).to(dev)
+    Pb, Rb = PQZ.to(torch.bfloat16), RR.to(torch.bfloat16)
+    with torch.no_grad():
+        P1, R1 = Pb.clone(), Rb.clone()
+        P1[:, 2 * d:] = 1.0
+        R1[:, d:] = 0.0
+        nb = ops.rel_attn_aggregate(P1, R1, a, g, 0.05, -1, 1.0)
+        want = deg.float().sqrt().view(-1, 1).expand(n, d)
+        assert (nb - want).abs().max().item() <= 2e-4 * max(1.0, float(want.max()))
+        out = ops.rel_attn_aggregate(Pb, Rb, a, g, 0.05, nr, 0.5)
+        P2 = Pb.clone()
+        P2[: ent_bases[4]] = (torch.randn(ent_bases[4], 3 * d, device=dev) * 0.3).to(torch.bfloat16)   # perturb el..fr
+        out2 = ops.rel_attn_aggregate(P2, Rb, a, g, 0.05, nr, 0.5)
+        assert torch.equal(out[ent_bases[4]:], out2[ent_bases[4]:])           # ja rows are untouched, bitwise
+    # ---- scoring over all entities, 2 layers
+    gen = torch.Generator(device=dev).manual_seed(0)
+    comp = [torch.randn(n, d, device=dev, generator=gen) * 0.1, out]
+    rel = [torch.randn(nr, d, device=dev, generator=gen) * 0.02 for _ in range(2)]
+    B = 1000
+    hb = torch.randint(0, n, (B,), device=dev, generator=gen)
+    rb = torch.randint(0, nr, (B,), device=dev, generator=gen)
+    gold = torch.randint(0, n, (B,), device=dev, generator=gen)
+    d32 = scoring.linkpred_dist(comp, rel, hb, rb)
+    d16 = scoring.linkpred_dist(comp, rel, hb, rb, table_dtype=torch.bfloat16)
+    assert d16.shape == (B, n) and d16.dtype == torch.float32
+    ref = 0
+    for c, r in zip(comp, rel):
+        er = (c[hb[:16]] + r[rb[:16]]).to(torch.bfloat16).double().cpu()
+        ref = ref + torch.cdist(er, c[:4096].to(torch.bfloat16).double().cpu(), p=1)
+    assert (d16[:16, :4096].double().cpu() - ref).abs().max().item() <= 1e-5 * float(ref.max())
+    assert (d16 - d32).abs().max().item() <= 1e-2 * float(d32.max())         # 2^-9 per element, random signs
+    r32, r16 = scoring.filtered_rank(d32, gold), scoring.filtered_rank(d16, gold)
+    top32 = torch.topk(-d32, 10, dim=1).indices
+    top16 = torch.topk(-d16, 10, dim=1).indices
+    overlap = (top32.unsqueeze(2) == top16.unsqueeze(1)).any(2).float().mean().item()
+    assert overlap >= 0.98
+    rel_rank_diff = ((r32 - r16).abs().float() / r32.float().clamp(min=1)).mean().item()
+    assert rel_rank_diff < 0.02
