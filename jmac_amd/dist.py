@@ -243,3 +243,116 @@ class ShardedRelationAwareLayer(nn.Module):
         nb = self.local_aggregate(P.contiguous(), QZ, RR, a, sg, L.atv_mlp.negative_slope)
         pre = (nb + Z_loc - RR[-1, d:]) * 0.5                        # self loop: softmax over a singleton
         return L.layer_act(sync_batch_norm(pre, sg.n_global, L.bn, self.group))
+
+
+# ------------------------------------------------------------------------------------------------
+# query-sharded scoring (SURVEY.md section 8e "Scoring"; BASELINE config 5: OpenEA 15K alignment on 2 GPUs)
+# ------------------------------------------------------------------------------------------------
+# Rows of the score matrix (queries) are split over ranks, the candidate table is replicated: top-k and ranks are
+# row-local, so get_neg needs only a gather of the [L_r, k] index slabs.  CSLS is the one real exchange: its column
+# term r2[j] = mean of the k largest entries of COLUMN j runs over all ranks' rows, so each rank's per-column top-k
+# candidates ([N2, k] values) are all-gathered and merged before the row-local rescoring and rank count.
+class _HipScoring:
+    """The product's local kernels (jmac_amd.scoring); tests inject a torch stand-in under gloo."""
+
+    @staticmethod
+    def sim_topk(a, b, k):
+        from . import scoring
+        return scoring.sim_topk(a, b, k)
+
+    @staticmethod
+    def sim_matrix(a, b):
+        from . import scoring
+        return scoring.sim_matrix(a, b)
+
+    @staticmethod
+    def row_topk_values(s, k):
+        from . import scoring
+        return scoring.row_topk(s, k)[0]
+
+    @staticmethod
+    def rank_of_gold(s, gold):
+        """1-based rank of column gold[i] in row i of s, descending, ties -> lower index first."""
+        from . import scoring
+        return scoring.filtered_rank(-s, gold.to(torch.int32)).to(torch.int64)
+
+
+def shard_rows(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous even split of n query rows: ranks [0, n % world) get one extra row."""
+    base, extra = divmod(int(n), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _rank(group=None) -> int:
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def _all_gather_padded(x: torch.Tensor, n_max: int, group=None) -> torch.Tensor:
+    """x [n_r, ...] -> [world, n_max, ...] (rows past n_r are zero)."""
+    world = _world(group)
+    if x.shape[0] < n_max:
+        x = torch.cat([x, x.new_zeros((n_max - x.shape[0],) + tuple(x.shape[1:]))], 0)
+    x = x.contiguous()
+    if _skip(group):
+        return x.unsqueeze(0)
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    if x.is_cuda and dist.get_backend(group) == "gloo":               # tests only: stage through the host
+        h = torch.empty(out.shape, dtype=x.dtype)
+        dist.all_gather_into_tensor(h, x.cpu(), group=group)
+        out.copy_(h)
+    else:
+        dist.all_gather_into_tensor(out, x, group=group)
+    return out.view((world,) + tuple(x.shape))
+
+
+def sharded_get_neg(ILL, emb_src: torch.Tensor, emb_dst: torch.Tensor, k: int, group=None, kernels=None) -> torch.Tensor:
+    """get_neg (modules/utils/util.py:31-54; DBPv1: JMAC_DBPv1/modules/utils/util.py:35-58) with the seed rows split
+    over ranks: each rank scores its slice of ILL against ALL of emb_dst (MFMA sim + top-k), the [L_r, k] index slabs
+    are gathered.  Every rank returns the full flattened [L*k] int64 result, identical to the one-rank call."""
+    kn = kernels or _HipScoring
+    world, rank = _world(group), _rank(group)
+    ill = torch.as_tensor(ILL, dtype=torch.long, device=emb_src.device).reshape(-1)
+    L = int(ill.numel())
+    lo, hi = shard_rows(L, world, rank)
+    idx = kn.sim_topk(emb_src.index_select(0, ill[lo:hi]), emb_dst, k) if hi > lo else \
+        torch.zeros((0, k), dtype=torch.int64, device=emb_src.device)
+    n_max = shard_rows(L, world, 0)[1]
+    slabs = _all_gather_padded(idx.to(torch.int64), n_max, group)     # [world, n_max, k]
+    parts = [slabs[r, : shard_rows(L, world, r)[1] - shard_rows(L, world, r)[0]] for r in range(world)]
+    return torch.cat(parts, 0).reshape(-1)
+
+
+def sharded_alignment_test(embeds1: torch.Tensor, embeds2: torch.Tensor, top_k=(1, 5, 10), csls_k: int = 10, group=None,
+                           kernels=None):
+    """modules/finding/evaluation.py:20-28 -> alignment.py:10-112 (metric='cosine', accurate=True, CSLS csls_k) with
+    the rows of the similarity matrix split over ranks.  Row i of embeds1 is aligned with row i of embeds2; both tables
+    are replicated.  Returns (top_k, hits [%], mr, mrr), identical on every rank and to scoring.alignment_test."""
+    kn = kernels or _HipScoring
+    world, rank = _world(group), _rank(group)
+    n1, n2 = embeds1.shape[0], embeds2.shape[0]
+    lo, hi = shard_rows(n1, world, rank)
+    e1 = F.normalize(embeds1[lo:hi], 2, -1)
+    e2 = F.normalize(embeds2, 2, -1)
+    s = kn.sim_matrix(e1, e2)                                         # [n_r, n2] row block of the score matrix
+    if csls_k > 0:
+        r1 = kn.row_topk_values(s, csls_k).mean(1)                    # row term: local
+        kk = min(csls_k, max(hi - lo, 1))
+        if hi > lo:
+            colv = kn.row_topk_values(s.t().contiguous(), kk)         # [n2, kk]: this rank's candidates per column
+        else:
+            colv = s.new_full((n2, kk), float("-inf"))
+        if kk < csls_k:
+            colv = torch.cat([colv, colv.new_full((n2, csls_k - kk), float("-inf"))], 1)
+        allv = _all_gather_padded(colv, n2, group)                    # [world, n2, csls_k]
+        merged = allv.permute(1, 0, 2).reshape(n2, -1)
+        r2 = merged.topk(csls_k, dim=1).values.mean(1)                # k largest over all ranks' rows
+        s = 2 * s - r1.view(-1, 1) - r2.view(1, -1)
+    gold = torch.arange(lo, hi, device=s.device)
+    rk = kn.rank_of_gold(s, gold).to(torch.float64) if hi > lo else torch.zeros(0, dtype=torch.float64, device=s.device)
+    stats = torch.stack([(rk <= k).double().sum() for k in top_k] + [rk.sum(), (1.0 / rk).sum()])
+    if not _skip(group):
+        _all_reduce(stats, group)
+    stats = stats / n1
+    hits = [round(float(h) * 100.0, 3) for h in stats[: len(top_k)]]
+    return list(top_k), hits, float(stats[-2]), float(stats[-1])

@@ -24,7 +24,11 @@ PQZ = (torch.randn(n, 3 * d, device=dev, generator=gen) * 0.3).requires_grad_(Tr
 RR = (torch.randn(nrel, 2 * d, device=dev, generator=gen) * 0.3).requires_grad_(True)
 a = (torch.randn(d, device=dev, generator=gen) * 0.1).requires_grad_(True)
 G = torch.randn(n, d, device=dev, generator=gen)
-fb = synth.fwd_algorithmic_bytes(n, e, d)
+bf16 = bool(os.environ.get("BF16"))
+if bf16:
+    PQZ, RR = PQZ.detach().to(torch.bfloat16), RR.detach().to(torch.bfloat16)
+    do_bwd = 0
+fb = synth.fwd_algorithmic_bytes(n, e, d, 2 if bf16 else 4)
 with torch.no_grad():
     for _ in range(2): ops.rel_attn_aggregate(PQZ, RR, a, g, 0.05, nrel - 1, 0.5, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -32,7 +36,7 @@ with torch.no_grad():
     for _ in range(5): ops.rel_attn_aggregate(PQZ, RR, a, g, 0.05, nrel - 1, 0.5, 1)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
-print(dbg, "GRID=%s U=%s chunk=%s items=%d splits=%d  fwd %.3f ms  %.0f GB/s (%.1f%% of 8TB/s)" % (os.environ.get("JMAC_GRID"), os.environ.get("JMAC_FWD_U"), g.chunk, g.by_dst.n_items_max, g.by_dst.n_splits_max, ms, fb / ms / 1e6, fb / ms / 1e6 / 80))
+print("bf16" if bf16 else "f32", dbg, "GRID=%s U=%s chunk=%s items=%d splits=%d  fwd %.3f ms  %.0f GB/s (%.1f%% of 8TB/s)" % (os.environ.get("JMAC_GRID"), os.environ.get("JMAC_FWD_U"), g.chunk, g.by_dst.n_items_max, g.by_dst.n_splits_max, ms, fb / ms / 1e6, fb / ms / 1e6 / 80))
 if do_bwd:
     g.ensure_backward_views()
     out = ops.rel_attn_aggregate(PQZ, RR, a, g, 0.05, nrel - 1, 0.5, 1)

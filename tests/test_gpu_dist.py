@@ -131,3 +131,50 @@ def test_rccl_entry_points_world1():
     assert_close(ret[0]["out"], ref, 1e-4, 1e-6, "out")
     assert_close(ret[0]["gx"], Xc.grad, 1e-4, 1e-6, "grad_X")
     assert_close(ret[0]["gw"], p["w_att"].grad, 1e-4, 1e-6, "grad w_att")
+
+
+# ---- config 5 (OpenEA 15K shape, alignment only, 2 ranks): query-sharded scoring on the HIP kernels ------------
+def _align_case():
+    gen = torch.Generator().manual_seed(21)
+    n, d = 10500, 300                                   # the 70 % test split of 15K links; N = 30 000 entity table
+    base = torch.randn(n, d, generator=gen)
+    e1 = base + 0.9 * torch.randn(n, d, generator=gen)
+    e2 = base + 0.9 * torch.randn(n, d, generator=gen)
+    table = torch.nn.functional.normalize(torch.randn(30000, d, generator=gen), 2, -1)
+    ill = torch.randperm(30000, generator=gen)[:3000]
+    return e1, e2, table, ill
+
+
+def _score_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from jmac_amd.dist import sharded_alignment_test, sharded_get_neg
+        dev = torch.device("cuda", 0)
+        e1, e2, table, ill = _align_case()
+        neg = sharded_get_neg(ill.tolist(), table.to(dev), table.to(dev), 25)      # DBPv1 get_neg: one table, k = 25
+        res = sharded_alignment_test(e1.to(dev), e2.to(dev), (1, 5, 10), csls_k=10)
+        torch.cuda.synchronize()
+        ret[rank] = (neg.cpu(), res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_scoring_two_ranks_config5_shape():
+    from jmac_amd import scoring
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    mp.spawn(_score_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    e1, e2, table, ill = _align_case()
+    dev = torch.device("cuda", 0)
+    want_neg = scoring.get_neg(ill.tolist(), table.to(dev), table.to(dev), 25).cpu()
+    want = scoring.alignment_test(e1.to(dev), e2.to(dev), (1, 5, 10), csls_k=10)
+    assert bool((want_neg.view(-1, 25)[:, 0] == ill).all())          # a row's nearest neighbour in its own table is itself
+    for r in range(world):
+        neg, res = ret[r]
+        assert torch.equal(neg, want_neg)                            # index work: bit-exact against the one-rank path
+        assert res[0] == want[0] and res[1] == want[1]
+        assert abs(res[2] - want[2]) < 1e-9 and abs(res[3] - want[3]) < 1e-12
+    assert want[1][0] > 50.0                                         # the planted alignment is recovered
