@@ -451,6 +451,31 @@ def aggregate_from_tables(PQZ: Tensor, RR: Tensor, a: Tensor, edge_index: Tensor
 
 
 # --------------------------------------------------------------------------------------------
+# EnTr bookkeeping (next row f4): train.py:297-325
+# --------------------------------------------------------------------------------------------
+def transfer_knowledge(triples_src, triples_dst, pairs, keys1: set, keys2: set):
+    """transfer_knowledge, train.py:297-325, with the dict of train.py:202 built from the [L,2] pair list.
+    Loop restatement (small cases only).  keys*: sets of (h, r, t) tuples, updated in place like the reference's
+    string sets.  `links.get(x)` is tested for truthiness: a missing entry and a mapped id of 0 both fail."""
+    links = {int(a): int(b) for a, b in pairs}
+    inverse = {v: k for k, v in links.items()}
+    add_src, add_dst = [], []
+    for h, r, t in triples_src:
+        if links.get(int(h)) and links.get(int(t)):
+            key = (links[int(h)], int(r), links[int(t)])
+            if key not in keys2:
+                keys2.add(key)
+                add_dst.append(key)
+    for h, r, t in triples_dst:
+        if inverse.get(int(h)) and inverse.get(int(t)):
+            key = (inverse[int(h)], int(r), inverse[int(t)])
+            if key not in keys1:
+                keys1.add(key)
+                add_src.append(key)
+    return [tuple(int(v) for v in x) for x in triples_src] + add_src, [tuple(int(v) for v in x) for x in triples_dst] + add_dst
+
+
+# --------------------------------------------------------------------------------------------
 # Alignment evaluation (next row f1): modules/finding/similarity.py:13-84, alignment.py:10-112
 # --------------------------------------------------------------------------------------------
 def csls_sim(sim: Tensor, k: int) -> Tensor:

@@ -330,6 +330,65 @@ def gen_aligneval():
     _save("align_eval", **out)
 
 
+def _load_ref_train():
+    """train.py cannot be imported (syntax error at :101): read, repair that line in memory, exec (accommodation 3)."""
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd(); os.chdir(tmp)
+    try:
+        src = open(os.path.join(REF, "train.py")).read().split("\n")
+        assert "--no_name_info, action" in src[100]
+        src[100] = src[100].replace("'--no_name_info, action", "'--no_name_info', action")
+        train_mod = types.ModuleType("ref_train")
+        train_mod.__dict__["__name__"] = "ref_train"
+        exec(compile("\n".join(src), "train.py", "exec"), train_mod.__dict__)
+    finally:
+        os.chdir(cwd)
+    return train_mod
+
+
+def gen_entr():
+    """EnTr bookkeeping (row f4): train.py:138-211 seed_enlargement_triple_transferring (first-visit branch: no
+    multinomial draw, so it is deterministic) and train.py:297-325 transfer_knowledge, on the model_small embeddings."""
+    train_mod = _load_ref_train()
+    g = dict(np.load(os.path.join(HERE, "model_small.npz")))
+    rng = np.random.default_rng(55)
+    n1, n2, nrel = int(g["n1"]), int(g["n2"]), int(g["nrel"])
+    out1, out2 = torch.from_numpy(g["emb1_align"]), torch.from_numpy(g["emb2_align"])
+    triples1 = g["train1"].astype(np.int64)
+    h = rng.integers(0, n2, 260); r = rng.integers(0, nrel - 1, 260); t = rng.integers(0, n2, 260)
+    triples2 = np.unique(np.stack([h, r, t], 1), axis=0)[rng.permutation(250)[:230]].astype(np.int64)
+    # links: 70 pairs; entity 0 on either side (the reference's `links.get(x)` truthiness quirk), one source listed twice
+    src = rng.permutation(n1)[:70]; dst = rng.permutation(n2)[:70]
+    src[3], dst[3] = 5, 0
+    src[4], dst[4] = 0, 7
+    src[9] = src[8]
+    links = np.stack([src, dst], 1).astype(np.int64)
+    # make sure several triples have both ends linked, in both directions, some colliding with existing triples
+    for i in range(12):
+        a, b = rng.integers(0, 70, 2)
+        triples1[i] = [links[a, 0], rng.integers(0, nrel - 1), links[b, 0]]
+        triples2[i] = [links[b, 1], rng.integers(0, nrel - 1), links[a, 1]]
+    triples2[12] = [links[20, 1], triples1[0, 1], links[21, 1]]
+    triples1[12] = [links[20, 0], triples1[0, 1], links[21, 0]]          # its image already exists in KG 2
+    triples1[13] = triples1[1]                                          # duplicate source triple: transferred once
+    kg = lambda tr: types.SimpleNamespace(triple_keys=set("%d_%d_%d" % tuple(x) for x in tr.tolist()))
+    kg1, kg2 = kg(triples1), kg(triples2)
+    args = types.SimpleNamespace(num_negative=5, pair_sample_weight=0.2)
+    test_src = rng.permutation(n1)[:25].tolist(); test_dst = rng.permutation(n2)[:25].tolist()
+    ge, gs = [-1], [links]
+    nt1, nt2, nk1, nk2, feed, gs_out = train_mod.seed_enlargement_triple_transferring(
+        out1, out2, test_src, test_dst, ge, 0, links, triples1.tolist(), triples2.tolist(), gs, [0, n1], [0, nrel],
+        [n1, n1 + n2], [nrel, 2 * nrel], kg1, kg2, args)
+    key = lambda ks: np.array(sorted(tuple(int(v) for v in k.split("_")) for k in ks), dtype=np.int64)
+    _save("entr_small", n1=n1, n2=n2, nrel=nrel, triples1=triples1, triples2=triples2, links=links,
+          test_src=np.array(test_src), test_dst=np.array(test_dst),
+          new_triples1=np.array([list(x) for x in nt1], dtype=np.int64), new_triples2=np.array([list(x) for x in nt2], dtype=np.int64),
+          keys1=key(nk1), keys2=key(nk2), entropy=np.float64(float(ge[0])),
+          neg_left=np.asarray(feed["neg_left"], dtype=np.float64), neg_right=_np(feed["neg_right"]),
+          neg2_left=_np(feed["neg2_left"]), neg2_right=np.asarray(feed["neg2_right"], dtype=np.float64),
+          feed_links=np.asarray(feed["links"], dtype=np.int64))
+
+
 def gen_dbpv1():
     from models.jmac_model import RelationalAwareLayer
     args = types.SimpleNamespace(leaky_relu_w=0.05, opn="sub")
@@ -342,12 +401,12 @@ def gen_dbpv1():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variant", default="all", choices=["all", "root", "dbpv1", "aligneval"])
+    ap.add_argument("--variant", default="all", choices=["all", "root", "dbpv1", "aligneval", "entr"])
     a = ap.parse_args()
     if a.variant == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for v in ("root", "dbpv1", "aligneval"):
+        for v in ("root", "dbpv1", "aligneval", "entr"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--variant", v], env=env)
     else:
         _paths(a.variant)
-        {"root": gen_root, "dbpv1": gen_dbpv1, "aligneval": gen_aligneval}[a.variant]()
+        {"root": gen_root, "dbpv1": gen_dbpv1, "aligneval": gen_aligneval, "entr": gen_entr}[a.variant]()
