@@ -389,6 +389,57 @@ def gen_entr():
           feed_links=np.asarray(feed["links"], dtype=np.int64))
 
 
+def gen_dataset():
+    """Dataset reader (row f2, formats): a seeded SYNTHETIC mini dataset in the DBP-5L on-disk format
+    (tests/golden/dbp5l_mini/: entity/<lang>.tsv, kg/<lang>-{train,val,test}.tsv, seed_{train,test}_pairs/<l1>-<l2>.tsv
+    with float-formatted ids, relations.txt) is written, then the REFERENCE's loader
+    (src/data_loader.py:158-221 ParseData.create_KG_objects_and_alignment -> src/utils.py:112-154) reads it."""
+    from src.data_loader import ParseData
+    root = os.path.join(HERE, "dbp5l_mini")
+    rng = np.random.default_rng(77)
+    sizes = {"el": 40, "ja": 55, "en": 70}
+    nrel = 12
+    for sub in ("entity", "kg", "seed_train_pairs", "seed_test_pairs"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    with open(os.path.join(root, "relations.txt"), "w") as f:
+        f.write("".join("http://example.org/property/r%d\n" % i for i in range(nrel)))
+    for lang, n in sizes.items():
+        with open(os.path.join(root, "entity", lang + ".tsv"), "w") as f:
+            f.write("".join("%s entity %d\n" % (lang, i) for i in range(n)))
+        tr = np.unique(np.stack([rng.integers(0, n, 4 * n), rng.integers(0, nrel, 4 * n), rng.integers(0, n, 4 * n)], 1), axis=0)
+        tr = tr[rng.permutation(len(tr))]
+        a, b = int(len(tr) * 0.6), int(len(tr) * 0.85)
+        for name, part in (("train", tr[:a]), ("val", tr[a:b]), ("test", tr[b:])):
+            np.savetxt(os.path.join(root, "kg", "%s-%s.tsv" % (lang, name)), part, fmt="%d", delimiter="\t")
+    for l1, l2 in (("el", "ja"), ("ja", "en"), ("el", "en")):
+        m = min(sizes[l1], sizes[l2])
+        pairs = np.stack([rng.permutation(sizes[l1])[:m], rng.permutation(sizes[l2])[:m]], 1).astype(np.float64)
+        np.savetxt(os.path.join(root, "seed_train_pairs", "%s-%s.tsv" % (l1, l2)), pairs[: m // 2], fmt="%.1f", delimiter="\t")
+        np.savetxt(os.path.join(root, "seed_test_pairs", "%s-%s.tsv" % (l1, l2)), pairs[m // 2:], fmt="%.1f", delimiter="\t")
+    lg = logging.getLogger("golden"); lg.setLevel(logging.ERROR)
+    out = {}
+    for target in ("ja", "en"):
+        pd_ = ParseData(types.SimpleNamespace(data_path=root, target_language=target, device="cpu"), lg)
+        kgs, s_train, s_test = pd_.create_KG_objects_and_alignment()
+        out["%s.kg_names" % target] = np.array(pd_.kg_names)
+        out["%s.num_entities" % target] = np.int64(pd_.num_entities)
+        for lang, kg in kgs.items():
+            pre = "%s.%s." % (target, lang)
+            out[pre + "train"], out[pre + "val"], out[pre + "test"] = kg.train_data, kg.val_data, kg.test_data
+            out[pre + "meta"] = np.array([kg.num_entity, kg.num_relation, int(kg.is_supporter_kg), kg.entity_id_base,
+                                          kg.relation_id_base, kg.upper_entity_base, kg.upper_relation_base], dtype=np.int64)
+            out[pre + "edge_index"], out[pre + "edge_type"] = np.asarray(kg.edge_index), np.asarray(kg.edge_type)
+            if not kg.is_supporter_kg:      # filter dictionary of the evaluator (knowledgegraph.py:45-46,62-86)
+                keys = sorted(kg.true_tail.keys())
+                out[pre + "true_tail_keys"] = np.array(keys, dtype=np.int64)
+                out[pre + "true_tail_ptr"] = np.cumsum([0] + [len(kg.true_tail[k]) for k in keys]).astype(np.int64)
+                out[pre + "true_tail_idx"] = np.array([t for k in keys for t in kg.true_tail[k]], dtype=np.int64)
+        for name, seeds in (("seeds_train", s_train), ("seeds_test", s_test)):
+            for (l1, l2), v in seeds.items():
+                out["%s.%s.%s-%s" % (target, name, l1, l2)] = v
+    _save("dbp5l_mini", **out)
+
+
 def gen_dbpv1():
     from models.jmac_model import RelationalAwareLayer
     args = types.SimpleNamespace(leaky_relu_w=0.05, opn="sub")
@@ -401,12 +452,12 @@ def gen_dbpv1():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variant", default="all", choices=["all", "root", "dbpv1", "aligneval", "entr"])
+    ap.add_argument("--variant", default="all", choices=["all", "root", "dbpv1", "aligneval", "entr", "dataset"])
     a = ap.parse_args()
     if a.variant == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for v in ("root", "dbpv1", "aligneval", "entr"):
+        for v in ("root", "dbpv1", "aligneval", "entr", "dataset"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--variant", v], env=env)
     else:
         _paths(a.variant)
-        {"root": gen_root, "dbpv1": gen_dbpv1, "aligneval": gen_aligneval, "entr": gen_entr}[a.variant]()
+        {"root": gen_root, "dbpv1": gen_dbpv1, "aligneval": gen_aligneval, "entr": gen_entr, "dataset": gen_dataset}[a.variant]()
