@@ -161,21 +161,44 @@ __global__ __launch_bounds__(kBlock) void filtered_rank_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// similarity GEMM  C = A * B^T  on the fp32-input MFMA (32x32x2), 128x128 tile per 4-wave block
+// similarity GEMM  C = A * B^T  on the fp32-input MFMA (32x32x2), 128x128 tile per 4-wave block, K staged 16 deep
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int SG_T = 128, SG_K = 8;
+constexpr int SG_T = 128, SG_K = 16;
+constexpr int SG_PLANE = SG_T * 4 + 8;      // floats per (sub-slab q, k-half h) plane; +8: the 4 planes a wave store
+                                            // instruction touches start on different banks
+constexpr int SG_IMG = 4 * SG_PLANE;        // one operand slab: planes (q, h) = (0,0) (0,1) (1,0) (1,1)
+constexpr int SG_SUPER = 8;                 // super-tile of 8x8 tiles per XCD visit (L2: 2 x 1.2 MB at d=300)
 
 __global__ __launch_bounds__(kBlock) void sim_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
-                                                          int64_t ldb, int M, int N, int d, float* __restrict__ C, int64_t ldc) {
-    // LDS image: [row][8 floats]; lane (r = l&31, h = l>>5) reads floats 4h..4h+3 of row r: one contiguous
-    // 1 KiB ds_read_b128 per 32-row block, conflict free.
-    __shared__ __attribute__((aligned(16))) float As[2][SG_T][SG_K];
-    __shared__ __attribute__((aligned(16))) float Bs[2][SG_T][SG_K];
+                                                          int64_t ldb, int M, int N, int d, float* __restrict__ C, int64_t ldc,
+                                                          int tiles_m, int tiles_n, int super_order) {
+    // LDS image of one operand slab (16 k): plane (q, h) holds, for every tile row, the 4 floats k = 8q + 4h .. +3.
+    // Lane (r = l&31, h = l>>5) of a wave reads its float4 of row r from plane (q, h): 32 lanes x 16 B contiguous,
+    // conflict free for ds_read_b128's lane groups.  The MFMA step s of a sub-slab contracts k = {8q+s, 8q+4+s}.
+    __shared__ __attribute__((aligned(16))) float As[2][SG_IMG];
+    __shared__ __attribute__((aligned(16))) float Bs[2][SG_IMG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;           // wave grid 2 x 2, each wave 64 x 64
-    const int m0 = blockIdx.y * SG_T, n0 = blockIdx.x * SG_T;
-    const int lrow = tid >> 1, lk = (tid & 1) * 4;     // loader: 128 rows x 2 float4
+
+    // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so ids {x, x+8, x+16, ...} share one L2.
+    // Those ids walk ONE super-tile of SG_SUPER x SG_SUPER tiles before moving on: its A and B panels stay L2-resident.
+    int tm, tn;
+    if (super_order) {
+        const int id = blockIdx.x;
+        const int sup_n = (tiles_n + SG_SUPER - 1) / SG_SUPER, sup_m = (tiles_m + SG_SUPER - 1) / SG_SUPER;
+        const int per = SG_SUPER * SG_SUPER;
+        const int xcd = id & 7, local = id >> 3;
+        const int sup = (local / per) * 8 + xcd, within = local % per;
+        if (sup >= sup_m * sup_n) return;
+        tm = (sup / sup_n) * SG_SUPER + within / SG_SUPER;
+        tn = (sup % sup_n) * SG_SUPER + within % SG_SUPER;
+        if (tm >= tiles_m || tn >= tiles_n) return;
+    } else {                                       // few tiles: plain row-major order, every XCD busy
+        tm = blockIdx.x / tiles_n;
+        tn = blockIdx.x % tiles_n;
+    }
+    const int m0 = tm * SG_T, n0 = tn * SG_T;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -184,65 +207,103 @@ __global__ __launch_bounds__(kBlock) void sim_gemm_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto gload = [&](const float* base, int64_t ld, int64_t row, int64_t nrows, int k0) -> float4 {
-        float4 v = f4zero();
-        if (row < nrows) {
-            const int k = k0 + lk;
-            const float* p = base + row * ld;
-            if (k + 3 < d) v = ld4(p + k);
-            else {
-                if (k + 0 < d) v.x = p[k + 0];
-                if (k + 1 < d) v.y = p[k + 1];
-                if (k + 2 < d) v.z = p[k + 2];
-            }
-        }
-        return v;
-    };
-    const int nk = (d + SG_K - 1) / SG_K;
-    float4 ra = gload(A, lda, m0 + lrow, M, 0), rb = gload(Bm, ldb, n0 + lrow, N, 0);
-    *reinterpret_cast<float4*>(&As[0][lrow][lk]) = ra;
-    *reinterpret_cast<float4*>(&Bs[0][lrow][lk]) = rb;
-    __syncthreads();
-    const int r = lane & 31, h = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            ra = gload(A, lda, m0 + lrow, M, (kt + 1) * SG_K);
-            rb = gload(Bm, ldb, n0 + lrow, N, (kt + 1) * SG_K);
-        }
-        float4 af[2], bf[2];
+    // loader: float4 f = tid + 256 i (i < 2): row = f / 4, k quad kq = f % 4 (4 consecutive lanes read 64 contiguous
+    // bytes of a row).  Every load is unconditional at a clamped address (a load behind an exec-mask branch is not
+    // overlapped with the MFMAs): rows past the end re-read the last row -- they only feed outputs that are never
+    // stored -- and float4s past d (d % 4 == 0, enforced by the launcher) are zeroed after the load.
+    auto gload = [&](const float* base, int64_t ld, int row0, int nrows, int k0, float4 (&v)[2]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            af[i] = *reinterpret_cast<const float4*>(&As[cur][wm * 64 + i * 32 + r][h * 4]);
-            bf[i] = *reinterpret_cast<const float4*>(&Bs[cur][wn * 64 + i * 32 + r][h * 4]);
+            const int f = tid + 256 * i;
+            const int row = min(row0 + (f >> 2), nrows - 1), k = k0 + 4 * (f & 3);
+            v[i] = ld4(base + (int64_t)row * ld + min(k, d - 4));     // zeroing waits for the data: done at store time
         }
+    };
+    auto sstore = [&](float* S, const float4 (&v)[2], int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            const float4 x = k0 + 4 * (f & 3) < d ? v[i] : f4zero();
+            *reinterpret_cast<float4*>(S + (f & 3) * SG_PLANE + (f >> 2) * 4) = x;      // plane index = kq = 2q + h
+        }
+    };
+    const int r = lane & 31, h = lane >> 5;
+    const int aoff = h * SG_PLANE + (wm * 64 + r) * 4, boff = h * SG_PLANE + (wn * 64 + r) * 4;
+    auto frags = [&](int buf, int q, float4 (&af)[2], float4 (&bf)[2]) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                // MFMA step s contracts k = {s, 4+s} of this 8-deep slice (lane half h supplies k = 4h+s)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-            }
+        for (int i = 0; i < 2; ++i) {
+            af[i] = *reinterpret_cast<const float4*>(As[buf] + q * 2 * SG_PLANE + aoff + i * 32 * 4);
+            bf[i] = *reinterpret_cast<const float4*>(Bs[buf] + q * 2 * SG_PLANE + boff + i * 32 * 4);
+        }
+    };
+    // the four accumulators rotate (dependency distance 4)
+    auto mfma16 = [&](const float4 (&af)[2], const float4 (&bf)[2]) {
+#define JMAC_SG_STEP(c)                                                                                   \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0].c, bf[0].c, acc[0][0], 0, 0, 0);          \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0].c, bf[1].c, acc[0][1], 0, 0, 0);          \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1].c, bf[0].c, acc[1][0], 0, 0, 0);          \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1].c, bf[1].c, acc[1][1], 0, 0, 0);
+        JMAC_SG_STEP(x)
+        JMAC_SG_STEP(y)
+        JMAC_SG_STEP(z)
+        JMAC_SG_STEP(w)
+#undef JMAC_SG_STEP
+    };
+
+    // Software pipeline, one barrier per slab.  At the top of slab kt: fragment set 0 holds (kt, q=0), the staging
+    // registers hold slab kt+1 (loads in flight).  The q=0 MFMAs cover the q=1 fragment reads and the LDS stores of
+    // slab kt+1; the q=1 MFMAs cover the first fragment reads of slab kt+1 and the global loads of slab kt+2.
+    const int nk = (d + SG_K - 1) / SG_K;
+    float4 ra[2], rb[2], af0[2], bf0[2], af1[2], bf1[2];
+    gload(A, lda, m0, M, 0, ra);
+    gload(Bm, ldb, n0, N, 0, rb);
+    sstore(As[0], ra, 0);
+    sstore(Bs[0], rb, 0);
+    if (nk > 1) {
+        gload(A, lda, m0, M, SG_K, ra);
+        gload(Bm, ldb, n0, N, SG_K, rb);
+    }
+    __syncthreads();
+    frags(0, 0, af0, bf0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        frags(cur, 1, af1, bf1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nk) {
-            *reinterpret_cast<float4*>(&As[cur ^ 1][lrow][lk]) = ra;
-            *reinterpret_cast<float4*>(&Bs[cur ^ 1][lrow][lk]) = rb;
+            sstore(As[cur ^ 1], ra, (kt + 1) * SG_K);
+            sstore(Bs[cur ^ 1], rb, (kt + 1) * SG_K);
+            if (kt + 2 < nk) {
+                gload(A, lda, m0, M, (kt + 2) * SG_K, ra);
+                gload(Bm, ldb, n0, N, (kt + 2) * SG_K, rb);
+            }
         }
         __syncthreads();
+        if (kt + 1 < nk) frags(cur ^ 1, 0, af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(af1, bf1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const bool full = m0 + SG_T <= M && n0 + SG_T <= N;      // block-uniform: interior tiles store without bounds tests
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            float* cbase = C + (int64_t)(m0 + wm * 64 + i * 32 + 4 * h) * ldc + (n0 + wn * 64 + j * 32 + r);
+            if (full) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int64_t m = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                const int64_t n = n0 + wn * 64 + j * 32 + r;
-                if (m < M && n < N) C[m * ldc + n] = acc[i][j][reg];
+                for (int reg = 0; reg < 16; ++reg) cbase[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg];
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int64_t m = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    const int64_t n = n0 + wn * 64 + j * 32 + r;
+                    if (m < M && n < N) C[m * ldc + n] = acc[i][j][reg];
+                }
             }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -386,8 +447,14 @@ __global__ __launch_bounds__(kBlock) void csls_apply_kernel(const float* __restr
 int launch_sim(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t d, float* C, int64_t ldc,
                hipStream_t st) {
     if (M == 0 || N == 0) return 0;
-    dim3 grid((unsigned)((N + SG_T - 1) / SG_T), (unsigned)((M + SG_T - 1) / SG_T));
-    hipLaunchKernelGGL(sim_gemm_kernel, grid, dim3(kBlock), 0, st, A, lda, B, ldb, (int)M, (int)N, (int)d, C, ldc);
+    const int tiles_m = (int)((M + SG_T - 1) / SG_T), tiles_n = (int)((N + SG_T - 1) / SG_T);
+    const int64_t sup = (int64_t)((tiles_m + SG_SUPER - 1) / SG_SUPER) * ((tiles_n + SG_SUPER - 1) / SG_SUPER);
+    const int super_order = sup >= 64 ? 1 : 0;                          // >= 8 super-tiles per XCD: the tail imbalance is small
+    const int64_t blocks = super_order ? (sup + 7) / 8 * 8 * SG_SUPER * SG_SUPER : (int64_t)tiles_m * tiles_n;
+    if (blocks >= INT32_MAX) return JMAC_ERANGE;
+    if (d % 4) return JMAC_EDIM;
+    hipLaunchKernelGGL(sim_gemm_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, A, lda, B, ldb, (int)M, (int)N, (int)d, C, ldc,
+                       tiles_m, tiles_n, super_order);
     return (int)hipGetLastError();
 }
 
