@@ -307,23 +307,129 @@ __global__ __launch_bounds__(kBlock) void sim_gemm_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// row top-k: one block per row, k rounds of (value desc, index asc) arg-max after the previous pick
+// row top-k: one block per row.  Order: value descending, ties -> lower index first.
+//   pass A  histogram of the 12 leading bits of an order-preserving key -> the bin b* that holds the k-th largest value
+//   pass B  every entry of bins >= b* (a few dozen for similarity rows) is collected in LDS
+//   select  each candidate counts the candidates that beat it: that count is its output slot
+// Two streaming passes over the row instead of k; rows whose candidate set exceeds the LDS list (e.g. constant rows)
+// take k rounds of (value, index) arg-max over the row in place.
 // ------------------------------------------------------------------------------------------------
+constexpr int TK_BINS = 4096, TK_CAP = 1024;
+
+__device__ __forceinline__ unsigned tk_key(float v) {          // ascending float order == ascending unsigned order
+    const unsigned u = v == 0.f ? 0u : __float_as_uint(v);    // -0 and +0 compare equal: one key
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// a beats b: larger value, or equal value and lower index
+__device__ __forceinline__ bool tk_beats(unsigned ka, int ia, unsigned kb, int ib) { return ka > kb || (ka == kb && ia < ib); }
+
 __global__ __launch_bounds__(kBlock) void row_topk_kernel(const float* __restrict__ S, int64_t lds, int N, int k,
-                                                          float* __restrict__ val, int32_t* __restrict__ idx, int use_lds) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+                                                          float* __restrict__ val, int32_t* __restrict__ idx) {
+    __shared__ int hist[TK_BINS];
+    __shared__ unsigned ckey[TK_CAP];
+    __shared__ int cidx[TK_CAP];
+    __shared__ int chunk_sum[kBlock];
+    __shared__ int sh_bin, sh_above, sh_cnt;
     __shared__ float wv[kBlock / 64];
     __shared__ int wi[kBlock / 64];
     __shared__ float pick_v;
     __shared__ int pick_i;
-    float* cache = reinterpret_cast<float*>(smem);
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* row = S + (int64_t)b * lds;
-    if (use_lds) {
-        for (int n = tid; n < N; n += kBlock) cache[n] = row[n];
-        __syncthreads();
-        row = cache;
+    const bool vec = (((uintptr_t)row) & 15) == 0;
+    for (int i = tid; i < TK_BINS; i += kBlock) hist[i] = 0;
+    if (tid == 0) sh_cnt = 0;
+    __syncthreads();
+    // ---- pass A
+    const int N4 = vec ? (N >> 2) : 0;
+    for (int q = tid; q < N4; q += kBlock) {
+        const float4 v = ld4(row + 4 * q);
+        atomicAdd(&hist[tk_key(v.x) >> 20], 1);
+        atomicAdd(&hist[tk_key(v.y) >> 20], 1);
+        atomicAdd(&hist[tk_key(v.z) >> 20], 1);
+        atomicAdd(&hist[tk_key(v.w) >> 20], 1);
     }
+    for (int n = 4 * N4 + tid; n < N; n += kBlock) atomicAdd(&hist[tk_key(row[n]) >> 20], 1);
+    __syncthreads();
+    // ---- b*: chunk c = bins [BINS - 16(c+1), BINS - 16c), scanned from the top
+    {
+        int s16 = 0;
+        const int hi = TK_BINS - 16 * tid;
+#pragma unroll
+        for (int j = 1; j <= 16; ++j) s16 += hist[hi - j];
+        chunk_sum[tid] = s16;
+        __syncthreads();
+        if (tid < 64) {          // one wave: inclusive scan of the 256 chunk sums, 4 per lane
+            int a0 = chunk_sum[4 * tid], a1 = chunk_sum[4 * tid + 1], a2 = chunk_sum[4 * tid + 2], a3 = chunk_sum[4 * tid + 3];
+            const int tot = a0 + a1 + a2 + a3;
+            int inc = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o, 64);
+                if (tid >= o) inc += t;
+            }
+            int before = inc - tot;                       // entries in chunks above this lane's four
+            const int sums[4] = {a0, a1, a2, a3};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (before < k && before + sums[j] >= k) {   // the k-th largest lies in chunk 4*tid + j
+                    const int top = TK_BINS - 16 * (4 * tid + j);
+                    int above = before;
+                    for (int t = 1; t <= 16; ++t) {
+                        const int h = hist[top - t];
+                        if (above + h >= k) {
+                            sh_bin = top - t;
+                            sh_above = above;
+                            break;
+                        }
+                        above += h;
+                    }
+                }
+                before += sums[j];
+            }
+        }
+        __syncthreads();
+    }
+    const int bstar = sh_bin;
+    const int C = sh_above + hist[bstar];               // candidates = all entries of bins >= b*  (C >= k)
+    if (C <= TK_CAP) {
+        // ---- pass B
+        for (int q = tid; q < N4; q += kBlock) {
+            const float4 v = ld4(row + 4 * q);
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned key = tk_key(e[j]);
+                if ((int)(key >> 20) >= bstar) {
+                    const int slot = atomicAdd(&sh_cnt, 1);
+                    ckey[slot] = key;
+                    cidx[slot] = 4 * q + j;
+                }
+            }
+        }
+        for (int n = 4 * N4 + tid; n < N; n += kBlock) {
+            const unsigned key = tk_key(row[n]);
+            if ((int)(key >> 20) >= bstar) {
+                const int slot = atomicAdd(&sh_cnt, 1);
+                ckey[slot] = key;
+                cidx[slot] = n;
+            }
+        }
+        __syncthreads();
+        // ---- select: slot = number of candidates that beat this one (keys are distinct as (key, index) pairs)
+        for (int c = tid; c < C; c += kBlock) {
+            const unsigned kc = ckey[c];
+            const int ic = cidx[c];
+            int better = 0;
+            for (int o = 0; o < C; ++o) better += tk_beats(ckey[o], cidx[o], kc, ic) ? 1 : 0;
+            if (better < k) {
+                idx[(int64_t)b * k + better] = ic;
+                if (val) val[(int64_t)b * k + better] = row[ic];
+            }
+        }
+        return;
+    }
+    // ---- fallback: k rounds of arg-max after the previous pick
     float pv = INFINITY;
     int pi = -1;
     for (int r = 0; r < k; ++r) {
@@ -460,10 +566,7 @@ int launch_sim(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t
 
 int launch_topk(const float* S, int64_t lds, int64_t L, int64_t N, int32_t k, float* val, int32_t* idx, hipStream_t st) {
     if (L == 0) return 0;
-    const size_t bytes = (size_t)N * 4;
-    const int use_lds = bytes <= 64 * 1024 ? 1 : 0;   // default LDS limit per workgroup without opt-in
-    hipLaunchKernelGGL(row_topk_kernel, dim3((unsigned)L), dim3(kBlock), use_lds ? bytes : 16, st, S, lds, (int)N, (int)k, val,
-                       idx, use_lds);
+    hipLaunchKernelGGL(row_topk_kernel, dim3((unsigned)L), dim3(kBlock), 0, st, S, lds, (int)N, (int)k, val, idx);
     return (int)hipGetLastError();
 }
 

@@ -100,6 +100,25 @@ def test_topk_bit_exact_with_ties(L, N, k):
     assert (idx2.cpu() == s2.topk(k, dim=1)[1]).all()
 
 
+@pytest.mark.parametrize("L,N,k", [(40, 30000, 25), (33, 10501, 10), (7, 56589, 25), (16, 1027, 25)])
+def test_topk_large_rows_two_pass_select(L, N, k):
+    """Config-5 shapes: the histogram/select path (random similarities), odd row lengths (unaligned rows take the
+    scalar loads), signed zeros (equal under float comparison: lower index first) and a constant row (every entry
+    ties: the candidate list overflows and the in-place arg-max rounds run)."""
+    from jmac_amd import scoring
+    gen = torch.Generator().manual_seed(N + k)
+    s = torch.randn(L, N, generator=gen) * 0.06
+    s[1, ::3] = 0.0
+    s[1, 1::3] = -0.0
+    s[1, 2::3] = -1.0
+    s[2] = 0.25
+    s[3, : N // 2] = s[3, N // 2: 2 * (N // 2)]                        # every value twice
+    val, idx = scoring.row_topk(s.cuda(), k)
+    want = orc.topk_lowest_index(s, k)
+    assert torch.equal(idx.cpu(), want)
+    assert torch.equal(val.cpu(), s.gather(1, want))
+
+
 def test_alignment_quality_matches_reference_golden():
     from jmac_amd import scoring
     g = load_golden("model_small")
