@@ -14,6 +14,7 @@ Extra objects on the same line:
   roofline      the aggregation forward kernel: algorithmic bytes / HIP-event duration
   cpu_baseline  the oracle (un-factorised reference formulation, PyTorch CPU) timed on the same step
   scoring       scored triples/s: B=1000 queries x all N candidates x 2 layers + filtered rank
+  sim           config-5 shape: fp32 MFMA similarity GEMM (TFLOP/s, fraction of the f32 matrix peak), get_neg, CSLS test
   synth         config 4 (1M entities / 20M triples / 1k relations): aggregation kernel GB/s at HBM scale
 """
 import argparse
@@ -203,16 +204,30 @@ def raw_kernel_timing(N, E, nr, d, ei, et, device, iters=20, bwd_mode=1):
     a = (torch.randn(d, device=device, generator=gen) * 0.1).requires_grad_(True)
     G = torch.randn(N, d, device=device, generator=gen)
     res = {}
-    with torch.no_grad():
-        for _ in range(3):
-            ops.rel_attn_aggregate(PQZ, RR, a, g, 0.05, nr - 1, 0.5, bwd_mode)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            ops.rel_attn_aggregate(PQZ, RR, a, g, 0.05, nr - 1, 0.5, bwd_mode)
-        e1.record()
-        torch.cuda.synchronize()
-        res["fwd_ms"] = e0.elapsed_time(e1) / iters
+    # forward: the C-ABI entry point itself, buffers preallocated, launches back to back on torch's current stream
+    # with one HIP-event pair around the batch -> the kernel's own duration (a python-level op call adds ~6 us of
+    # allocator / ctypes time per launch, which is what the in-step event pairs see)
+    from jmac_amd._lib import lib, ptr, stream
+    L, sc = lib(), g.by_dst
+    out_b = torch.empty((N, d), device=device)
+    smax, sden = torch.empty(N, device=device), torch.empty(N, device=device)
+    wsb = int(L.jmac_rel_attn_fwd_workspace_bytes(sc.n_parts_max, d))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=device)
+    Pd = PQZ.detach()
+    args = (ptr(Pd), 3 * d, Pd.data_ptr() + d * 4, 3 * d, ptr(RR), 2 * d, ptr(a), ptr(g.rowptr), ptr(g.col), ptr(g.etype),
+            ptr(sc.items), ptr(sc.splits), ptr(sc.counts), sc.n_items_max, sc.n_splits_max, sc.n_parts_max, N, d, 0.05,
+            nr - 1, 0.5, ptr(out_b), d, ptr(smax), ptr(sden), ptr(ws), wsb, stream())
+    nf = max(iters, 5) * 4
+    for _ in range(5):
+        L.jmac_rel_attn_aggregate_fwd_f32(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(nf):
+        L.jmac_rel_attn_aggregate_fwd_f32(*args)
+    e1.record()
+    torch.cuda.synchronize()
+    res["fwd_ms"] = e0.elapsed_time(e1) / nf
+    res["fwd_launches"] = nf
     out = ops.rel_attn_aggregate(PQZ, RR, a, g, 0.05, nr - 1, 0.5, bwd_mode)
     for _ in range(2):
         torch.autograd.grad(out, [PQZ, RR, a], G, retain_graph=True)
@@ -256,6 +271,37 @@ def scoring_bench(w, iters=10):
             "B": B, "N": w.N, "layers": 2, "valu_frac_of_peak": (3.0 * B * w.N * w.d * 2 / dt) / 157.3e12}
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3      # 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md)
+
+
+def sim_bench(device, iters=10):
+    """Config 5 (OpenEA 15K shape): the fp32 MFMA similarity GEMM + fused top-k of get_neg, and the CSLS alignment test."""
+    from jmac_amd import scoring
+    gen = torch.Generator(device=device).manual_seed(0)
+    tab = torch.nn.functional.normalize(torch.randn(30000, 300, device=device, generator=gen))
+    q = tab[torch.randperm(30000, device=device, generator=gen)[:3000]]
+    big = tab[:12000], tab[12000:24000]
+
+    def t(fn, n=iters):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    gemm_ms = t(lambda: scoring.sim_matrix(*big))
+    tf = 2.0 * 12000 * 12000 * 300 / (gemm_ms * 1e-3) / 1e12
+    neg_ms = t(lambda: scoring.sim_topk(q, tab, 25))
+    test_ms = t(lambda: scoring.alignment_test(tab[:10500], tab[10500:21000], (1, 5, 10), csls_k=10), 3)
+    return {"workload": "config 5 shape: N=30000 d=300; quality GEMM 12000x12000, get_neg 3000x30000 k=25, CSLS test 10500^2",
+            "sim_gemm_ms": gemm_ms, "sim_gemm_tflops": tf, "mfma_frac_of_f32_peak": tf / MFMA_F32_PEAK_TFLOPS,
+            "mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS, "get_neg_ms": neg_ms, "get_neg_pairs_per_s": 3000 * 30000 / (neg_ms * 1e-3),
+            "alignment_test_ms": test_ms}
+
+
 def synth_measure(a, device):
     """Config 4 at HBM scale: the aggregation kernel on 1M entities / 20M triples / 1k relations, d=300."""
     from jmac_amd import synth
@@ -265,7 +311,31 @@ def synth_measure(a, device):
     r = raw_kernel_timing(n, e, nrel, a.dim, ei_t, et_t, device, iters=5, bwd_mode=a.bwd_mode)
     fb, bb = synth.fwd_algorithmic_bytes(n, e, a.dim), synth.bwd_algorithmic_bytes(n, e, a.dim)
     deg = np.bincount(ei[0], minlength=n)
-    return {"workload": "synthetic power-law 1M entities / 20M triples / 1k relations (config 4) x%.2f" % a.synth_scale,
+    bf = {}
+    try:                                               # bf16 tables (config 3's table form) on the same graph
+        from jmac_amd import ops
+        from jmac_amd.graph import RelGraph
+        g = RelGraph(ei_t, et_t, n, nrel)
+        gen = torch.Generator(device=device).manual_seed(0)
+        PQZ = (torch.randn(n, 3 * a.dim, device=device, generator=gen) * 0.3).to(torch.bfloat16)
+        RR = (torch.randn(nrel, 2 * a.dim, device=device, generator=gen) * 0.3).to(torch.bfloat16)
+        av = torch.randn(a.dim, device=device, generator=gen) * 0.1
+        with torch.no_grad():
+            for _ in range(2):
+                ops.rel_attn_aggregate(PQZ, RR, av, g, 0.05, nrel - 1, 0.5)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ops.rel_attn_aggregate(PQZ, RR, av, g, 0.05, nrel - 1, 0.5)
+            e1.record()
+            torch.cuda.synchronize()
+        ms16 = e0.elapsed_time(e1) / 5
+        fb16 = synth.fwd_algorithmic_bytes(n, e, a.dim, 2)
+        bf = {"fwd_bf16_ms": ms16, "fwd_bf16_GBps": fb16 / (ms16 * 1e-3) / 1e9, "fwd_bf16_frac_hbm": fb16 / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del PQZ, RR, g
+    except Exception as ex:                            # pragma: no cover
+        bf = {"fwd_bf16_error": str(ex)}
+    return {**bf, "workload": "synthetic power-law 1M entities / 20M triples / 1k relations (config 4) x%.2f" % a.synth_scale,
             "N": n, "E": e, "max_in_degree": int(deg.max()), "d": a.dim,
             "fwd_ms": r["fwd_ms"], "fwd_edges_per_s": e / (r["fwd_ms"] * 1e-3),
             "fwd_GBps": fb / (r["fwd_ms"] * 1e-3) / 1e9, "fwd_frac_hbm": fb / (r["fwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -360,11 +430,10 @@ def main():
                                "exec": exec_mode, "parallelism": "replicas x%d" % world,
                                "edges_counted_per_step": world * layer_calls * w.E},
                     "roofline": None, "cpu_baseline": None, "sharded": sharded}
-            prof = kernel_profile(w, 5)
             from jmac_amd import synth as _synth
             fb = _synth.fwd_algorithmic_bytes(w.N, w.E, w.d)
-            fms = prof["rel_attn_fwd"][0]
-            line["roofline"] = {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<3,4,75> (rank 0)", "achieved": fb / (fms * 1e-3) / 1e9,
+            fms = raw_kernel_timing(w.N, w.E, w.nr, w.d, w.ei, w.et, device, iters=25, bwd_mode=a.bwd_mode)["fwd_ms"]
+            line["roofline"] = {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<3, 2, 75, float> (rank 0)", "achieved": fb / (fms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "traffic": pmc_traffic("ja", "rel_attn_fwd_kernel") if w.d == 300 else None,
                                 "algorithmic_bytes_per_launch": fb, "avg_launch_ms": fms}
@@ -378,12 +447,13 @@ def main():
     fbytes = synth.fwd_algorithmic_bytes(w.N, w.E, w.d)
     bbytes = synth.bwd_algorithmic_bytes(w.N, w.E, w.d)
     raw = raw_kernel_timing(w.N, w.E, w.nr, w.d, w.ei, w.et, device, iters=50, bwd_mode=a.bwd_mode)
-    fwd_ms = prof["rel_attn_fwd"][0]
-    roof = {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<3,4>", "achieved": fbytes / (fwd_ms * 1e-3) / 1e9,
+    fwd_ms = raw["fwd_ms"]
+    roof = {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<3, 2, 75, float>", "achieved": fbytes / (fwd_ms * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fbytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": pmc_traffic("ja", "rel_attn_fwd_kernel") if (w.d == 300 and a.workload == "dbp5l-ja") else None,
-            "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": fwd_ms, "launches": prof["rel_attn_fwd"][2],
-            "back_to_back_ms": raw["fwd_ms"],
+            "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": fwd_ms, "launches": raw["fwd_launches"],
+            "timing": "HIP events around %d back-to-back C-ABI launches on the launch stream" % raw["fwd_launches"],
+            "in_step_op_ms": prof["rel_attn_fwd"][0],
             "note": "ja-scale working set (72 MB) is Infinity-Cache resident; HBM-scale figure is in 'synth'"}
     roof_bwd = {"bound": "hbm", "kernels": "rel_attn_bwd_dst + 2x rel_attn_bwd_gather (+reductions)",
                 "achieved": bbytes / (prof["rel_attn_bwd"][0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -399,6 +469,10 @@ def main():
                        "edges_counted_per_step": layer_calls * w.E},
             "roofline": roof, "roofline_bwd": roof_bwd}
     line["scoring"] = scoring_bench(w)
+    try:
+        line["sim"] = sim_bench(device)
+    except Exception as ex:                          # pragma: no cover
+        line["sim"] = {"error": str(ex)}
 
     if not a.no_cpu_baseline:
         # PyTorch-CPU scales poorly past one socket's worth of cores on these small ops (256 threads ran 30x
