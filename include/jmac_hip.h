@@ -222,6 +222,17 @@ int jmac_csls_apply_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, con
                         const float* r2, float* out, int64_t ldo, jmac_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Small fp32 GEMM for the relation-side projections (replaces the torch.mm calls on the ~10^3-row
+ * relation tables: src/jmac_model.py:40-42 rel_transform_weight1/2, :195-196 relation MLPs, and the
+ * hoisted rel'' @ [Wb|Wg] of the factorised layer) and their backward forms.
+ *   C[M,N] = op(A) op(B), row-major; transX != 0: op(X) = X^T, i.e. A is stored [K,M] / B is stored [N,K].
+ * Exact fp32 products on the fp32-input MFMA, fixed summation order (bitwise reproducible).  Any M, N, K, ld.
+ * --------------------------------------------------------------------------------------------- */
+int jmac_gemm_f32(const float* A, int64_t lda, int32_t transA, const float* B, int64_t ldb,
+                  int32_t transB, int64_t M, int64_t N, int64_t K, float* C, int64_t ldc,
+                  jmac_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Loss gathers.  Indices are the reference's int64 tensors (batch_h /
  * batch_r / batch_t, links, neg_left ...), values in range; rows may have any d (16-byte aligned rows
  * with d % 4 == 0 take the vector path).

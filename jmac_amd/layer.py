@@ -58,11 +58,18 @@ class RelationAwareLayer(nn.Module):
         self.table_dtype = torch.float32
 
     # -- pieces ---------------------------------------------------------------------------------
+    @staticmethod
+    def _rel_mm(a, b):
+        """Products on the relation table (~10^3 rows): the library GEMM is launch/occupancy bound there."""
+        if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape[0] <= ops.SMALL_MM_MAX_ROWS:
+            return ops.small_mm(a, b)
+        return torch.mm(a, b)
+
     def transform_relations(self, rel_emb):
         rel = torch.cat([rel_emb, self.loop_rel], dim=0)                  # jmac_model.py:39
-        rel = torch.mm(rel, self.rel_transform_weight1)
+        rel = self._rel_mm(rel, self.rel_transform_weight1)
         rel = self.atv_mlp(rel) if self.rel_activation == "leaky_relu" else F.relu(rel)
-        return torch.mm(rel, self.rel_transform_weight2)                  # :42
+        return self._rel_mm(rel, self.rel_transform_weight2)              # :42
 
     def _tables(self, ent_emb, rel):
         """P|Q|Z and Rq|Rz, zero-padded to a multiple of 4 columns for 16-byte rows."""
@@ -79,7 +86,7 @@ class RelationAwareLayer(nn.Module):
                 raise RuntimeError("table_dtype=bfloat16 is the inference form of the layer: call it under torch.no_grad()")
             wcat, ent_emb, rel = wcat.to(torch.bfloat16), ent_emb.to(torch.bfloat16), rel.to(torch.bfloat16)
         PQZ = torch.mm(ent_emb, wcat)                                     # [N, 3dp]
-        RR = torch.mm(rel, wcat[:, dp:])                                  # [nr+1, 2dp]
+        RR = self._rel_mm(rel, wcat[:, dp:])                              # [nr+1, 2dp]
         return PQZ, RR, a.float(), dp
 
     def pre_bn(self, ent_emb, rel_emb, edge_index, edge_type):

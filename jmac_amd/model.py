@@ -65,7 +65,8 @@ class JMAC(nn.Module):
 
     # ---- encoders -------------------------------------------------------------------------------
     def _rel_mlp(self, r, w1, w2):
-        return torch.mm(self.atv_mlp(torch.mm(r, w1)), w2)
+        mm = RelationAwareLayer._rel_mm                                   # src/jmac_model.py:195-196
+        return mm(self.atv_mlp(mm(r, w1)), w2)
 
     def forward_name(self, edge_index, edge_type, ent_bases, rel_bases):
         """src/jmac_model.py:172-204."""

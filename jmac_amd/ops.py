@@ -248,3 +248,47 @@ def bn_tanh(x, weight, bias, running_mean, running_var, training: bool, momentum
     if x.shape[1] % 4 != 0:
         raise ValueError("bn_tanh needs d % 4 == 0 (pad on the host)")
     return _BnTanh.apply(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps))
+
+
+# ---- small fp32 GEMM (relation-side projections) -----------------------------------------------------------------
+def _gemm(A, ta, B, tb, M, N, K):
+    C_ = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    check(lib().jmac_gemm_f32(ptr(A), A.stride(0), 1 if ta else 0, ptr(B), B.stride(0), 1 if tb else 0, M, N, K, ptr(C_), N,
+                              stream()), "jmac_gemm_f32")
+    return C_
+
+
+def _rowmajor(t: torch.Tensor) -> torch.Tensor:
+    return t if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous()
+
+
+class _SmallMM(torch.autograd.Function):
+    """C = A @ B on jmac_gemm_f32 with its two backward forms (dA = G B^T, dB = A^T G)."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        require_device(A, B)
+        A, B = _rowmajor(_f32c(A)), _rowmajor(_f32c(B))
+        if A.shape[1] != B.shape[0]:
+            raise ValueError("small_mm: %s @ %s" % (tuple(A.shape), tuple(B.shape)))
+        ctx.save_for_backward(A, B)
+        return _gemm(A, False, B, False, A.shape[0], B.shape[1], A.shape[1])
+
+    @staticmethod
+    def backward(ctx, G):
+        A, B = ctx.saved_tensors
+        G = _rowmajor(_f32c(G))
+        M, K = A.shape
+        N = B.shape[1]
+        dA = _gemm(G, False, B, True, M, K, N) if ctx.needs_input_grad[0] else None      # [M,N] x [K,N]^T
+        dB = _gemm(A, True, G, False, K, N, M) if ctx.needs_input_grad[1] else None      # [M,K]^T x [M,N]
+        return dA, dB
+
+
+SMALL_MM_MAX_ROWS = 4096     # the relation tables of DBP-5L (962 rows per KG, 4806 for the union) and OpenEA (2 x num_rel)
+
+
+def small_mm(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """``torch.mm`` for the relation-side products ([~10^3, d] x [d, d..2d]): one 32x32 tile per 4-wave block, K split
+    over the waves, fragments straight from L2 -- ~4 us where the library GEMM takes ~17 us."""
+    return _SmallMM.apply(A, B)

@@ -74,6 +74,24 @@ def _oracle_case(n, nr, d, e, seed, hub=None, slope=0.05):
     return torch.from_numpy(ei), torch.from_numpy(et), X, R, G
 
 
+def _kink_flips(lay, p64, X64, R64, ei, et, Xg, Rg):
+    """Number of attention pre-activations h_e[k] whose SIGN differs between the fp32 tables on the GPU and the
+    float64 oracle.  The forward is continuous across the LeakyReLU kink, the gradient is not (slope 1 vs 0.05): with
+    E*d ~ 10^6 values of O(1) and fp32 rounding ~1e-6, an element landing on the other side is a matter of chance,
+    and where it happens the two gradients legitimately differ (measured: fp32-CPU vs f64 differ by 2e-2 in one
+    gradient at d=512).  Such cases are compared at a looser gradient tolerance; the forward tolerance never changes."""
+    d = X64.shape[1]
+    with torch.no_grad():
+        rel32 = lay.transform_relations(Rg)
+        PQZ, RR, _, dp = lay._tables(Xg, rel32)
+        dst, src = ei[0].cuda(), ei[1].cuda()
+        h32 = (PQZ[dst, :d] + PQZ[src, dp:dp + d] - RR[et.cuda(), :d]).cpu()
+        rel64 = orc.transform_relations(p64, R64, 0.05, "leaky_relu")
+        wt, wb = p64["w_att"][:d], p64["w_att"][d:]
+        h64 = (X64 @ wt)[ei[0]] + (X64 @ wb)[ei[1]] - (rel64 @ wb)[et]
+    return int(((h32 > 0) != (h64 > 0)).sum())
+
+
 @pytest.mark.parametrize("n,nr,d,e,hub,chunk", [
     (600, 25, 300, 5000, 700, 64),      # d=300 (BASELINE dim), a hub split into 11 chunks
     (500, 17, 256, 4000, 300, 128),     # d=256 (reference default)
@@ -105,12 +123,15 @@ def test_layer_matches_oracle_random(n, nr, d, e, hub, chunk, mode):
     out = lay(Xg, Rg, ei.cuda(), et.cuda())
     assert_close(out, ref, RTOL, 1e-6, "out")
     (out * G.cuda()).sum().backward()
-    assert_close(Xg.grad, Xc.grad, RTOL, 1e-6, "grad_X")
-    assert_close(Rg.grad, Rc.grad, RTOL, 1e-6, "grad_R")
+    flips = _kink_flips(lay, {k: v.detach() for k, v in p.items()}, Xc.detach(), Rc.detach(), ei, et, Xg.detach(), Rg.detach())
+    assert flips <= 3, flips                                         # a handful at most out of e*d pre-activations
+    grtol = RTOL if flips == 0 else 5e-2                             # see _kink_flips (one flip moved grad w_att by 1.4 %)
+    assert_close(Xg.grad, Xc.grad, grtol, 1e-6, "grad_X")
+    assert_close(Rg.grad, Rc.grad, grtol, 1e-6, "grad_R")
     gscale = Rc.grad.abs().max().item()
     for name, prm in lay.named_parameters():
         atol = 1e-4 * gscale + 1e-6 if name == "loop_rel" else 1e-6
-        assert_close(prm.grad, p[name].grad, RTOL, atol, "grad " + name)
+        assert_close(prm.grad, p[name].grad, grtol, atol, "grad " + name)
 
 
 def test_deterministic_backward_is_bitwise_reproducible():
