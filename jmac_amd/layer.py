@@ -31,6 +31,46 @@ def _identity(x):
     return x
 
 
+def _wcat(w_att, gcn_weight, d_in, d, dp):
+    """[Wt | Wb | Wgcn] as one [d_in, 3dp] matrix (w_att = [Wt; Wb] stacked by rows, src/jmac_model.py:24,75-76)."""
+    wt, wb, wg = w_att[:d_in], w_att[d_in:], gcn_weight
+    if dp != d:
+        wt, wb, wg = (F.pad(w, (0, dp - d)) for w in (wt, wb, wg))
+    return torch.cat([wt, wb, wg], dim=1)
+
+
+class _ProjectTables(torch.autograd.Function):
+    """[P|Q|Z] = X [Wt|Wb|Wg],  [Rq|Rz] = R'' [Wb|Wg]  with one hand-written backward.
+
+    Left to autograd, the slices of w_att / of the concatenated weight each cost a zero-fill, a copy and an add in
+    the backward (12 launch-bound kernels per layer at DBP-5L size); here d[Wt|Wb|Wg] is produced by one GEMM, the
+    relation term is accumulated into its column slice by the second GEMM (addmm), and the two parameter gradients
+    are cut from it."""
+
+    @staticmethod
+    def forward(ctx, ent_emb, rel, w_att, gcn_weight, dp):
+        d_in, d = gcn_weight.shape
+        wcat = _wcat(w_att, gcn_weight, d_in, d, dp)
+        ctx.save_for_backward(ent_emb, rel, wcat)
+        ctx.dims = (d_in, d, dp)
+        return torch.mm(ent_emb, wcat), RelationAwareLayer._rel_mm_nograd(rel, wcat[:, dp:])
+
+    @staticmethod
+    def backward(ctx, dPQZ, dRR):
+        ent_emb, rel, wcat = ctx.saved_tensors
+        d_in, d, dp = ctx.dims
+        need = ctx.needs_input_grad
+        d_ent = torch.mm(dPQZ, wcat.t()) if need[0] else None
+        d_rel = RelationAwareLayer._rel_mm_nograd(dRR, wcat[:, dp:].t()) if need[1] else None
+        d_watt = d_gcn = None
+        if need[2] or need[3]:
+            dw = torch.mm(ent_emb.t(), dPQZ)                           # [d_in, 3dp]
+            dw[:, dp:].addmm_(rel.t(), dRR)                            # relation rows see [Wb|Wg] only
+            d_watt = torch.cat([dw[:, :d], dw[:, dp:dp + d]], dim=0)   # back to the [2 d_in, d] stacking
+            d_gcn = dw[:, 2 * dp:2 * dp + d]
+        return d_ent, d_rel, d_watt, d_gcn, None
+
+
 class RelationAwareLayer(nn.Module):
     """ctor ``(in_channels, out_channels, rel_dim, act, args)`` reading ``args.leaky_relu_w`` and
     ``args.comp_op`` (src/jmac_model.py:14-30)."""
@@ -59,6 +99,13 @@ class RelationAwareLayer(nn.Module):
 
     # -- pieces ---------------------------------------------------------------------------------
     @staticmethod
+    def _rel_mm_nograd(a, b):
+        """_rel_mm inside a hand-written backward (no autograd graph wanted)."""
+        if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape[0] <= ops.SMALL_MM_MAX_ROWS:
+            return ops._gemm_any(a, b)
+        return torch.mm(a, b)
+
+    @staticmethod
     def _rel_mm(a, b):
         """Products on the relation table (~10^3 rows): the library GEMM is launch/occupancy bound there."""
         if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape[0] <= ops.SMALL_MM_MAX_ROWS:
@@ -75,18 +122,17 @@ class RelationAwareLayer(nn.Module):
         """P|Q|Z and Rq|Rz, zero-padded to a multiple of 4 columns for 16-byte rows."""
         d_in, d = self.in_channels, self.out_channels
         dp = (d + 3) // 4 * 4
-        wt, wb, wg = self.w_att[:d_in], self.w_att[d_in:], self.gcn_weight
         a = self.a_att.reshape(-1)
         if dp != d:
-            pad = lambda w: F.pad(w, (0, dp - d))
-            wt, wb, wg, a = pad(wt), pad(wb), pad(wg), F.pad(a, (0, dp - d))
-        wcat = torch.cat([wt, wb, wg], dim=1)                             # [d_in, 3dp]
+            a = F.pad(a, (0, dp - d))
         if self.table_dtype == torch.bfloat16:
-            if torch.is_grad_enabled() and (ent_emb.requires_grad or wcat.requires_grad):
+            if torch.is_grad_enabled() and (ent_emb.requires_grad or self.w_att.requires_grad):
                 raise RuntimeError("table_dtype=bfloat16 is the inference form of the layer: call it under torch.no_grad()")
-            wcat, ent_emb, rel = wcat.to(torch.bfloat16), ent_emb.to(torch.bfloat16), rel.to(torch.bfloat16)
-        PQZ = torch.mm(ent_emb, wcat)                                     # [N, 3dp]
-        RR = self._rel_mm(rel, wcat[:, dp:])                              # [nr+1, 2dp]
+            wcat = _wcat(self.w_att, self.gcn_weight, d_in, d, dp).to(torch.bfloat16)
+            PQZ = torch.mm(ent_emb.to(torch.bfloat16), wcat)              # [N, 3dp]
+            RR = torch.mm(rel.to(torch.bfloat16), wcat[:, dp:])           # [nr+1, 2dp]
+            return PQZ, RR, a.float(), dp
+        PQZ, RR = _ProjectTables.apply(ent_emb, rel, self.w_att, self.gcn_weight, dp)
         return PQZ, RR, a.float(), dp
 
     def pre_bn(self, ent_emb, rel_emb, edge_index, edge_type):

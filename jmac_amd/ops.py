@@ -285,6 +285,19 @@ class _SmallMM(torch.autograd.Function):
         return dA, dB
 
 
+def _gemm_any(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """A @ B on jmac_gemm_f32 for operands that may be transposed views (``x.t()`` is passed as a transposed operand,
+    not copied)."""
+    def operand(t):
+        if t.stride(1) == 1:
+            return t, False
+        if t.stride(0) == 1:
+            return t.t(), True                                   # stored [cols, rows] row-major
+        return t.contiguous(), False
+    (a, ta), (b, tb) = operand(A), operand(B)
+    return _gemm(a, ta, b, tb, A.shape[0], B.shape[1], A.shape[1])
+
+
 SMALL_MM_MAX_ROWS = 4096     # the relation tables of DBP-5L (962 rows per KG, 4806 for the union) and OpenEA (2 x num_rel)
 
 

@@ -1,0 +1,20 @@
+import csv, collections, sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+adam=[i for i,r in enumerate(rows) if 'multi_tensor_apply' in r['Kernel_Name'] and 'FusedOptimizer' in r['Kernel_Name']]
+a,b=adam[-21],adam[-1]
+win=rows[a+1:b+1]
+tot=collections.Counter(); cnt=collections.Counter()
+for r in win:
+    n=r['Kernel_Name']; d=int(r['End_Timestamp'])-int(r['Start_Timestamp'])
+    tot[n]+=d; cnt[n]+=1
+busy=sum(tot.values())/20
+span=(int(rows[b]['End_Timestamp'])-int(rows[a]['End_Timestamp']))/20
+print("span us %.1f busy us %.1f kernels/step %.1f"%(span/1e3, busy/1e3,len(win)/20))
+groups=collections.Counter()
+for n,t in tot.items():
+    g = "gemm(lib)" if n.startswith("Cijk") else ("jmac" if "anonymous namespace" in n and "at::native" not in n else "torch-elementwise")
+    groups[g]+=t/20/1e3
+print(dict(groups))
+for n,t in tot.most_common(int(sys.argv[2]) if len(sys.argv)>2 else 30):
+    print("%8.1f us  x%5.1f  %s"%(t/20/1e3,cnt[n]/20,n[:110]))
