@@ -381,11 +381,13 @@ def main():
             init_dist()
         from bench_dist import run_sharded          # destination-sharded synthetic graph, RCCL all-gather
         line = run_sharded(a, rank, world, device)
-        if rank == 0:
-            print(json.dumps(line))
         if dist_on:
             import torch.distributed as dist
+            dist.barrier()
             dist.destroy_process_group()
+        if rank == 0:                                   # after the teardown: RCCL's banner lines come first
+            sys.stdout.flush()
+            print(json.dumps(line), flush=True)
         return
 
     # Default workload at any N: one DBP-5L-ja-shaped KG per GPU.  Graphs of this size do not shard
@@ -437,9 +439,11 @@ def main():
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "traffic": pmc_traffic("ja", "rel_attn_fwd_kernel") if w.d == 300 else None,
                                 "algorithmic_bytes_per_launch": fb, "avg_launch_ms": fms}
-            print(json.dumps(line))
         dist.barrier()
         dist.destroy_process_group()
+        if rank == 0:                                   # after the teardown: RCCL's banner lines come first
+            sys.stdout.flush()
+            print(json.dumps(line), flush=True)
         return
 
     from jmac_amd import synth
