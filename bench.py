@@ -267,8 +267,13 @@ def scoring_bench(w, iters=10):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / iters
     m.train()
+    # the L1 kernel issues 2 full-rate VALU instructions per (b, n, k): v_sub_f32 and v_add_f32 with the |.| source
+    # modifier (|.| has no packed form).  Issue peak = 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s;
+    # 157.3 TFLOP/s is the packed-FMA figure (4 flops per lane slot) that SURVEY 8d's "3 ops per element" is priced against.
+    elems = float(B) * w.N * w.d * 2
     return {"scored_triples_per_s": B / dt, "pair_scores_per_s": B * w.N * 2 / dt, "ms_per_batch": dt * 1e3,
-            "B": B, "N": w.N, "layers": 2, "valu_frac_of_peak": (3.0 * B * w.N * w.d * 2 / dt) / 157.3e12}
+            "B": B, "N": w.N, "layers": 2, "valu_frac_of_peak": (3.0 * elems / dt) / 157.3e12,
+            "valu_issue_frac": (2.0 * elems / dt) / 39.3e12}
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md)
