@@ -298,7 +298,11 @@ def _gemm_any(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return _gemm(a, ta, b, tb, A.shape[0], B.shape[1], A.shape[1])
 
 
-SMALL_MM_MAX_ROWS = 4096     # the relation tables of DBP-5L (962 rows per KG, 4806 for the union) and OpenEA (2 x num_rel)
+# Row bound below which the layer routes its relation-side products (962 rows per DBP-5L KG) through small_mm.
+# 0 = off (default): measured inside the training step the kernel takes 10.5-15 us per product against the library's
+# 17 us untuned -- and 8-9 us once torch's TunableOp has picked the library kernel for the shape (bench.py turns it
+# on), so the library keeps these.  The op stays available (deterministic summation order, any strides / transposes).
+SMALL_MM_MAX_ROWS = 0
 
 
 def small_mm(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
