@@ -43,9 +43,15 @@ def enable_gemm_tuning(rank):
         tun.tuning_enable(True)
         tun.set_max_tuning_duration(30)
         tun.set_max_tuning_iterations(10)
-        tun.set_filename("/tmp/jmac_tunableop_rank%d.csv" % rank)
+        fn = os.environ.get("JMAC_TUNABLEOP_FILE", "/tmp/jmac_tunableop_rank%d.csv" % rank)
+        tun.set_filename(fn)
         if hasattr(tun, "write_file_on_exit"):
             tun.write_file_on_exit(False)
+        if os.path.exists(fn):                           # a previous run's selections (e.g. before a profiled run)
+            try:
+                tun.read_file(fn)
+            except Exception:
+                pass
         return True
     except Exception as ex:                              # pragma: no cover
         sys.stderr.write("TunableOp unavailable (%s)\n" % (ex,))
@@ -56,6 +62,10 @@ def freeze_gemm_tuning():
     try:
         import torch.cuda.tunable as tun
         tun.tuning_enable(False)                         # keep using the selected kernels, tune nothing new
+        try:
+            tun.write_file(tun.get_filename())
+        except Exception:
+            pass
     except Exception:                                    # pragma: no cover
         pass
 
