@@ -451,6 +451,47 @@ def aggregate_from_tables(PQZ: Tensor, RR: Tensor, a: Tensor, edge_index: Tensor
 
 
 # --------------------------------------------------------------------------------------------
+# DBPv1 model (row a17): JMAC_DBPv1/models/jmac_model.py:151-277
+# --------------------------------------------------------------------------------------------
+def dbpv1_forward_base(params: Dict[str, Tensor], info: Tensor, edge_index: Tensor, edge_type: Tensor, num_gcn_layer: int = 2,
+                       slope: float = 0.05, training: bool = False, bn_state: Optional[Dict[str, Tensor]] = None):
+    """JMAC_MODEL.forward_base, :151-178, dropout off; the layers use ReLU between the relation transforms (:51)."""
+    bn_state = bn_state if bn_state is not None else {}
+
+    def conv(name, x, r):
+        return layer_forward(_sub(params, name), x, r, edge_index, edge_type, slope, "sub", "relu", training,
+                             bn_state.get(name + ".bn.running_mean"), bn_state.get(name + ".bn.running_var"))
+    ent, relc, reli = params["ent_completion_att"], params["rel_completion_att"], params["rel_info_att"]
+    a0 = torch.cat((F.normalize(ent, p=2, dim=-1), info), dim=1) @ params["align_linear1_1"]
+    a1 = conv("conv1_align", a0, reli)
+    align_layers, comp_layers, rel_layers = [a0, a1], [ent], [relc]
+    if num_gcn_layer == 2:
+        c1 = conv("conv1_completion", ent, relc)
+        a_in = torch.cat((F.normalize(c1), a1), dim=1) @ params["align_linear2_1"]
+        rel_c1 = F.leaky_relu(relc @ params["rel_linear11"], slope) @ params["rel_linear12"]
+        rel_a = F.leaky_relu(reli @ params["rel_linear11_align"], slope) @ params["rel_linear12_align"]
+        a2 = conv("conv2_align", a_in, rel_a)
+        align_layers.append(a2)
+        comp_layers.append(c1)
+        rel_layers.append(rel_c1)
+    return torch.cat(align_layers, dim=1) @ params["all_linear_comp"], comp_layers, rel_layers
+
+
+def dbpv1_completion_loss(comp, rel, batch_h, batch_r, batch_t, links, batch_size: int, margin: float):
+    """:235-277: rows L2-normalised before the L1 score; alignment_loss_simple on one table."""
+    links = torch.as_tensor(np.asarray(links), dtype=torch.long)
+    loss = 0
+    for ent, rl in zip(comp, rel):
+        h, t, r = F.normalize(ent[batch_h], 2, -1), F.normalize(ent[batch_t], 2, -1), F.normalize(rl[batch_r], 2, -1)
+        score = torch.norm((h + r) - t, 1, -1).flatten()
+        pos = score[:batch_size].view(-1, min(batch_size, len(score[:batch_size]))).permute(1, 0)
+        neg = score[batch_size:].view(-1, min(batch_size, len(score[batch_size:]))).permute(1, 0)
+        m = torch.tensor([margin], dtype=score.dtype)
+        loss = loss + torch.max(pos - neg, -m).mean() + m + pair_cosine_distance(ent, links[:, 0], ent, links[:, 1]).mean()
+    return loss
+
+
+# --------------------------------------------------------------------------------------------
 # EnTr bookkeeping (next row f4): train.py:297-325
 # --------------------------------------------------------------------------------------------
 def transfer_knowledge(triples_src, triples_dst, pairs, keys1: set, keys2: set):

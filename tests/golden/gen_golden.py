@@ -440,6 +440,66 @@ def gen_dataset():
     _save("dbp5l_mini", **out)
 
 
+def gen_dbpv1_model():
+    """Model-level fixture of the DBPv1 variant (row a17): JMAC_DBPv1/models/jmac_model.py:116-277 JMAC_MODEL on one
+    merged graph with inverse edges (jmac_trainer.py:93-96): forward_base, get_emb, completion_loss (rows L2-normalised
+    before the L1 score, :245-247), alignment_loss, with grads."""
+    from models.jmac_model import JMAC_MODEL
+    rng = np.random.default_rng(91)
+    torch.manual_seed(19)
+    n, nrel, d = 150, 7, 40
+    args = types.SimpleNamespace(emb_dim=d, completion_dropout_rate=0.0, leaky_relu_w=0.05, opn="sub", num_gcn_layer=2,
+                                 num_negative=4, margin_align=1.0, margin_completion=5.0, completion_batch_size=30)
+    info = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32))
+    model = JMAC_MODEL(n, nrel, info, args)
+    tr = np.unique(np.stack([rng.integers(0, n, 500), rng.integers(0, nrel, 500), rng.integers(0, n, 500)], 1), axis=0)
+    # inverse edges get relation id r + num_rel (jmac_trainer.py:93-96)
+    ei = np.stack([np.concatenate([tr[:, 0], tr[:, 2]]), np.concatenate([tr[:, 2], tr[:, 0]])]).astype(np.int64)
+    et = np.concatenate([tr[:, 1], tr[:, 1] + nrel]).astype(np.int64)
+    eit, ett = torch.from_numpy(ei), torch.from_numpy(et)
+    model.train()
+    with torch.no_grad():
+        for _ in range(2):
+            model.forward_base(eit, ett)
+    arrays = {"n": n, "nrel": nrel, "d": d, "edge_index": ei, "edge_type": et, "ent_info_att": _np(info)}
+    model.eval()
+    for k, v in model.state_dict().items():
+        arrays["state." + k] = _np(v)
+    with torch.no_grad():
+        a, comp, rel = model.forward_base(eit, ett)
+        ga, gc = model.get_emb(eit, ett, pyt=True)
+    arrays.update(align=_np(a), comp_l0=_np(comp[0]), comp_l1=_np(comp[1]), rel_l0=_np(rel[0]), rel_l1=_np(rel[1]),
+                  emb_align=_np(ga), emb_comp=_np(gc))
+    model.train()
+    B, K = args.completion_batch_size, args.num_negative
+    trip = torch.from_numpy(tr[:B].astype(np.int64))
+    neg = torch.from_numpy(rng.integers(0, n, (B, K)).astype(np.int64))
+    data = {"batch_h": trip[:, 0].repeat(K + 1), "batch_r": trip[:, 1].repeat(K + 1),
+            "batch_t": torch.cat((trip[:, 2], neg.view(-1)))}
+    links = np.stack([rng.permutation(n // 2)[:20], n // 2 + rng.permutation(n // 2)[:20]], 1)
+    feed = {"links": links,
+            "neg_left": np.repeat(links[:, 0], K), "neg_right": torch.from_numpy(rng.integers(0, n, 20 * K)),
+            "neg2_left": torch.from_numpy(rng.integers(0, n, 20 * K)), "neg2_right": np.repeat(links[:, 1], K)}
+    bn_before = {k: _np(v) for k, v in model.state_dict().items() if "running" in k}
+    model.zero_grad()
+    closs = model.completion_loss(data, eit, ett, feed)
+    closs.backward()
+    arrays.update(batch_h=_np(data["batch_h"]), batch_r=_np(data["batch_r"]), batch_t=_np(data["batch_t"]), links=links,
+                  neg_left=feed["neg_left"], neg_right=_np(feed["neg_right"]), neg2_left=_np(feed["neg2_left"]),
+                  neg2_right=feed["neg2_right"], completion_loss=np.float64(closs.item()),
+                  closs_grad_ent=_np(model.ent_completion_att.grad), closs_grad_rel=_np(model.rel_completion_att.grad),
+                  closs_grad_w_att=_np(model.conv1_completion.w_att.grad))
+    for k, v in bn_before.items():
+        arrays["bn_before." + k] = v
+    model.load_state_dict({**model.state_dict(), **{k: torch.from_numpy(v) for k, v in bn_before.items()}})
+    model.zero_grad()
+    aloss = model.alignment_loss(feed, eit, ett)
+    aloss.backward()
+    arrays.update(alignment_loss=np.float64(aloss.item()), aloss_grad_ent=_np(model.ent_completion_att.grad),
+                  aloss_grad_all_linear=_np(model.all_linear_comp.grad), aloss_grad_rel_info=_np(model.rel_info_att.grad))
+    _save("model_dbpv1", **arrays)
+
+
 def gen_dbpv1():
     from models.jmac_model import RelationalAwareLayer
     args = types.SimpleNamespace(leaky_relu_w=0.05, opn="sub")
@@ -448,6 +508,7 @@ def gen_dbpv1():
     print("layer fixture (reference: JMAC_DBPv1/models/jmac_model.py RelationalAwareLayer)")
     ei, et = random_graph(rng, 180, 14, 800)
     _save("layer_dbpv1", **run_layer_case(RelationalAwareLayer, mk, "dbpv1", 180, 14, 40, ei, et, 8))
+    gen_dbpv1_model()
 
 
 if __name__ == "__main__":

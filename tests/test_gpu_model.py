@@ -71,3 +71,48 @@ def test_losses_and_grads():
     assert_close(m.name_linear.grad, g["aloss_grad_name_linear"], 1e-4, 1e-7)
     assert_close(m.conv2_alignment.gcn_weight.grad, g["aloss_grad_conv2_gcn"], 1e-4, 1e-7)
     assert_close(m.ent_init_att_completion.grad, g["aloss_grad_ent"], 1e-4, 1e-7)
+
+
+# ---- DBPv1 variant (row a17): JMAC_DBPv1/models/jmac_model.py JMAC_MODEL ---------------------------------------
+def _dbpv1(g, with_bn_before=False):
+    import types
+    from jmac_amd.model_dbpv1 import JMAC_MODEL
+    args = types.SimpleNamespace(emb_dim=int(g["d"]), completion_dropout_rate=0.0, leaky_relu_w=0.05, opn="sub",
+                                 num_gcn_layer=2, num_negative=4, margin_align=1.0, margin_completion=5.0,
+                                 completion_batch_size=30)
+    m = JMAC_MODEL(int(g["n"]), int(g["nrel"]), g["ent_info_att"], args)
+    sd = {k[len("state."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("state.")}
+    if with_bn_before:
+        for k in list(sd):
+            if ("bn_before." + k) in g:
+                sd[k] = torch.from_numpy(g["bn_before." + k])
+    m.load_state_dict(sd, strict=True)                                   # reference checkpoint loads as is
+    return m.cuda()
+
+
+def test_dbpv1_model_matches_reference_golden():
+    g = load_golden("model_dbpv1")
+    ei, et = t(g["edge_index"], "cuda"), t(g["edge_type"], "cuda")
+    m = _dbpv1(g).eval()
+    with torch.no_grad():
+        a, comp, rel = m.forward_base(ei, et)
+        assert_close(a, g["align"], 1e-4) and assert_close(comp[1], g["comp_l1"], 1e-4) and assert_close(rel[1], g["rel_l1"], 1e-4)
+        ea, ec = m.get_emb(ei, et, pyt=True)
+        assert_close(ea, g["emb_align"], 1e-4) and assert_close(ec, g["emb_comp"], 1e-4)
+    feed = {"links": g["links"], "neg_left": g["neg_left"], "neg_right": t(g["neg_right"]), "neg2_left": t(g["neg2_left"]),
+            "neg2_right": g["neg2_right"]}
+    data = {"batch_h": t(g["batch_h"], "cuda"), "batch_r": t(g["batch_r"], "cuda"), "batch_t": t(g["batch_t"], "cuda")}
+    m = _dbpv1(g, with_bn_before=True).train()
+    loss = m.completion_loss(data, ei, et, feed)
+    assert abs(loss.item() - float(g["completion_loss"])) < 1e-4 * abs(float(g["completion_loss"]))
+    loss.backward()
+    assert_close(m.ent_completion_att.grad, g["closs_grad_ent"], 1e-4, 1e-7)
+    assert_close(m.rel_completion_att.grad, g["closs_grad_rel"], 1e-4, 1e-7)
+    assert_close(m.conv1_completion.w_att.grad, g["closs_grad_w_att"], 1e-4, 1e-7)
+    m = _dbpv1(g, with_bn_before=True).train()
+    al = m.alignment_loss(feed, ei, et)
+    assert abs(al.item() - float(g["alignment_loss"])) < 1e-4 * abs(float(g["alignment_loss"]))
+    al.backward()
+    assert_close(m.ent_completion_att.grad, g["aloss_grad_ent"], 1e-4, 1e-7)
+    assert_close(m.all_linear_comp.grad, g["aloss_grad_all_linear"], 1e-4, 1e-7)
+    assert_close(m.rel_info_att.grad, g["aloss_grad_rel_info"], 1e-4, 1e-7)

@@ -150,3 +150,29 @@ def test_alignment_eval_matches_reference():
         assert abs(mr - float(g["mr_csls%d" % k])) < 1e-9 and abs(mrr - float(g["mrr_csls%d" % k])) < 1e-9
         # the reference's np.partition-based neighbourhood mean may swap the k-th for the (k+1)-th neighbour
         assert np.abs(s.numpy() - g["sim_csls%d" % k]).max() < (1e-6 if k == 0 else 2e-2)
+
+
+def test_dbpv1_model_oracle_matches_reference_golden():
+    """Row a17: the oracle's restatement of JMAC_DBPv1's JMAC_MODEL (forward_base, get_emb, completion_loss with
+    L2-normalised rows) against the reference's captured outputs."""
+    g = load_golden("model_dbpv1")
+    p = {k[len("state."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("state.")}
+    bn = {k: v.clone() for k, v in p.items() if "running" in k}
+    ei, et = torch.from_numpy(g["edge_index"]), torch.from_numpy(g["edge_type"])
+    info = torch.from_numpy(g["ent_info_att"])
+    a, comp, rel = orc.dbpv1_forward_base(p, info, ei, et, 2, 0.05, False, bn)
+    for got, key in ((a, "align"), (comp[1], "comp_l1"), (rel[1], "rel_l1")):
+        assert (got - torch.from_numpy(g[key])).abs().max().item() <= 2e-6 * max(1.0, float(np.abs(g[key]).max()))
+    ea, ec = orc.get_emb(a, comp)
+    assert (ea - torch.from_numpy(g["emb_align"])).abs().max().item() < 2e-6
+    assert (ec - torch.from_numpy(g["emb_comp"])).abs().max().item() < 2e-6
+    # completion loss in train mode from the BN state the reference started from
+    pb = dict(p)
+    for k in list(pb):
+        if ("bn_before." + k) in g:
+            pb[k] = torch.from_numpy(g["bn_before." + k])
+    bnb = {k: v.clone() for k, v in pb.items() if "running" in k}
+    _, comp_t, rel_t = orc.dbpv1_forward_base(pb, info, ei, et, 2, 0.05, True, bnb)
+    loss = orc.dbpv1_completion_loss(comp_t, rel_t, torch.from_numpy(g["batch_h"]), torch.from_numpy(g["batch_r"]),
+                                     torch.from_numpy(g["batch_t"]), g["links"], 30, 5.0)
+    assert abs(float(loss) - float(g["completion_loss"])) < 2e-6 * abs(float(g["completion_loss"]))
