@@ -172,7 +172,7 @@ constexpr int SG_SUPER = 8;                 // super-tile of 8x8 tiles per XCD v
 
 __global__ __launch_bounds__(kBlock) void sim_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
                                                           int64_t ldb, int M, int N, int d, float* __restrict__ C, int64_t ldc,
-                                                          int tiles_m, int tiles_n, int super_order) {
+                                                          int tiles_m, int tiles_n, int super_order, int n_ids) {
     // LDS image of one operand slab (16 k): plane (q, h) holds, for every tile row, the 4 floats k = 8q + 4h .. +3.
     // Lane (r = l&31, h = l>>5) of a wave reads its float4 of row r from plane (q, h): 32 lanes x 16 B contiguous,
     // conflict free for ds_read_b128's lane groups.  The MFMA step s of a sub-slab contracts k = {8q+s, 8q+4+s}.
@@ -181,36 +181,34 @@ __global__ __launch_bounds__(kBlock) void sim_gemm_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;           // wave grid 2 x 2, each wave 64 x 64
 
-    // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so ids {x, x+8, x+16, ...} share one L2.
-    // Those ids walk ONE super-tile of SG_SUPER x SG_SUPER tiles before moving on: its A and B panels stay L2-resident.
-    int tm, tn;
-    if (super_order) {
-        const int id = blockIdx.x;
-        const int sup_n = (tiles_n + SG_SUPER - 1) / SG_SUPER, sup_m = (tiles_m + SG_SUPER - 1) / SG_SUPER;
-        const int per = SG_SUPER * SG_SUPER;
-        const int xcd = id & 7, local = id >> 3;
-        const int sup = (local / per) * 8 + xcd, within = local % per;
-        if (sup >= sup_m * sup_n) return;
-        tm = (sup / sup_n) * SG_SUPER + within / SG_SUPER;
-        tn = (sup % sup_n) * SG_SUPER + within % SG_SUPER;
-        if (tm >= tiles_m || tn >= tiles_n) return;
-    } else {                                       // few tiles: plain row-major order, every XCD busy
-        tm = blockIdx.x / tiles_n;
-        tn = blockIdx.x % tiles_n;
-    }
-    const int m0 = tm * SG_T, n0 = tn * SG_T;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // Tile ids are walked persistently: block b takes ids b, b + gridDim, ... (gridDim is a multiple of 8, so a block's
+    // ids stay on its XCD).  XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs, so ids {x, x+8, ...}
+    // share one L2; those ids walk ONE super-tile of SG_SUPER x SG_SUPER tiles before moving on: its A and B panels
+    // stay L2-resident.  Ids that fall outside the matrix (ragged super-tiles) are skipped.
+    auto tile_of = [&](int id, int& tm, int& tn) -> bool {
+        if (super_order) {
+            const int sup_n = (tiles_n + SG_SUPER - 1) / SG_SUPER, sup_m = (tiles_m + SG_SUPER - 1) / SG_SUPER;
+            const int per = SG_SUPER * SG_SUPER;
+            const int xcd = id & 7, local = id >> 3;
+            const int sup = (local / per) * 8 + xcd, within = local % per;
+            if (sup >= sup_m * sup_n) return false;
+            tm = (sup / sup_n) * SG_SUPER + within / SG_SUPER;
+            tn = (sup % sup_n) * SG_SUPER + within % SG_SUPER;
+            return tm < tiles_m && tn < tiles_n;
+        }
+        tm = id / tiles_n;                           // few tiles: plain row-major order, every XCD busy
+        tn = id % tiles_n;
+        return true;
+    };
+    auto next_tile = [&](int id, int& tm, int& tn) -> int {     // first valid id >= id, or n_ids
+        while (id < n_ids && !tile_of(id, tm, tn)) id += gridDim.x;
+        return id < n_ids ? id : n_ids;
+    };
 
     // loader: float4 f = tid + 256 i (i < 2): row = f / 4, k quad kq = f % 4 (4 consecutive lanes read 64 contiguous
     // bytes of a row).  Every load is unconditional at a clamped address (a load behind an exec-mask branch is not
     // overlapped with the MFMAs): rows past the end re-read the last row -- they only feed outputs that are never
-    // stored -- and float4s past d (d % 4 == 0, enforced by the launcher) are zeroed after the load.
+    // stored -- and float4s past d (d % 4 == 0, enforced by the launcher) are zeroed at store time.
     auto gload = [&](const float* base, int64_t ld, int row0, int nrows, int k0, float4 (&v)[2]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -236,6 +234,7 @@ __global__ __launch_bounds__(kBlock) void sim_gemm_kernel(const float* __restric
             bf[i] = *reinterpret_cast<const float4*>(Bs[buf] + q * 2 * SG_PLANE + boff + i * 32 * 4);
         }
     };
+    f32x16 acc[2][2];
     // the four accumulators rotate (dependency distance 4)
     auto mfma16 = [&](const float4 (&af)[2], const float4 (&bf)[2]) {
 #define JMAC_SG_STEP(c)                                                                                   \
@@ -250,60 +249,83 @@ __global__ __launch_bounds__(kBlock) void sim_gemm_kernel(const float* __restric
 #undef JMAC_SG_STEP
     };
 
-    // Software pipeline, one barrier per slab.  At the top of slab kt: fragment set 0 holds (kt, q=0), the staging
-    // registers hold slab kt+1 (loads in flight).  The q=0 MFMAs cover the q=1 fragment reads and the LDS stores of
-    // slab kt+1; the q=1 MFMAs cover the first fragment reads of slab kt+1 and the global loads of slab kt+2.
     const int nk = (d + SG_K - 1) / SG_K;
     float4 ra[2], rb[2], af0[2], bf0[2], af1[2], bf1[2];
-    gload(A, lda, m0, M, 0, ra);
-    gload(Bm, ldb, n0, N, 0, rb);
-    sstore(As[0], ra, 0);
-    sstore(Bs[0], rb, 0);
-    if (nk > 1) {
-        gload(A, lda, m0, M, SG_K, ra);
-        gload(Bm, ldb, n0, N, SG_K, rb);
-    }
-    __syncthreads();
-    frags(0, 0, af0, bf0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        frags(cur, 1, af1, bf1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma16(af0, bf0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) {
-            sstore(As[cur ^ 1], ra, (kt + 1) * SG_K);
-            sstore(Bs[cur ^ 1], rb, (kt + 1) * SG_K);
-            if (kt + 2 < nk) {
-                gload(A, lda, m0, M, (kt + 2) * SG_K, ra);
-                gload(Bm, ldb, n0, N, (kt + 2) * SG_K, rb);
-            }
+    int tm, tn;
+    int id = next_tile(blockIdx.x, tm, tn);
+    if (id >= n_ids) return;
+    gload(A, lda, tm * SG_T, M, 0, ra);
+    gload(Bm, ldb, tn * SG_T, N, 0, rb);
+    while (id < n_ids) {
+        const int m0 = tm * SG_T, n0 = tn * SG_T;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+        // Software pipeline, one barrier per slab.  At the top of slab kt: fragment set 0 holds (kt, q=0), the staging
+        // registers hold slab kt+1 (loads in flight).  The q=0 MFMAs cover the q=1 fragment reads and the LDS stores of
+        // slab kt+1; the q=1 MFMAs cover the first fragment reads of slab kt+1 and the global loads of slab kt+2.
+        sstore(As[0], ra, 0);
+        sstore(Bs[0], rb, 0);
+        if (nk > 1) {
+            gload(A, lda, m0, M, SG_K, ra);
+            gload(Bm, ldb, n0, N, SG_K, rb);
         }
         __syncthreads();
-        if (kt + 1 < nk) frags(cur ^ 1, 0, af0, bf0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma16(af1, bf1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const bool full = m0 + SG_T <= M && n0 + SG_T <= N;      // block-uniform: interior tiles store without bounds tests
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float* cbase = C + (int64_t)(m0 + wm * 64 + i * 32 + 4 * h) * ldc + (n0 + wn * 64 + j * 32 + r);
-            if (full) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) cbase[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg];
-            } else {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int64_t m = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    const int64_t n = n0 + wn * 64 + j * 32 + r;
-                    if (m < M && n < N) C[m * ldc + n] = acc[i][j][reg];
+        frags(0, 0, af0, bf0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            frags(cur, 1, af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) {
+                sstore(As[cur ^ 1], ra, (kt + 1) * SG_K);
+                sstore(Bs[cur ^ 1], rb, (kt + 1) * SG_K);
+                if (kt + 2 < nk) {
+                    gload(A, lda, m0, M, (kt + 2) * SG_K, ra);
+                    gload(Bm, ldb, n0, N, (kt + 2) * SG_K, rb);
                 }
             }
+            __syncthreads();
+            if (kt + 1 < nk) frags(cur ^ 1, 0, af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // the next tile's first slab is requested BEFORE this tile's 64 KB of results are stored: the stores and the
+        // loads overlap, and no wave reads LDS any more (the last fragment reads precede the last barrier)
+        int ntm = 0, ntn = 0;
+        const int nid = next_tile(id + gridDim.x, ntm, ntn);
+        if (nid < n_ids) {
+            gload(A, lda, ntm * SG_T, M, 0, ra);
+            gload(Bm, ldb, ntn * SG_T, N, 0, rb);
+        }
+        // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        const bool full = m0 + SG_T <= M && n0 + SG_T <= N;      // block-uniform: interior tiles store without bounds tests
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float* cbase = C + (int64_t)(m0 + wm * 64 + i * 32 + 4 * h) * ldc + (n0 + wn * 64 + j * 32 + r);
+                if (full) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) cbase[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg];
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int64_t m = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        const int64_t n = n0 + wn * 64 + j * 32 + r;
+                        if (m < M && n < N) C[m * ldc + n] = acc[i][j][reg];
+                    }
+                }
+            }
+        id = nid;
+        tm = ntm;
+        tn = ntn;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -556,11 +578,24 @@ int launch_sim(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t
     const int tiles_m = (int)((M + SG_T - 1) / SG_T), tiles_n = (int)((N + SG_T - 1) / SG_T);
     const int64_t sup = (int64_t)((tiles_m + SG_SUPER - 1) / SG_SUPER) * ((tiles_n + SG_SUPER - 1) / SG_SUPER);
     const int super_order = sup >= 64 ? 1 : 0;                          // >= 8 super-tiles per XCD: the tail imbalance is small
-    const int64_t blocks = super_order ? (sup + 7) / 8 * 8 * SG_SUPER * SG_SUPER : (int64_t)tiles_m * tiles_n;
-    if (blocks >= INT32_MAX) return JMAC_ERANGE;
+    const int64_t n_ids = super_order ? (sup + 7) / 8 * 8 * SG_SUPER * SG_SUPER : (int64_t)tiles_m * tiles_n;
+    if (n_ids >= INT32_MAX) return JMAC_ERANGE;
     if (d % 4) return JMAC_EDIM;
-    hipLaunchKernelGGL(sim_gemm_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, A, lda, B, ldb, (int)M, (int)N, (int)d, C, ldc,
-                       tiles_m, tiles_n, super_order);
+    // persistent: as many blocks as are resident at once (occupancy query: 3 per CU with 80 + 64 accumulation VGPRs and
+    // 33 KB of LDS), rounded down to a multiple of 8 so that a block's tile ids stay on its XCD
+    static int resident = 0;
+    if (resident == 0) {
+        int dev = 0, cus = 256, occ = 3;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(sim_gemm_kernel), kBlock, 0) != hipSuccess || occ < 1)
+            occ = 3;
+        resident = (cus * occ) / 8 * 8;
+        if (resident < 8) resident = 8;
+    }
+    const unsigned grid = (unsigned)(n_ids < resident ? n_ids : resident);
+    hipLaunchKernelGGL(sim_gemm_kernel, dim3(grid), dim3(kBlock), 0, st, A, lda, B, ldb, (int)M, (int)N, (int)d, C, ldc,
+                       tiles_m, tiles_n, super_order, (int)n_ids);
     return (int)hipGetLastError();
 }
 

@@ -91,12 +91,15 @@ def filtered_rank(dist: torch.Tensor, gold, filt_ptr: Optional[torch.Tensor] = N
     return rank
 
 
-def sim_matrix(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+def sim_matrix(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a @ b.T on the fp32-input MFMA (exact fp32 products).  ``out``: optional preallocated [M, N] fp32 result."""
     require_device(a, b)
     a, b = _rows16(a), _rows16(b)
     M, d = a.shape
     N = b.shape[0]
-    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    c = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if c.shape != (M, N) or c.dtype != torch.float32 or not c.is_contiguous():
+        raise ValueError("sim_matrix: out must be a contiguous fp32 [%d, %d] tensor" % (M, N))
     check(lib().jmac_sim_matrix_f32(ptr(a), d, ptr(b), d, M, N, d, ptr(c), N, stream()), "jmac_sim_matrix_f32")
     return c
 
