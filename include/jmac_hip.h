@@ -164,6 +164,15 @@ int jmac_bn_tanh_bwd_f32(const float* x, int64_t ldx, const float* y, int64_t ld
                          float* gx, int64_t ldgx, float* gweight, float* gbias, void* ws,
                          size_t ws_bytes, jmac_stream_t stream);
 
+/* Row L2 normalisation  y = x / max(||x||_2, eps)  (replaces F.normalize(x, 2, -1) of JMAC.forward_name and get_emb,
+ * src/jmac_model.py:179,191,227-228; eps = 1e-12 is torch's default).  inv [N] receives 1 / max(||x_r||, eps) for the
+ * backward:  gx = inv (g - y (g.y)),  or inv g on rows whose norm was clamped.  Any d and leading dimensions. */
+int jmac_row_normalize_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, float eps, float* y,
+                               int64_t ldy, float* inv, jmac_stream_t stream);
+int jmac_row_normalize_bwd_f32(const float* y, int64_t ldy, const float* g, int64_t ldg, const float* inv,
+                               int64_t N, int64_t d, float eps, float* gx, int64_t ldgx,
+                               jmac_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Completion scoring (replaces: torch.cdist(er, all_kg_emb, p=1), src/jmac_model.py:312; the
  * filter/sort/np.where ranking loop of src/validate.py:50-64).

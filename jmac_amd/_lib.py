@@ -57,6 +57,8 @@ _SIGS = {
                                        vp, sz, vp]),
     "jmac_bn_tanh_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, vp, vp, vp, i32, vp, i64, vp, vp,
                                        vp, sz, vp]),
+    "jmac_row_normalize_fwd_f32": (C.c_int, [vp, i64, i64, i64, f32, vp, i64, vp, vp]),
+    "jmac_row_normalize_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, f32, vp, i64, vp]),
     "jmac_l1_score_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, vp]),
     "jmac_l1_score_bf16": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, vp]),
     "jmac_filtered_rank_f32": (C.c_int, [vp, i64, vp, vp, vp, i64, i64, vp, vp]),

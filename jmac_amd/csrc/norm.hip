@@ -219,6 +219,43 @@ inline unsigned stream_grid(int64_t total) {
     return (unsigned)(need < 8192 ? need : 8192);
 }
 
+// ---- row L2 normalisation: y = x / max(||x||_2, eps)  (F.normalize(x, 2, -1), src/jmac_model.py:179,191,227-228) ------
+// one wave per row, scalar lane layout (any d, any 4-byte-aligned leading dimension); inv[r] = 1 / max(||x_r||, eps).
+__global__ __launch_bounds__(kBlock) void row_normalize_fwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t N, int d,
+                                                                   float eps, float* __restrict__ y, int64_t ldy,
+                                                                   float* __restrict__ inv) {
+    const int lane = lane_id();
+    const int64_t w0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t r = w0; r < N; r += nw) {
+        const float* xr = x + r * ldx;
+        float ss = 0.f;
+        for (int c = lane; c < d; c += 64) ss = fmaf(xr[c], xr[c], ss);
+        ss = wave_sum(ss);
+        const float iv = 1.f / fmaxf(sqrtf(ss), eps);
+        for (int c = lane; c < d; c += 64) y[r * ldy + c] = xr[c] * iv;
+        if (lane == 0) inv[r] = iv;
+    }
+}
+
+// gx = inv * (g - y (g.y))   where the norm exceeds eps; gx = inv * g where it was clamped (constant denominator)
+__global__ __launch_bounds__(kBlock) void row_normalize_bwd_kernel(const float* __restrict__ y, int64_t ldy,
+                                                                   const float* __restrict__ g, int64_t ldg,
+                                                                   const float* __restrict__ inv, int64_t N, int d, float eps,
+                                                                   float* __restrict__ gx, int64_t ldgx) {
+    const int lane = lane_id();
+    const int64_t w0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t r = w0; r < N; r += nw) {
+        const float* yr = y + r * ldy;
+        const float* gr = g + r * ldg;
+        float dot = 0.f;
+        for (int c = lane; c < d; c += 64) dot = fmaf(gr[c], yr[c], dot);
+        dot = wave_sum(dot);
+        const float iv = inv[r];
+        if (iv * eps >= 1.f) dot = 0.f;                // ||x|| <= eps: y = x / eps, no radial term
+        for (int c = lane; c < d; c += 64) gx[r * ldgx + c] = iv * (gr[c] - yr[c] * dot);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -279,6 +316,30 @@ int jmac_bn_tanh_bwd_f32(const float* x, int64_t ldx, const float* y, int64_t ld
     if (N > 0)
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(N * D4)), dim3(kBlock), 0, st, x, ldx, y, ldy, gy, ldgy, N, D4,
                            weight, save_mean, save_invstd, gweight, gbias, training, gx, ldgx);
+    return (int)hipGetLastError();
+}
+
+int jmac_row_normalize_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, float eps, float* y, int64_t ldy, float* inv,
+                               jmac_stream_t stream) {
+    if (N < 0 || d <= 0 || d >= INT32_MAX) return JMAC_EINVAL;
+    if (N == 0) return JMAC_OK;
+    if (!x || !y || !inv) return JMAC_EINVAL;
+    int64_t blocks = (N + kBlock / 64 - 1) / (kBlock / 64);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(row_normalize_fwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, N, (int)d, eps,
+                       y, ldy, inv);
+    return (int)hipGetLastError();
+}
+
+int jmac_row_normalize_bwd_f32(const float* y, int64_t ldy, const float* g, int64_t ldg, const float* inv, int64_t N, int64_t d,
+                               float eps, float* gx, int64_t ldgx, jmac_stream_t stream) {
+    if (N < 0 || d <= 0 || d >= INT32_MAX) return JMAC_EINVAL;
+    if (N == 0) return JMAC_OK;
+    if (!y || !g || !inv || !gx) return JMAC_EINVAL;
+    int64_t blocks = (N + kBlock / 64 - 1) / (kBlock / 64);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(row_normalize_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, y, ldy, g, ldg, inv, N,
+                       (int)d, eps, gx, ldgx);
     return (int)hipGetLastError();
 }
 

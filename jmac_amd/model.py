@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import losses, scoring
+from . import losses, ops, scoring
 from .layer import RelationAwareLayer, get_param
 
 
@@ -77,13 +77,13 @@ class JMAC(nn.Module):
         rel_comp = self.rel_init_att_completion[r0:r1]
         rel_align = self.rel_init_att_alignment[r0:r1]
         name_att = torch.mm(self.ent_info_att[e0:e1].to(dev), self.name_linear)
-        comp0 = self.completion_dropout(F.normalize(comp_att))
+        comp0 = self.completion_dropout(ops.row_normalize(comp_att))
         align0 = torch.mm(torch.cat((comp0, name_att), dim=1), self.uni_linear1_1)
         a1 = self.conv1_alignment(align0, rel_align, edge_index, edge_type)
         align_layers, comp_layers, comp_rel_layers = [align0, a1], [comp_att], [rel_comp]
         if self.args.num_gcn_layer == 2:
             c1 = self.conv1_completion(comp_att, rel_comp, edge_index, edge_type)
-            c1n = self.completion_dropout(F.normalize(c1))
+            c1n = self.completion_dropout(ops.row_normalize(c1))
             a_in = torch.mm(torch.cat((c1n, a1), dim=1), self.uni_linear2_1)
             rel_c1 = self._rel_mlp(rel_comp, self.rel_linear11, self.rel_linear12)
             rel_a_in = self._rel_mlp(rel_align, self.rel_linear11_uni, self.rel_linear12_uni)
@@ -109,8 +109,8 @@ class JMAC(nn.Module):
     def get_emb(self, edge_index, edge_type, ent_bases, rel_bases, pyt=False):
         """src/jmac_model.py:223-234."""
         align_out, comp_layers, _ = self.forward_base(edge_index, edge_type, ent_bases, rel_bases)
-        a = F.normalize(align_out, 2, -1).detach()
-        c = F.normalize(comp_layers[-1], 2, -1).detach()
+        a = ops.row_normalize(align_out).detach()
+        c = ops.row_normalize(comp_layers[-1]).detach()
         if pyt:
             return a.cpu(), c.cpu()
         return a.cpu().numpy(), c.cpu().numpy()

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import losses
+from . import losses, ops
 from .layer import RelationalAwareLayer, get_param
 from .model import _idx
 
@@ -50,13 +50,13 @@ class JMAC_MODEL(nn.Module):
     def forward_base(self, edge_index, edge_type):
         """JMAC_DBPv1/models/jmac_model.py:151-178."""
         dev = self.ent_completion_att.device
-        init_comp = self.completion_dropout(F.normalize(self.ent_completion_att, p=2, dim=-1))
+        init_comp = self.completion_dropout(ops.row_normalize(self.ent_completion_att))
         a0 = torch.mm(torch.cat((init_comp, self.ent_info_att.to(dev)), dim=1), self.align_linear1_1)
         a1 = self.conv1_align(a0, self.rel_info_att, edge_index, edge_type)
         align_layers, comp_layers, comp_rel_layers = [a0, a1], [self.ent_completion_att], [self.rel_completion_att]
         if self.args.num_gcn_layer == 2:
             c1 = self.conv1_completion(self.ent_completion_att, self.rel_completion_att, edge_index, edge_type)
-            c1n = self.completion_dropout(F.normalize(c1))
+            c1n = self.completion_dropout(ops.row_normalize(c1))
             a_in = torch.mm(torch.cat((c1n, a1), dim=1), self.align_linear2_1)
             rel_c1 = self._rel_mlp(self.rel_completion_att, self.rel_linear11, self.rel_linear12)
             rel_a_in = self._rel_mlp(self.rel_info_att, self.rel_linear11_align, self.rel_linear12_align)
@@ -69,7 +69,7 @@ class JMAC_MODEL(nn.Module):
     def get_emb(self, edge_index, edge_type, pyt=False):
         """:181-189."""
         a, comp, _ = self.forward_base(edge_index, edge_type)
-        a, c = F.normalize(a, 2, -1).detach().cpu(), F.normalize(comp[-1], 2, -1).detach().cpu()
+        a, c = ops.row_normalize(a).detach().cpu(), ops.row_normalize(comp[-1]).detach().cpu()
         return (a, c) if pyt else (a.numpy(), c.numpy())
 
     def alignment_loss_simple(self, links, ent_embeddings):
@@ -97,7 +97,7 @@ class JMAC_MODEL(nn.Module):
         bs = self.args.completion_batch_size
         loss = 0
         for layer in range(self.args.num_gcn_layer):
-            score = losses.triple_l1_score(F.normalize(comp[layer], 2, -1), F.normalize(rel[layer], 2, -1), h, r, t, period=bs)
+            score = losses.triple_l1_score(ops.row_normalize(comp[layer]), ops.row_normalize(rel[layer]), h, r, t, period=bs)
             pos, neg = score[:bs], score[bs:]
             pos = pos.view(-1, min(bs, len(pos))).permute(1, 0)
             neg = neg.view(-1, min(bs, len(neg))).permute(1, 0)

@@ -309,3 +309,35 @@ def small_mm(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     """``torch.mm`` for the relation-side products ([~10^3, d] x [d, d..2d]): one 32x32 tile per 4-wave block, K split
     over the waves, fragments straight from L2 -- ~4 us where the library GEMM takes ~17 us."""
     return _SmallMM.apply(A, B)
+
+
+# ---- row L2 normalisation (F.normalize(x, 2, -1)) ------------------------------------------------------------------
+class _RowNormalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        require_device(x)
+        x = _rowmajor(_f32c(x))
+        N, d = x.shape
+        y = torch.empty((N, d), dtype=torch.float32, device=x.device)
+        inv = torch.empty(max(N, 1), dtype=torch.float32, device=x.device)
+        check(lib().jmac_row_normalize_fwd_f32(ptr(x), x.stride(0), N, d, float(eps), ptr(y), d, ptr(inv), stream()),
+              "jmac_row_normalize_fwd_f32")
+        ctx.save_for_backward(y, inv)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, inv = ctx.saved_tensors
+        g = _rowmajor(_f32c(g))
+        N, d = y.shape
+        gx = torch.empty((N, d), dtype=torch.float32, device=y.device)
+        check(lib().jmac_row_normalize_bwd_f32(ptr(y), d, ptr(g), g.stride(0), ptr(inv), N, d, ctx.eps, ptr(gx), d, stream()),
+              "jmac_row_normalize_bwd_f32")
+        return gx, None
+
+
+def row_normalize(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """``F.normalize(x, 2, -1)`` for a 2-D fp32 tensor: one kernel each way instead of norm / clamp / div and their
+    six-kernel backward."""
+    return _RowNormalize.apply(x, float(eps))

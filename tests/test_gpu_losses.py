@@ -109,3 +109,28 @@ def test_losses_on_reference_golden_model():
     d0 = orc.triple_l1_score(t(g["comp1_l0"]).double(), t(g["rel1_l0"]).double(), h, r, tl)
     lp = torch.from_numpy(g["lp_dist"])[torch.arange(len(h)), tl]
     assert_close(ref + d0, lp, 1e-5)
+
+
+@pytest.mark.parametrize("N,d", [(300, 300), (1000, 256), (17, 7), (1, 1), (64, 513)])
+def test_row_normalize_fwd_bwd(N, d):
+    """F.normalize(x, 2, -1) (src/jmac_model.py:179,191,227-228) incl. a zero row (norm clamped at eps) and a strided input."""
+    from jmac_amd import ops
+    gen = torch.Generator().manual_seed(N + d)
+    big = torch.randn(N, d + 4, generator=gen)
+    x = big[:, 2:2 + d]                                        # row stride d + 4
+    if N > 3:
+        big[3] = 0
+    g = torch.randn(N, d, generator=gen)
+    x64 = x.double().requires_grad_(True)
+    ref = torch.nn.functional.normalize(x64, 2, -1)
+    (ref * g.double()).sum().backward()
+    xg = big.cuda()[:, 2:2 + d].detach().requires_grad_(True)
+    out = ops.row_normalize(xg)
+    (out * g.cuda()).sum().backward()
+    assert_close(out, ref, 1e-6, atol=1e-7)
+    keep = torch.ones(N, dtype=torch.bool)
+    if N > 3:
+        keep[3] = False                                         # zero row: gradient = g / eps in both (1e12-scaled)
+        assert torch.isfinite(xg.grad).all()
+        assert_close(xg.grad.cpu()[3] * 1e-12, x64.grad[3] * 1e-12, 1e-5)
+    assert_close(xg.grad.cpu()[keep], x64.grad[keep], 1e-5, atol=1e-6)
