@@ -70,6 +70,18 @@ def freeze_gemm_tuning():
         pass
 
 
+def emit(line):
+    """Rank 0's ONE JSON line, as the last thing on stdout: RCCL writes a version banner through C stdio, which sits
+    in libc's buffer until it is flushed -- flush it first, then print."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                    # pragma: no cover
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -433,8 +445,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:                                   # after the teardown: RCCL's banner lines come first
-            sys.stdout.flush()
-            print(json.dumps(line), flush=True)
+            emit(line)
         return
 
     # Default workload at any N: one DBP-5L-ja-shaped KG per GPU.  Graphs of this size do not shard
@@ -496,8 +507,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         if rank == 0:                                   # after the teardown: RCCL's banner lines come first
-            sys.stdout.flush()
-            print(json.dumps(line), flush=True)
+            emit(line)
         return
 
     from jmac_amd import synth
@@ -560,7 +570,7 @@ def main():
             line["synth"] = synth_measure(a, device)
         except Exception as ex:                      # pragma: no cover
             line["synth"] = {"error": str(ex)}
-    print(json.dumps(line))
+    emit(line)
 
 
 def _cpu_model():
