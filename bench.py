@@ -266,7 +266,7 @@ def raw_kernel_timing(N, E, nr, d, ei, et, device, iters=20, bwd_mode=1):
     Pd = PQZ.detach()
     args = (ptr(Pd), 3 * d, Pd.data_ptr() + d * 4, 3 * d, ptr(RR), 2 * d, ptr(a), ptr(g.rowptr), ptr(g.col), ptr(g.etype),
             ptr(sc.items), ptr(sc.splits), ptr(sc.counts), sc.n_items_max, sc.n_splits_max, sc.n_parts_max, N, d, 0.05,
-            nr - 1, 0.5, ptr(out_b), d, ptr(smax), ptr(sden), ptr(ws), wsb, stream())
+            nr - 1, 0, 0.5, ptr(out_b), d, ptr(smax), ptr(sden), ptr(ws), wsb, stream())
     nf = max(iters, 5) * 4
     for _ in range(5):
         L.jmac_rel_attn_aggregate_fwd_f32(*args)

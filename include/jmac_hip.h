@@ -90,7 +90,8 @@ int jmac_items_build(const int32_t* ptr, int64_t S, int32_t chunk, jmac_item_t* 
  * seg_max/seg_den [N] receive the per-destination softmax max / denominator for the backward.
  * Destinations (rows of P / out, N of them) and sources (rows of QZ, Nsrc >= max(col)+1 of them) may be
  * different index spaces (destination-sharded multi-GPU: P holds the rank's rows, QZ the all-gathered
- * table); the fused self term (loop_rel >= 0) reads QZ[i] and therefore needs the two spaces to coincide.
+ * table); the fused self term (loop_rel >= 0) reads QZ[self_off + i]: self_off = 0 when the two spaces coincide,
+ * = the row of the gathered table that holds the rank's destination 0 when the destinations are a slice of it.
  * --------------------------------------------------------------------------------------------- */
 size_t jmac_rel_attn_fwd_workspace_bytes(int64_t n_parts_max, int64_t d);
 
@@ -99,7 +100,7 @@ int jmac_rel_attn_aggregate_fwd_f32(
     const float* a_att, const int32_t* rowptr, const int32_t* col, const int32_t* etype,
     const jmac_item_t* items, const jmac_split_t* splits, const int32_t* counts,
     int64_t n_items_max, int64_t n_splits_max, int64_t n_parts_max, int64_t N, int64_t d,
-    float slope, int32_t loop_rel, float out_scale, float* out, int64_t ldo, float* seg_max,
+    float slope, int32_t loop_rel, int64_t self_off, float out_scale, float* out, int64_t ldo, float* seg_max,
     float* seg_den,
     void* ws, size_t ws_bytes, jmac_stream_t stream);
 
@@ -112,7 +113,7 @@ int jmac_rel_attn_aggregate_fwd_bf16(
     const float* a_att, const int32_t* rowptr, const int32_t* col, const int32_t* etype,
     const jmac_item_t* items, const jmac_split_t* splits, const int32_t* counts,
     int64_t n_items_max, int64_t n_splits_max, int64_t n_parts_max, int64_t N, int64_t d,
-    float slope, int32_t loop_rel, float out_scale, float* out, int64_t ldo, float* seg_max,
+    float slope, int32_t loop_rel, int64_t self_off, float out_scale, float* out, int64_t ldo, float* seg_max,
     float* seg_den,
     void* ws, size_t ws_bytes, jmac_stream_t stream);
 
@@ -143,7 +144,7 @@ int jmac_rel_attn_aggregate_bwd_f32(
     const float* a_att, const int32_t* col, const int32_t* etype, const int32_t* dst_of_slot,
     const jmac_view_t* by_dst, const jmac_view_t* by_src, const jmac_view_t* by_rel,
     int64_t N, int64_t Nsrc, int64_t E, int64_t nrel, int64_t d, float slope, int32_t loop_rel,
-    float out_scale, const float* out, int64_t ldo, const float* seg_max, const float* seg_den,
+    int64_t self_off, float out_scale, const float* out, int64_t ldo, const float* seg_max, const float* seg_den,
     const float* G, int64_t ldg,
     float* dP, int64_t lddp, float* dQZ, int64_t lddqz, float* dRR, int64_t lddrr, float* da,
     int32_t mode, void* ws, size_t ws_bytes, jmac_stream_t stream);
@@ -163,6 +164,28 @@ int jmac_bn_tanh_bwd_f32(const float* x, int64_t ldx, const float* y, int64_t ld
                          const float* save_mean, const float* save_invstd, int32_t training,
                          float* gx, int64_t ldgx, float* gweight, float* gbias, void* ws,
                          size_t ws_bytes, jmac_stream_t stream);
+
+/* Phased forms of the same BatchNorm + tanh for batch statistics that span several ranks (destination-sharded
+ * layer): the caller combines the per-rank moments / sums between the phases (torch.distributed over RCCL).
+ *   forward : jmac_col_moments_f32 -> mean[d], m2[d] = sum (x - mean)^2 of THIS rank's N rows
+ *             [all-gather, Chan's parallel combination -> global mean, invstd]
+ *             jmac_bn_tanh_apply_f32
+ *   backward: jmac_bn_tanh_bwd_sums_f32 -> sums[0:d] = sum gz, sums[d:2d] = sum gz*xhat over this rank's rows
+ *             (gz = gy (1 - y^2); these are also the rank's contributions to grad bias / grad weight)
+ *             [all-reduce]   jmac_bn_tanh_bwd_apply_f32 with the global sums and the global row count n_total. */
+int jmac_col_moments_f32(const float* x, int64_t ldx, int64_t N, int64_t d, float* mean, float* m2,
+                         void* ws, size_t ws_bytes, jmac_stream_t stream);
+int jmac_bn_tanh_apply_f32(const float* x, int64_t ldx, int64_t N, int64_t d, const float* weight,
+                           const float* bias, const float* mean, const float* invstd, float* y,
+                           int64_t ldy, jmac_stream_t stream);
+int jmac_bn_tanh_bwd_sums_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy,
+                              int64_t ldgy, int64_t N, int64_t d, const float* mean,
+                              const float* invstd, float* sums, void* ws, size_t ws_bytes,
+                              jmac_stream_t stream);
+int jmac_bn_tanh_bwd_apply_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy,
+                               int64_t ldgy, int64_t N, int64_t d, const float* weight,
+                               const float* mean, const float* invstd, const float* sums,
+                               int64_t n_total, float* gx, int64_t ldgx, jmac_stream_t stream);
 
 /* Row L2 normalisation  y = x / max(||x||_2, eps)  (replaces F.normalize(x, 2, -1) of JMAC.forward_name and get_emb,
  * src/jmac_model.py:179,191,227-228; eps = 1e-12 is torch's default).  inv [N] receives 1 / max(||x_r||, eps) for the

@@ -42,21 +42,25 @@ _SIGS = {
     "jmac_items_build": (C.c_int, [vp, i64, i32, vp, vp, vp, vp, sz, vp]),
     "jmac_rel_attn_fwd_workspace_bytes": (sz, [i64, i64]),
     "jmac_rel_attn_aggregate_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp,
-                                                  i64, i64, i64, i64, i64, f32, i32, f32, vp, i64, vp, vp,
+                                                  i64, i64, i64, i64, i64, f32, i32, i64, f32, vp, i64, vp, vp,
                                                   vp, sz, vp]),
     "jmac_rel_attn_aggregate_fwd_bf16": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp,
-                                                   i64, i64, i64, i64, i64, f32, i32, f32, vp, i64, vp, vp,
+                                                   i64, i64, i64, i64, i64, f32, i32, i64, f32, vp, i64, vp, vp,
                                                    vp, sz, vp]),
     "jmac_rel_attn_bwd_workspace_bytes": (sz, [i64, i64, i64, i64, i64, i64, i64, i32]),
     "jmac_rel_attn_aggregate_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp,
                                                   C.POINTER(View), C.POINTER(View), C.POINTER(View),
-                                                  i64, i64, i64, i64, i64, f32, i32, f32, vp, i64, vp, vp, vp, i64,
+                                                  i64, i64, i64, i64, i64, f32, i32, i64, f32, vp, i64, vp, vp, vp, i64,
                                                   vp, i64, vp, i64, vp, i64, vp, i32, vp, sz, vp]),
     "jmac_bn_tanh_workspace_bytes": (sz, [i64, i64]),
     "jmac_bn_tanh_fwd_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, i32, f32, f32, vp, i64, vp, vp,
                                        vp, sz, vp]),
     "jmac_bn_tanh_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, vp, vp, vp, i32, vp, i64, vp, vp,
                                        vp, sz, vp]),
+    "jmac_col_moments_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, sz, vp]),
+    "jmac_bn_tanh_apply_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, vp, i64, vp]),
+    "jmac_bn_tanh_bwd_sums_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, vp, vp, vp, vp, sz, vp]),
+    "jmac_bn_tanh_bwd_apply_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, vp, vp, vp, vp, i64, vp, i64, vp]),
     "jmac_row_normalize_fwd_f32": (C.c_int, [vp, i64, i64, i64, f32, vp, i64, vp, vp]),
     "jmac_row_normalize_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, f32, vp, i64, vp]),
     "jmac_l1_score_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, vp]),

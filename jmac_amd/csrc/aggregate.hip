@@ -43,6 +43,7 @@ struct FwdArgs {
     const jmac_split_t* splits;
     const int32_t* counts;
     int32_t N, D4, loop_rel, n_items_max;
+    int64_t self_off;     // row of QZ that holds destination 0 (fused self term; 0 unless destinations are a slice of the sources)
     float slope, out_scale;
     float *out, *seg_max, *seg_den;
     float *part_acc, *part_ml;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
         float4 pv[NCH], acc[NCH], zs[NCH];
         // a destination without in-edges needs no P row: re-read row 0 (cache hit) instead of its own
         const TT* prow = tP + (int64_t)(item.end > item.beg ? i : 0) * a.ldp;
-        const TT* zrow = tQZ + (int64_t)i * a.ldqz;
+        const TT* zrow = tQZ + ((int64_t)i + a.self_off) * a.ldqz;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             pv[k] = L.any_h(k) ? cvt4(ldraw(prow + (L.is_h[k] ? L.coff[k] : 0))) : f4zero();
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_combine_kernel(FwdArgs a)
                     float4 o = add4(add4(red[0][k][lane], red[1][k][lane]), add4(red[2][k][lane], red[3][k][lane]));
                     o = mul4(o, scale);
                     if (a.loop_rel >= 0) {
-                        float4 z = cvt4(ldraw(static_cast<const TT*>(a.QZ) + (int64_t)i * a.ldqz + L.coff[k]));
+                        float4 z = cvt4(ldraw(static_cast<const TT*>(a.QZ) + ((int64_t)i + a.self_off) * a.ldqz + L.coff[k]));
                         float4 rz = cvt4(ldraw(static_cast<const TT*>(a.RR) + (int64_t)a.loop_rel * a.ldrr + L.coff[k]));
                         o = add4(o, sub4(z, rz));
                     }
@@ -341,6 +342,7 @@ struct BwdArgs {
     const int32_t* counts;
     const int32_t* order;     // pass B / C: CSR slot of each entry
     int32_t N, D4, loop_rel, nrel;
+    int64_t self_off;
     float slope, out_scale;
     float *dP, *dQZ, *dRR;
     float* da_part;           // [gridDim.x, d]
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
         float4 pv[NCH_H], gv[NCH], accP[NCH_H];
         float tpart = 0.f;
         const float* prow = a.P + (int64_t)i * a.ldp;
-        const float* zrow = a.QZ + (int64_t)i * a.ldqz;
+        const float* zrow = a.QZ + ((int64_t)i + a.self_off) * a.ldqz;
         const float* grow = a.G + (int64_t)i * a.ldg;
         const float* orow = a.out + (int64_t)i * a.ldo;
 #pragma unroll
@@ -612,8 +614,8 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs a, 
         for (int k = 0; k < NCH; ++k) {
             if (!L.valid[k]) continue;
             float4 v = mul4(acc[k], a.sign);
-            if (direct && a.add_self && !L.is_h[k])
-                v = fma4(ld4(a.G + (int64_t)seg * a.ldg + (L.coff[k] - voff)), kappa, v);
+            if (direct && a.add_self && !L.is_h[k] && seg >= a.self_off && seg - a.self_off < a.N)
+                v = fma4(ld4(a.G + ((int64_t)seg - a.self_off) * a.ldg + (L.coff[k] - voff)), kappa, v);
             st4(row + L.coff[k], v);
         }
     }
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(kBlock) void sum_parts_kernel(const jmac_split_t* _
                                                            const float* __restrict__ part, int W4, float sign,
                                                            float* __restrict__ outp, int64_t ldout,
                                                            const float* __restrict__ G, int64_t ldg, int D4, float kappa,
-                                                           int add_self) {
+                                                           int add_self, int64_t self_off, int64_t n_self) {
     // one BLOCK per split segment: wave w sums partial rows w, w+4, w+8, ... (two rows in flight per lane), the four
     // wave sums are combined through LDS in wave order -> fixed summation order, and the hottest relation's thousands
     // of partial rows are no longer one wave's serial chain
@@ -652,7 +654,8 @@ __global__ __launch_bounds__(kBlock) void sum_parts_kernel(const jmac_split_t* _
             if (wave == 0 && c4 < W4) {
                 float4 acc = add4(add4(red[0][lane], red[1][lane]), add4(red[2][lane], red[3][lane]));
                 acc = mul4(acc, sign);
-                if (add_self && c4 >= D4) acc = fma4(ld4(G + (int64_t)s.seg * ldg + (c4 - D4) * 4), kappa, acc);
+                if (add_self && c4 >= D4 && s.seg >= self_off && s.seg - self_off < n_self)
+                    acc = fma4(ld4(G + ((int64_t)s.seg - self_off) * ldg + (c4 - D4) * 4), kappa, acc);
                 st4(outp + (int64_t)s.seg * ldout + c4 * 4, acc);
             }
             __syncthreads();
@@ -724,12 +727,13 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restri
 }
 
 // atomic mode: dQZ starts at [0 | kappa*G[i]] (the fused self loop's dZ term) or at zero
-__global__ void init_dqz_kernel(float* __restrict__ dQZ, int64_t lddqz, int64_t N, int64_t d, const float* __restrict__ G,
-                                int64_t ldg, float kappa, int add_self) {
+__global__ void init_dqz_kernel(float* __restrict__ dQZ, int64_t lddqz, int64_t Nsrc, int64_t d, const float* __restrict__ G,
+                                int64_t ldg, float kappa, int add_self, int64_t self_off, int64_t n_self) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N * 2 * d) {
+    if (i < Nsrc * 2 * d) {
         int64_t r = i / (2 * d), c = i % (2 * d);
-        dQZ[r * lddqz + c] = (add_self && c >= d) ? kappa * G[r * ldg + (c - d)] : 0.f;
+        const bool self = add_self && c >= d && r >= self_off && r - self_off < n_self;
+        dQZ[r * lddqz + c] = self ? kappa * G[(r - self_off) * ldg + (c - d)] : 0.f;
     }
 }
 
@@ -797,8 +801,8 @@ template <typename TT>
 static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t ldqz, const TT* RR, int64_t ldrr, const float* a_att,
                                const int32_t* rowptr, const int32_t* col, const int32_t* etype, const jmac_item_t* items,
                                const jmac_split_t* splits, const int32_t* counts, int64_t n_items_max, int64_t n_splits_max,
-                               int64_t n_parts_max, int64_t N, int64_t d, float slope, int32_t loop_rel, float out_scale, float* out,
-                               int64_t ldo, float* seg_max, float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+                               int64_t n_parts_max, int64_t N, int64_t d, float slope, int32_t loop_rel, int64_t self_off, float out_scale,
+                               float* out, int64_t ldo, float* seg_max, float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
     if (N < 0 || n_items_max < 0 || n_splits_max < 0) return JMAC_EINVAL;
     if (N == 0) return JMAC_OK;
     if (!P || !QZ || !RR || !a_att || !rowptr || !items || !counts || !out || !seg_max || !seg_den) return JMAC_EINVAL;
@@ -810,7 +814,8 @@ static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t l
     a.ldp = ldp; a.ldqz = ldqz; a.ldrr = ldrr; a.ldo = ldo;
     a.rowptr = rowptr; a.col = col; a.etype = etype;
     a.items = items; a.splits = splits; a.counts = counts;
-    a.N = (int32_t)N; a.D4 = (int32_t)(d / 4); a.loop_rel = loop_rel;
+    if (loop_rel >= 0 && self_off < 0) return JMAC_EINVAL;
+    a.N = (int32_t)N; a.D4 = (int32_t)(d / 4); a.loop_rel = loop_rel; a.self_off = loop_rel >= 0 ? self_off : 0;
     a.n_items_max = (int32_t)(n_items_max > 0 ? n_items_max : 1);
     a.slope = slope; a.out_scale = out_scale;
     a.out = out; a.seg_max = seg_max; a.seg_den = seg_den;
@@ -850,10 +855,10 @@ int jmac_rel_attn_aggregate_fwd_f32(const float* P, int64_t ldp, const float* QZ
                                     int64_t ldrr, const float* a_att, const int32_t* rowptr, const int32_t* col,
                                     const int32_t* etype, const jmac_item_t* items, const jmac_split_t* splits,
                                     const int32_t* counts, int64_t n_items_max, int64_t n_splits_max,
-                                    int64_t n_parts_max, int64_t N, int64_t d, float slope, int32_t loop_rel, float out_scale, float* out, int64_t ldo,
+                                    int64_t n_parts_max, int64_t N, int64_t d, float slope, int32_t loop_rel, int64_t self_off, float out_scale, float* out, int64_t ldo,
                                     float* seg_max, float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
     return launch_rel_attn_fwd<float>(P, ldp, QZ, ldqz, RR, ldrr, a_att, rowptr, col, etype, items, splits, counts, n_items_max,
-                                      n_splits_max, n_parts_max, N, d, slope, loop_rel, out_scale, out, ldo, seg_max, seg_den, ws,
+                                      n_splits_max, n_parts_max, N, d, slope, loop_rel, self_off, out_scale, out, ldo, seg_max, seg_den, ws,
                                       ws_bytes, stream);
 }
 
@@ -861,10 +866,10 @@ int jmac_rel_attn_aggregate_fwd_bf16(const uint16_t* P, int64_t ldp, const uint1
                                      int64_t ldrr, const float* a_att, const int32_t* rowptr, const int32_t* col,
                                      const int32_t* etype, const jmac_item_t* items, const jmac_split_t* splits,
                                      const int32_t* counts, int64_t n_items_max, int64_t n_splits_max,
-                                     int64_t n_parts_max, int64_t N, int64_t d, float slope, int32_t loop_rel, float out_scale, float* out, int64_t ldo,
+                                     int64_t n_parts_max, int64_t N, int64_t d, float slope, int32_t loop_rel, int64_t self_off, float out_scale, float* out, int64_t ldo,
                                      float* seg_max, float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
     return launch_rel_attn_fwd<bf16_t>(P, ldp, QZ, ldqz, RR, ldrr, a_att, rowptr, col, etype, items, splits, counts, n_items_max,
-                                       n_splits_max, n_parts_max, N, d, slope, loop_rel, out_scale, out, ldo, seg_max, seg_den, ws,
+                                       n_splits_max, n_parts_max, N, d, slope, loop_rel, self_off, out_scale, out, ldo, seg_max, seg_den, ws,
                                        ws_bytes, stream);
 }
 
@@ -898,12 +903,13 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
                                     int64_t ldrr, const float* a_att, const int32_t* col, const int32_t* etype,
                                     const int32_t* dst_of_slot, const jmac_view_t* by_dst, const jmac_view_t* by_src,
                                     const jmac_view_t* by_rel, int64_t N, int64_t Nsrc, int64_t E, int64_t nrel, int64_t d,
-                                    float slope, int32_t loop_rel, float out_scale, const float* out, int64_t ldo,
+                                    float slope, int32_t loop_rel, int64_t self_off, float out_scale, const float* out, int64_t ldo,
                                     const float* seg_max, const float* seg_den, const float* G, int64_t ldg, float* dP,
                                     int64_t lddp, float* dQZ, int64_t lddqz, float* dRR, int64_t lddrr, float* da,
                                     int32_t mode, void* ws, size_t ws_bytes, jmac_stream_t stream) {
     if (N < 0 || Nsrc < 0 || E < 0 || nrel <= 0) return JMAC_EINVAL;
-    if (loop_rel >= 0 && Nsrc != N) return JMAC_EINVAL;   // the fused self term indexes QZ by destination
+    if (loop_rel < 0) self_off = 0;
+    if (loop_rel >= 0 && (self_off < 0 || self_off + N > Nsrc)) return JMAC_EINVAL;   // the fused self term reads QZ[self_off + i]
     if (!P || !QZ || !RR || !a_att || !by_dst || !out || !seg_max || !seg_den || !G || !dP || !dQZ || !dRR || !da)
         return JMAC_EINVAL;
     if (mode != 0 && (!by_src || !by_rel || !dst_of_slot)) return JMAC_EINVAL;
@@ -923,7 +929,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
     a.ldp = ldp; a.ldqz = ldqz; a.ldrr = ldrr; a.ldo = ldo; a.ldg = ldg; a.lddp = lddp; a.lddqz = lddqz; a.lddrr = lddrr;
     a.rowptr = by_dst->ptr; a.col = col; a.etype = etype; a.dst_of_slot = dst_of_slot;
     a.items = by_dst->items; a.splits = by_dst->splits; a.counts = by_dst->counts; a.order = nullptr;
-    a.N = (int32_t)N; a.D4 = D4; a.loop_rel = loop_rel; a.nrel = (int32_t)nrel;
+    a.N = (int32_t)N; a.D4 = D4; a.loop_rel = loop_rel; a.nrel = (int32_t)nrel; a.self_off = self_off;
     a.slope = slope; a.out_scale = out_scale;
     a.dP = dP; a.dQZ = dQZ; a.dRR = dRR;
     a.da_part = (float*)(wsb + w.da_part);
@@ -938,7 +944,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
     if (mode == 0) {
         // dQZ / dRR are accumulated with atomics: initialise them (dZ half of dQZ starts at the self term)
         hipLaunchKernelGGL(init_dqz_kernel, dim3((unsigned)((Nsrc * 2 * d + T - 1) / T)), dim3(T), 0, st, dQZ, lddqz, Nsrc, d, G, ldg,
-                           out_scale, loop_rel >= 0 ? 1 : 0);
+                           out_scale, loop_rel >= 0 ? 1 : 0, self_off, N);
         hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((nrel * 2 * d + T - 1) / T)), dim3(T), 0, st, dRR, nrel, 2 * d, lddrr, 0.f);
         JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 0, D4T>), dim3(gridA), dim3(kBlock), 0, st, a));
     } else {
@@ -948,7 +954,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
     launch_reduce_rows(a.da_part, (int)gridA, (int)d, 1.f, da, st);
     if (by_dst->n_splits_max > 0)
         hipLaunchKernelGGL(sum_parts_kernel, dim3(split_grid(by_dst->n_splits_max)), dim3(kBlock), 0, st, by_dst->splits,
-                           by_dst->counts, a.part, D4, 1.f, dP, lddp, nullptr, (int64_t)0, 0, 0.f, 0);
+                           by_dst->counts, a.part, D4, 1.f, dP, lddp, nullptr, (int64_t)0, 0, 0.f, 0, (int64_t)0, (int64_t)0);
 
     // column sum of G for the fused self loop:  dRz[loop] -= kappa * sum_i G[i]
     float* colsum_part = (float*)(wsb + w.colsum_part);
@@ -967,7 +973,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
                                                   dim3(kBlock), 0, st, b, dQZ, lddqz));
         if (by_src->n_splits_max > 0)
             hipLaunchKernelGGL(sum_parts_kernel, dim3(split_grid(by_src->n_splits_max)), dim3(kBlock), 0, st, by_src->splits,
-                               by_src->counts, b.part, 2 * D4, 1.f, dQZ, lddqz, G, ldg, D4, out_scale, b.add_self);
+                               by_src->counts, b.part, 2 * D4, 1.f, dQZ, lddqz, G, ldg, D4, out_scale, b.add_self, self_off, N);
         BwdArgs c = a;
         c.items = by_rel->items; c.splits = by_rel->splits; c.counts = by_rel->counts; c.order = by_rel->order;
         c.part = (float*)(wsb + w.part_rel);
@@ -976,7 +982,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
                                                   dim3(kBlock), 0, st, c, dRR, lddrr));
         if (by_rel->n_splits_max > 0)
             hipLaunchKernelGGL(sum_parts_kernel, dim3(split_grid(by_rel->n_splits_max)), dim3(kBlock), 0, st, by_rel->splits,
-                               by_rel->counts, c.part, 2 * D4, 1.f, dRR, lddrr, nullptr, (int64_t)0, 0, 0.f, 0);
+                               by_rel->counts, c.part, 2 * D4, 1.f, dRR, lddrr, nullptr, (int64_t)0, 0, 0.f, 0, (int64_t)0, (int64_t)0);
     }
     if (loop_rel >= 0 && N > 0) {
         // pass C wrote zeros (mode 1) / the fill wrote zeros (mode 0) into dRz[loop]: overwrite it

@@ -86,6 +86,17 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
     }
 }
 
+// local column moments from the shifted sums: mean = K + s1/n, M2 = sum (x - mean)^2 = s2 - s1^2/n
+__global__ void moments_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ x, int64_t N, int d,
+                                        float* __restrict__ mean, float* __restrict__ m2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    const float s1 = sums[c], s2 = sums[d + c], n = (float)N;
+    mean[c] = x[c] + s1 / n;
+    const float v = s2 - s1 * s1 / n;
+    m2[c] = v > 0.f ? v : 0.f;
+}
+
 __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var, int d,
                                      float eps, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -179,10 +190,9 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
                                                               const float* __restrict__ gy, int64_t ldgy, int64_t N, int D4,
                                                               const float* __restrict__ weight, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, const float* __restrict__ gweight,
-                                                              const float* __restrict__ gbias, int training,
+                                                              const float* __restrict__ gbias, int training, float invn,
                                                               float* __restrict__ gx, int64_t ldgx) {
     const int64_t total = N * D4;
-    const float invn = 1.f / (float)N;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int64_t r = i / D4;
         const int c4 = (int)(i % D4);
@@ -315,7 +325,7 @@ int jmac_bn_tanh_bwd_f32(const float* x, int64_t ldx, const float* y, int64_t ld
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, sums, (int)d, gweight, gbias);
     if (N > 0)
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(N * D4)), dim3(kBlock), 0, st, x, ldx, y, ldy, gy, ldgy, N, D4,
-                           weight, save_mean, save_invstd, gweight, gbias, training, gx, ldgx);
+                           weight, save_mean, save_invstd, gweight, gbias, training, 1.f / (float)N, gx, ldgx);
     return (int)hipGetLastError();
 }
 
@@ -340,6 +350,70 @@ int jmac_row_normalize_bwd_f32(const float* y, int64_t ldy, const float* g, int6
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(row_normalize_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, y, ldy, g, ldg, inv, N,
                        (int)d, eps, gx, ldgx);
+    return (int)hipGetLastError();
+}
+
+// ---- phased forms for batch statistics that span several ranks (destination-sharded layer, jmac_amd/dist.py) ---------
+// moments -> [combine across ranks on the host side of the ABI] -> apply;  backward: sums -> [all-reduce] -> apply.
+
+int jmac_col_moments_f32(const float* x, int64_t ldx, int64_t N, int64_t d, float* mean, float* m2, void* ws, size_t ws_bytes,
+                         jmac_stream_t stream) {
+    if (N <= 0 || !x || !mean || !m2) return JMAC_EINVAL;
+    if (d <= 0 || d % 4 || ldx % 4) return JMAC_EDIM;
+    if (!ws || ws_bytes < jmac_bn_tanh_workspace_bytes(N, d)) return JMAC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int D4 = (int)(d / 4);
+    float* partial = (float*)ws;
+    const unsigned g = stat_grid(N, D4);
+    hipLaunchKernelGGL(col_stats_partial_kernel, dim3(g), dim3(kBlock), stat_smem(D4), st, x, ldx, N, D4, partial);
+    float* sums = partial + (size_t)kStatBlocks * 2 * d;
+    launch_reduce_rows(partial, (int)g, (int)(2 * d), 1.f, sums, st);
+    hipLaunchKernelGGL(moments_finalize_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, sums, x, N, (int)d, mean, m2);
+    return (int)hipGetLastError();
+}
+
+int jmac_bn_tanh_apply_f32(const float* x, int64_t ldx, int64_t N, int64_t d, const float* weight, const float* bias,
+                           const float* mean, const float* invstd, float* y, int64_t ldy, jmac_stream_t stream) {
+    if (N < 0 || !weight || !bias || !mean || !invstd) return JMAC_EINVAL;
+    if (d <= 0 || d % 4 || ldx % 4 || ldy % 4) return JMAC_EDIM;
+    if (N == 0) return JMAC_OK;
+    if (!x || !y) return JMAC_EINVAL;
+    const int D4 = (int)(d / 4);
+    hipLaunchKernelGGL(bn_tanh_apply_kernel, dim3(stream_grid(N * D4)), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, N, D4, weight,
+                       bias, mean, invstd, y, ldy);
+    return (int)hipGetLastError();
+}
+
+int jmac_bn_tanh_bwd_sums_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy, int64_t ldgy, int64_t N,
+                              int64_t d, const float* mean, const float* invstd, float* sums, void* ws, size_t ws_bytes,
+                              jmac_stream_t stream) {
+    if (N < 0 || !mean || !invstd || !sums) return JMAC_EINVAL;
+    if (d <= 0 || d % 4 || ldx % 4 || ldy % 4 || ldgy % 4) return JMAC_EDIM;
+    if (!ws || ws_bytes < jmac_bn_tanh_workspace_bytes(N, d)) return JMAC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int D4 = (int)(d / 4);
+    float* partial = (float*)ws;
+    unsigned g = 0;
+    if (N > 0) {
+        if (!x || !y || !gy) return JMAC_EINVAL;
+        g = stat_grid(N, D4);
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g), dim3(kBlock), stat_smem(D4), st, x, ldx, y, ldy, gy, ldgy, N, D4, mean,
+                           invstd, partial);
+    }
+    launch_reduce_rows(partial, (int)g, (int)(2 * d), 1.f, sums, st);     // sums[0:d] = sum gz, sums[d:2d] = sum gz * xhat
+    return (int)hipGetLastError();
+}
+
+int jmac_bn_tanh_bwd_apply_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy, int64_t ldgy, int64_t N,
+                               int64_t d, const float* weight, const float* mean, const float* invstd, const float* sums,
+                               int64_t n_total, float* gx, int64_t ldgx, jmac_stream_t stream) {
+    if (N < 0 || n_total <= 0 || !weight || !mean || !invstd || !sums) return JMAC_EINVAL;
+    if (d <= 0 || d % 4 || ldx % 4 || ldy % 4 || ldgy % 4 || ldgx % 4) return JMAC_EDIM;
+    if (N == 0) return JMAC_OK;
+    if (!x || !y || !gy || !gx) return JMAC_EINVAL;
+    const int D4 = (int)(d / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(N * D4)), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, y, ldy, gy, ldgy,
+                       N, D4, weight, mean, invstd, sums + d, sums, 1, 1.f / (float)n_total, gx, ldgx);
     return (int)hipGetLastError();
 }
 

@@ -207,6 +207,134 @@ def sync_batch_norm(x: torch.Tensor, n_global: int, bn: nn.BatchNorm1d, group=No
 
 
 # ------------------------------------------------------------------------------------------------
+# BatchNorm + tanh with batch statistics over the rows of ALL ranks, on the fused kernels
+# ------------------------------------------------------------------------------------------------
+class _HipBN:
+    """Rank-local phases (libjmac_hip.so, include/jmac_hip.h "phased forms"); tests inject a torch stand-in under gloo."""
+
+    @staticmethod
+    def moments(x):
+        from ._lib import check, lib, ptr, stream
+        n, d = x.shape
+        mean = torch.empty(d, dtype=torch.float32, device=x.device)
+        m2 = torch.empty(d, dtype=torch.float32, device=x.device)
+        wsb = int(lib().jmac_bn_tanh_workspace_bytes(n, d))
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=x.device)
+        check(lib().jmac_col_moments_f32(ptr(x), x.stride(0), n, d, ptr(mean), ptr(m2), ptr(ws), wsb, stream()), "jmac_col_moments_f32")
+        return mean, m2
+
+    @staticmethod
+    def apply(x, weight, bias, mean, invstd):
+        from ._lib import check, lib, ptr, stream
+        n, d = x.shape
+        y = torch.empty((n, d), dtype=torch.float32, device=x.device)
+        check(lib().jmac_bn_tanh_apply_f32(ptr(x), x.stride(0), n, d, ptr(weight), ptr(bias), ptr(mean), ptr(invstd), ptr(y), d,
+                                           stream()), "jmac_bn_tanh_apply_f32")
+        return y
+
+    @staticmethod
+    def bwd_sums(x, y, gy, mean, invstd):
+        from ._lib import check, lib, ptr, stream
+        n, d = x.shape
+        sums = torch.empty(2 * d, dtype=torch.float32, device=x.device)
+        wsb = int(lib().jmac_bn_tanh_workspace_bytes(n, d))
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=x.device)
+        check(lib().jmac_bn_tanh_bwd_sums_f32(ptr(x), x.stride(0), ptr(y), d, ptr(gy), gy.stride(0), n, d, ptr(mean), ptr(invstd),
+                                              ptr(sums), ptr(ws), wsb, stream()), "jmac_bn_tanh_bwd_sums_f32")
+        return sums
+
+    @staticmethod
+    def bwd_apply(x, y, gy, weight, mean, invstd, sums, n_total):
+        from ._lib import check, lib, ptr, stream
+        n, d = x.shape
+        gx = torch.empty((n, d), dtype=torch.float32, device=x.device)
+        check(lib().jmac_bn_tanh_bwd_apply_f32(ptr(x), x.stride(0), ptr(y), d, ptr(gy), gy.stride(0), n, d, ptr(weight), ptr(mean),
+                                               ptr(invstd), ptr(sums), int(n_total), ptr(gx), d, stream()), "jmac_bn_tanh_bwd_apply_f32")
+        return gx
+
+
+def _all_gather_small(t: torch.Tensor, group=None) -> torch.Tensor:
+    """[k] per rank -> [world, k]."""
+    return _all_gather_padded(t.view(1, -1), 1, group).view(_world(group) if not _skip(group) else 1, -1)
+
+
+class _SyncBnTanh(torch.autograd.Function):
+    """tanh(BatchNorm1d(x)) (src/jmac_model.py:52) with TRAIN-mode statistics over the rows of all ranks.
+
+    forward : local (mean, M2) -> all-gather of [2d+1] per rank -> Chan's parallel combination -> fused apply
+    backward: local sums of gz and gz*xhat -> all-reduce -> fused apply with the global row count.
+    grad weight / grad bias are the RANK's contributions (allreduce_grads sums the replicated parameters' grads)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, n_global, group, kernels):
+        x = x.contiguous()
+        n_loc, d = x.shape
+        if n_loc > 0:
+            mean_l, m2_l = kernels.moments(x)
+        else:
+            mean_l, m2_l = x.new_zeros(d), x.new_zeros(d)
+        packed = torch.cat([mean_l, m2_l, x.new_full((1,), float(n_loc))])
+        allp = _all_gather_small(packed, group).double()                     # [world, 2d+1]
+        cnt = allp[:, 2 * d]
+        n = cnt.sum()
+        mean = (allp[:, :d] * cnt.view(-1, 1)).sum(0) / n
+        m2 = allp[:, d:2 * d].sum(0) + (cnt.view(-1, 1) * (allp[:, :d] - mean) ** 2).sum(0)
+        var = m2 / n
+        mean_f, invstd = mean.float(), torch.rsqrt(var + eps).float()
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean_f, alpha=momentum)
+                unb = (var * (n / torch.clamp(n - 1, min=1))).float()
+                running_var.mul_(1 - momentum).add_(unb, alpha=momentum)
+                num_batches_tracked.add_(1)
+        y = kernels.apply(x, weight, bias, mean_f, invstd)
+        ctx.save_for_backward(x, y, weight, mean_f, invstd)
+        ctx.group, ctx.kernels, ctx.n_total = group, kernels, int(n_global)   # host-side count: no device sync
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        gy = gy.contiguous()
+        d = x.shape[1]
+        sums_l = ctx.kernels.bwd_sums(x, y, gy, mean, invstd) if x.shape[0] > 0 else x.new_zeros(2 * d)
+        sums = sums_l.clone()
+        if not _skip(ctx.group):
+            _all_reduce(sums, ctx.group)
+        gx = ctx.kernels.bwd_apply(x, y, gy, weight, mean, invstd, sums, ctx.n_total) if x.shape[0] > 0 else torch.zeros_like(x)
+        return gx, sums_l[d:].clone(), sums_l[:d].clone(), None, None, None, None, None, None, None, None
+
+
+def sync_bn_tanh(x: torch.Tensor, bn: nn.BatchNorm1d, n_global: int, group=None, kernels=None) -> torch.Tensor:
+    """tanh(bn(x)) with batch statistics over ALL ranks' rows (n_global of them); eval mode uses the running
+    statistics (row-local)."""
+    kernels = kernels or _HipBN
+    if not (bn.training or not bn.track_running_stats):
+        inv = torch.rsqrt(bn.running_var + bn.eps)
+        return _EvalBnTanh.apply(x, bn.weight, bn.bias, bn.running_mean, inv, kernels)
+    track = bn.track_running_stats
+    return _SyncBnTanh.apply(x, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
+                             bn.num_batches_tracked if track else None, bn.momentum if bn.momentum is not None else 0.1,
+                             bn.eps, int(n_global), group, kernels)
+
+
+class _EvalBnTanh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, mean, invstd, kernels):
+        x = x.contiguous()
+        y = kernels.apply(x, weight, bias, mean.contiguous(), invstd.contiguous())
+        ctx.save_for_backward(x, y, weight, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        gz = gy * (1 - y * y)
+        xhat = (x - mean) * invstd
+        return gz * (weight * invstd), (gz * xhat).sum(0), gz.sum(0), None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
 # the sharded layer
 # ------------------------------------------------------------------------------------------------
 def hip_local_aggregate(P, QZ, RR, a, sg: ShardedGraph, slope: float) -> torch.Tensor:
@@ -215,17 +343,30 @@ def hip_local_aggregate(P, QZ, RR, a, sg: ShardedGraph, slope: float) -> torch.T
     return ops.rel_attn_aggregate_split(P, QZ, RR, a, sg.rel_graph(P.device, RR.shape[0]), slope, 1.0)
 
 
+def hip_local_layer(P, QZ, RR, a, sg: ShardedGraph, slope: float) -> torch.Tensor:
+    """(nb[i] + Z[i] - Rz[loop]) / 2 for the rank's rows in ONE kernel: the fused self term reads the rank's own rows of
+    the gathered table at offset rank * n_max."""
+    from . import ops
+    return ops.rel_attn_aggregate_split(P, QZ, RR, a, sg.rel_graph(P.device, RR.shape[0]), slope, 0.5,
+                                        loop_rel=RR.shape[0] - 1, self_off=sg.rank * sg.n_max)
+
+
 class ShardedRelationAwareLayer(nn.Module):
     """RelationAwareLayer (src/jmac_model.py:10-53) on a destination-sharded graph.
 
     ``forward(x_local [n_r, d], rel_emb [nr, d], sg)`` returns the rank's [n_r, d] output slab; parameters
-    are replicated (same names as the reference layer), their gradients summed with ``allreduce_grads``."""
+    are replicated (same names as the reference layer), their gradients summed with ``allreduce_grads``.
 
-    def __init__(self, layer: nn.Module, group=None, local_aggregate: Optional[Callable] = None):
+    Product path (default): the aggregation, the self loop and the /2 are one kernel (``hip_local_layer``), BatchNorm +
+    tanh run on the fused phased kernels with the statistics combined across ranks (``sync_bn_tanh``).  With an injected
+    ``local_aggregate`` (CPU test double) the torch formulation of the same steps is used."""
+
+    def __init__(self, layer: nn.Module, group=None, local_aggregate: Optional[Callable] = None, bn_kernels=None):
         super().__init__()
         self.layer = layer                       # a jmac_amd.layer.RelationAwareLayer (holds the parameters)
         self.group = group
-        self.local_aggregate = local_aggregate or hip_local_aggregate
+        self.local_aggregate = local_aggregate
+        self.bn_kernels = bn_kernels
 
     def forward(self, x_local: torch.Tensor, rel_emb: torch.Tensor, sg: ShardedGraph) -> torch.Tensor:
         L = self.layer
@@ -240,8 +381,14 @@ class ShardedRelationAwareLayer(nn.Module):
         if sg.n_local < sg.n_max:                                    # pad to the common slab height
             QZ_loc = F.pad(QZ_loc, (0, 0, 0, sg.n_max - sg.n_local))
         QZ = all_gather_rows(QZ_loc.contiguous(), self.group)        # [world*n_max, 2d]
-        nb = self.local_aggregate(P.contiguous(), QZ, RR, a, sg, L.atv_mlp.negative_slope)
-        pre = (nb + Z_loc - RR[-1, d:]) * 0.5                        # self loop: softmax over a singleton
+        slope = L.atv_mlp.negative_slope
+        if self.local_aggregate is None:
+            pre = hip_local_layer(P.contiguous(), QZ, RR, a, sg, slope)
+        else:
+            nb = self.local_aggregate(P.contiguous(), QZ, RR, a, sg, slope)
+            pre = (nb + Z_loc - RR[-1, d:]) * 0.5                    # self loop: softmax over a singleton
+        if L.layer_act is torch.tanh and (self.local_aggregate is None or self.bn_kernels is not None):
+            return sync_bn_tanh(pre, L.bn, sg.n_global, self.group, self.bn_kernels)
         return L.layer_act(sync_batch_norm(pre, sg.n_global, L.bn, self.group))
 
 

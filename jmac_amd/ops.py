@@ -83,7 +83,7 @@ class _RelAttnAggregate(torch.autograd.Function):
         check(fwd()(
             ptr(PQZ), d3, PQZ.data_ptr() + d * esz, d3, ptr(RR), RR.shape[1], ptr(a),
             ptr(graph.rowptr), ptr(graph.col), ptr(graph.etype), ptr(s.items), ptr(s.splits), ptr(s.counts),
-            s.n_items_max, s.n_splits_max, s.n_parts_max, N, d, float(slope), int(loop_rel), float(out_scale),
+            s.n_items_max, s.n_splits_max, s.n_parts_max, N, d, float(slope), int(loop_rel), 0, float(out_scale),
             ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(ws), ws_bytes, stream()),
             "jmac_rel_attn_aggregate_fwd_%s" % ("bf16" if bf16 else "f32"))
         if ev0 is not None:
@@ -124,7 +124,7 @@ class _RelAttnAggregate(torch.autograd.Function):
             ptr(PQZ), d3, PQZ.data_ptr() + d * esz, d3, ptr(RR), RR.shape[1], ptr(a),
             ptr(graph.col), ptr(graph.etype), ptr(graph.dst_of_slot) if mode else None,
             C.byref(vd), C.byref(vs) if mode else None, C.byref(vr) if mode else None,
-            N, N, graph.E, nrel, d, float(ctx.slope), int(ctx.loop_rel), float(ctx.out_scale),
+            N, N, graph.E, nrel, d, float(ctx.slope), int(ctx.loop_rel), 0, float(ctx.out_scale),
             ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(G), d,
             ptr(dPQZ), d3, dPQZ.data_ptr() + d * esz, d3, ptr(dRR), dRR.shape[1], ptr(da),
             mode, ptr(ws), ws_bytes, stream()), "jmac_rel_attn_aggregate_bwd_f32")
@@ -143,10 +143,10 @@ def rel_attn_aggregate(PQZ: torch.Tensor, RR: torch.Tensor, a: torch.Tensor, gra
 
 class _RelAttnAggregateSplit(torch.autograd.Function):
     """Same op with P [N_dst, d] and QZ [N_src, 2d] as separate tables (destination-sharded multi-GPU: P holds
-    the rank's rows, QZ the all-gathered table).  No fused self term (the two index spaces differ)."""
+    the rank's rows, QZ the all-gathered table).  The fused self term reads QZ[self_off + i] (loop_rel < 0: none)."""
 
     @staticmethod
-    def forward(ctx, P, QZ, RR, a, graph: RelGraph, slope: float, out_scale: float):
+    def forward(ctx, P, QZ, RR, a, graph: RelGraph, slope: float, out_scale: float, loop_rel: int, self_off: int):
         require_device(P, QZ, RR, a)
         P, QZ, RR, a = _f32c(P).contiguous(), _f32c(QZ).contiguous(), _f32c(RR).contiguous(), _f32c(a).contiguous()
         N, d = P.shape
@@ -164,12 +164,12 @@ class _RelAttnAggregateSplit(torch.autograd.Function):
         check(L.jmac_rel_attn_aggregate_fwd_f32(
             ptr(P), d, ptr(QZ), 2 * d, ptr(RR), RR.shape[1], ptr(a),
             ptr(graph.rowptr), ptr(graph.col), ptr(graph.etype), ptr(s.items), ptr(s.splits), ptr(s.counts),
-            s.n_items_max, s.n_splits_max, s.n_parts_max, N, d, float(slope), -1, float(out_scale),
+            s.n_items_max, s.n_splits_max, s.n_parts_max, N, d, float(slope), int(loop_rel), int(self_off), float(out_scale),
             ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(ws), ws_bytes, stream()), "jmac_rel_attn_aggregate_fwd_f32")
         if ev0 is not None:
             PROFILE.append(("rel_attn_fwd", ev0, _ev()))
         ctx.save_for_backward(P, QZ, RR, a, out, seg_max, seg_den)
-        ctx.graph, ctx.slope, ctx.out_scale = graph, slope, out_scale
+        ctx.graph, ctx.slope, ctx.out_scale, ctx.loop_rel, ctx.self_off = graph, slope, out_scale, int(loop_rel), int(self_off)
         return out
 
     @staticmethod
@@ -191,17 +191,18 @@ class _RelAttnAggregateSplit(torch.autograd.Function):
         check(L.jmac_rel_attn_aggregate_bwd_f32(
             ptr(P), d, ptr(QZ), 2 * d, ptr(RR), RR.shape[1], ptr(a),
             ptr(graph.col), ptr(graph.etype), ptr(graph.dst_of_slot), C.byref(vd), C.byref(vs), C.byref(vr),
-            N, nsrc, graph.E, nrel, d, float(ctx.slope), -1, float(ctx.out_scale),
+            N, nsrc, graph.E, nrel, d, float(ctx.slope), ctx.loop_rel, ctx.self_off, float(ctx.out_scale),
             ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(G), d,
             ptr(dP), d, ptr(dQZ), 2 * d, ptr(dRR), dRR.shape[1], ptr(da), 1, ptr(ws), ws_bytes, stream()),
             "jmac_rel_attn_aggregate_bwd_f32")
         if ev0 is not None:
             PROFILE.append(("rel_attn_bwd", ev0, _ev()))
-        return dP, dQZ, dRR, da, None, None, None
+        return dP, dQZ, dRR, da, None, None, None, None, None
 
 
-def rel_attn_aggregate_split(P, QZ, RR, a, graph: RelGraph, slope: float, out_scale: float = 1.0) -> torch.Tensor:
-    return _RelAttnAggregateSplit.apply(P, QZ, RR, a, graph, float(slope), float(out_scale))
+def rel_attn_aggregate_split(P, QZ, RR, a, graph: RelGraph, slope: float, out_scale: float = 1.0, loop_rel: int = -1,
+                             self_off: int = 0) -> torch.Tensor:
+    return _RelAttnAggregateSplit.apply(P, QZ, RR, a, graph, float(slope), float(out_scale), int(loop_rel), int(self_off))
 
 
 class _BnTanh(torch.autograd.Function):

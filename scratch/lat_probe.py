@@ -31,7 +31,7 @@ def run(name, ei, et, n, bwd=False):
         st = stream()
         args = (ptr(PQZ), 3 * d, PQZ.data_ptr() + d * 4, 3 * d, ptr(RR), 2 * d, ptr(a), ptr(g.rowptr), ptr(g.col), ptr(g.etype),
                 ptr(sc.items), ptr(sc.splits), ptr(sc.counts), sc.n_items_max, sc.n_splits_max, sc.n_parts_max, n, d, 0.05,
-                nrel - 1, 0.5, ptr(out), d, ptr(smax), ptr(sden), ptr(ws), wsb, st)
+                nrel - 1, 0, 0.5, ptr(out), d, ptr(smax), ptr(sden), ptr(ws), wsb, st)
         fn = lambda: L.jmac_rel_attn_aggregate_fwd_f32(*args)
         iters = 300
     for _ in range(10): fn()

@@ -35,6 +35,31 @@ def _standin_aggregate(P, QZ, RR, a, sg, slope):
     return orc.scatter_sum(alpha * diff[:, d:], dst, sg.n_local) * deg.sqrt().view(-1, 1)
 
 
+class _StandinBN:
+    """Test double for the phased BN + tanh kernels (include/jmac_hip.h): same contract, torch on the CPU."""
+
+    @staticmethod
+    def moments(x):
+        m = x.mean(0)
+        return m, ((x - m) ** 2).sum(0)
+
+    @staticmethod
+    def apply(x, weight, bias, mean, invstd):
+        return torch.tanh((x - mean) * invstd * weight + bias)
+
+    @staticmethod
+    def bwd_sums(x, y, gy, mean, invstd):
+        gz = gy * (1 - y * y)
+        return torch.cat([gz.sum(0), (gz * (x - mean) * invstd).sum(0)])
+
+    @staticmethod
+    def bwd_apply(x, y, gy, weight, mean, invstd, sums, n_total):
+        d = x.shape[1]
+        gz = gy * (1 - y * y)
+        xh = (x - mean) * invstd
+        return weight * invstd * (gz - (sums[:d] + xh * sums[d:]) / n_total)
+
+
 def _case(seed=3, n=90, nr=7, d=16, e=700):
     rng = np.random.default_rng(seed)
     ei, et = random_graph(rng, n, nr, e, hub=120)
@@ -56,7 +81,8 @@ def _worker(rank, world, port, ret):
         sg = ShardedGraph(ei, et, bounds, rank)
         torch.manual_seed(11)
         base = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())
-        lay = ShardedRelationAwareLayer(base, local_aggregate=_standin_aggregate).train()
+        lay = ShardedRelationAwareLayer(base, local_aggregate=_standin_aggregate,
+                                        bn_kernels=_StandinBN if os.environ.get("JMAC_TEST_FUSED_BN") else None).train()
         x = X[sg.lo:sg.hi].clone().requires_grad_(True)
         r = R.clone().requires_grad_(True)
         out = lay(x, r, sg)
@@ -72,8 +98,15 @@ def _worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(300)
-def test_sharded_layer_equals_single_process_oracle():
+@pytest.mark.parametrize("fused_bn", [False, True])
+def test_sharded_layer_equals_single_process_oracle(fused_bn, monkeypatch):
+    """fused_bn: BatchNorm + tanh through sync_bn_tanh (per-rank moments, all-gather, Chan combination, all-reduced
+    backward sums) with the kernels' torch stand-in; otherwise the plain torch formulation."""
     world = 2
+    if fused_bn:
+        monkeypatch.setenv("JMAC_TEST_FUSED_BN", "1")
+    else:
+        monkeypatch.delenv("JMAC_TEST_FUSED_BN", raising=False)
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
