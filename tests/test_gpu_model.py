@@ -116,3 +116,38 @@ def test_dbpv1_model_matches_reference_golden():
     assert_close(m.ent_completion_att.grad, g["aloss_grad_ent"], 1e-4, 1e-7)
     assert_close(m.all_linear_comp.grad, g["aloss_grad_all_linear"], 1e-4, 1e-7)
     assert_close(m.rel_info_att.grad, g["aloss_grad_rel_info"], 1e-4, 1e-7)
+
+
+def test_forward_no_name_pred_head_and_subset_candidates():
+    """The branches train.py's defaults do not take: --no_name_info (src/jmac_model.py:207-220), pred_head=True
+    (:308-309) and an all_index that is a proper subset (:304-305), against the oracle on the golden model's weights."""
+    import types
+    import oracle.jmac_oracle as orc
+    from jmac_amd.model import JMAC
+    g = load_golden("model_small")
+    args = make_args(dim=int(g["d"]), dropout=0.0, num_gcn_layer=2, num_negative=5, margin_align=1.0,
+                     margin_completion=5.0, batch_size=40, no_name_info=True, device="cuda")
+    m = JMAC(args, g["name_emb"], 2 * int(g["nrel"]), int(g["n1"]) + int(g["n2"]))
+    sd = {k[len("state."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("state.")}
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    e1i, e1t, eb1, rb1 = _graphs(g)[:4]
+    p = {k: v.double() for k, v in sd.items()}
+    bn = {k: v.clone() for k, v in p.items() if "running" in k}
+    ref_out, ref_comp, ref_rel = orc.forward_no_name(p, e1i.cpu(), e1t.cpu(), eb1, rb1, 2, 0.05, "sub", False, bn)
+    with torch.no_grad():
+        out, comp, rel = m.forward_base(e1i, e1t, eb1, rb1)
+        assert m.forward_base.__func__ is JMAC.forward_no_name
+        assert_close(out, ref_out, 1e-4) and assert_close(comp[1], ref_comp[1], 1e-4) and assert_close(rel[1], ref_rel[1], 1e-4)
+        h, r = g["lp_h"].tolist(), g["lp_r"].tolist()
+        n1 = int(g["n1"])
+        d_head = m.forward_linkpred(h, r, e1i, e1t, list(range(n1)), eb1, rb1, pred_head=True)
+        assert_close(d_head, orc.linkpred_dist(ref_comp, ref_rel, h, r, pred_head=True), 1e-4)
+        sub = list(range(5, n1, 3))                                   # candidates = a subset of the entities
+        hs = [x % len(sub) for x in h]                                # e_index addresses the SUBSET table (:304-306)
+        d_sub = m.forward_linkpred(hs, r, e1i, e1t, sub, eb1, rb1)
+        want = 0
+        for ent, rl in zip(ref_comp, ref_rel):
+            ent_s = ent[torch.tensor(sub)]
+            want = want + torch.cdist(ent_s[torch.tensor(hs)] + rl[torch.tensor(r)], ent_s, p=1)
+        assert_close(d_sub, want, 1e-4)
