@@ -355,7 +355,7 @@ def sim_bench(device, iters=10):
     test_ms = t(lambda: scoring.alignment_test(tab[:10500], tab[10500:21000], (1, 5, 10), csls_k=10), 3)
     return {"workload": "config 5 shape: N=30000 d=300; quality GEMM 12000x12000, get_neg 3000x30000 k=25, CSLS test 10500^2",
             "sim_gemm_ms": gemm_ms, "sim_gemm_tflops": tf, "mfma_frac_of_f32_peak": tf / MFMA_F32_PEAK_TFLOPS,
-            "mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS, "get_neg_ms": neg_ms, "get_neg_pairs_per_s": 3000 * 30000 / (neg_ms * 1e-3),
+            "mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS, "mfma_util_pmc_percent": pmc_mfma_util(), "get_neg_ms": neg_ms, "get_neg_pairs_per_s": 3000 * 30000 / (neg_ms * 1e-3),
             "alignment_test_ms": test_ms}
 
 
@@ -411,6 +411,15 @@ def pmc_traffic(key, kernel_prefix):
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def pmc_mfma_util():
+    """rocprofv3's MfmaUtil for sim_gemm_kernel from the committed PMC pass (profiles/r1_pmc_simgemm.json), or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_simgemm.json")))
+        return d["kernels"]["sim_gemm_kernel"]["MfmaUtil_percent_mean"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
