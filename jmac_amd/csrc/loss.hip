@@ -44,9 +44,16 @@ __global__ __launch_bounds__(kBlock) void triple_l1_fwd_kernel(const float* __re
         const int64_t b = u / parts, p = u % parts;
         int64_t ch = -1, cr = -1;
         float hr[NK];
-        for (int64_t x = b + p * period; x < T; x += stride) {
-            const int64_t ih = h[x], ir = r[x];
-            if (ih != ch || ir != cr) {          // wave-uniform
+        // two triples of the run per iteration: the index loads and the tail rows of both are in flight together
+        // (a wave's run is only a few triples long: without this every triple is its own index -> row -> reduce chain)
+        int64_t x = b + p * period;
+        while (x < T) {
+            const int64_t x2 = x + stride;
+            const bool in2 = x2 < T;
+            const int64_t ih = h[x], ir = r[x], it = t[x];
+            const int64_t ih2 = h[in2 ? x2 : x], ir2 = r[in2 ? x2 : x], it2 = t[in2 ? x2 : x];
+            const bool pair = in2 && ih2 == ih && ir2 == ir;          // wave-uniform
+            if (ih != ch || ir != cr) {
                 ch = ih;
                 cr = ir;
                 const float* ph = ent + ih * lde;
@@ -57,15 +64,30 @@ __global__ __launch_bounds__(kBlock) void triple_l1_fwd_kernel(const float* __re
                     hr[k] = c < d ? ph[c] + pr[c] : 0.f;
                 }
             }
-            const float* pt = ent + t[x] * lde;
-            float acc = 0.f;
+            const float* pt = ent + it * lde;
+            const float* pt2 = ent + (pair ? it2 : it) * lde;
+            float tv[NK], tv2[NK];
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
                 const int c = lane + 64 * k;
-                if (c < d) acc += fabsf(hr[k] - pt[c]);
+                tv[k] = c < d ? pt[c] : 0.f;
+                tv2[k] = c < d ? pt2[c] : 0.f;
             }
-            acc = wave_sum(acc);
-            if (lane == 0) score[x] = acc;
+            float acc[2] = {0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int c = lane + 64 * k;
+                if (c < d) {
+                    acc[0] += fabsf(hr[k] - tv[k]);
+                    acc[1] += fabsf(hr[k] - tv2[k]);
+                }
+            }
+            wave_sum_n<2>(acc);
+            if (lane == 0) {
+                score[x] = acc[0];
+                if (pair) score[x2] = acc[1];
+            }
+            x += pair ? 2 * stride : stride;
         }
     }
 }
@@ -99,9 +121,14 @@ __global__ __launch_bounds__(kBlock) void triple_l1_bwd_kernel(const float* __re
                 }
             }
         };
-        for (int64_t x = b + p * period; x < T; x += stride) {
+        int64_t x = b + p * period;
+        while (x < T) {
+            const int64_t x2 = x + stride;
+            const bool in2 = x2 < T;
             const int64_t ih = h[x], ir = r[x], it = t[x];
-            if (ih != ch || ir != cr) {          // wave-uniform
+            const int64_t ih2 = h[in2 ? x2 : x], ir2 = r[in2 ? x2 : x], it2 = t[in2 ? x2 : x];
+            const bool pair = in2 && ih2 == ih && ir2 == ir;          // wave-uniform
+            if (ih != ch || ir != cr) {
                 flush();
                 ch = ih;
                 cr = ir;
@@ -114,18 +141,30 @@ __global__ __launch_bounds__(kBlock) void triple_l1_bwd_kernel(const float* __re
                     acc[k] = 0.f;
                 }
             }
-            const float g = gscore[x];
+            const float g = gscore[x], g2 = pair ? gscore[x2] : 0.f;
             const float* pt = ent + it * lde;
+            const float* pt2 = ent + (pair ? it2 : it) * lde;
             float* qt = dent + it * ldde;
+            float* qt2 = dent + (pair ? it2 : it) * ldde;
+            float tv[NK], tv2[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int c = lane + 64 * k;
+                tv[k] = c < d ? pt[c] : 0.f;
+                tv2[k] = c < d ? pt2[c] : 0.f;
+            }
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
                 const int c = lane + 64 * k;
                 if (c < d) {
-                    const float v = g * sgn(hr[k] - pt[c]);
-                    acc[k] += v;
+                    const float v = g * sgn(hr[k] - tv[k]);
+                    const float v2 = g2 * sgn(hr[k] - tv2[k]);
+                    acc[k] += v + v2;
                     if (v != 0.f) atomicAdd(qt + c, -v);
+                    if (v2 != 0.f) atomicAdd(qt2 + c, -v2);
                 }
             }
+            x += pair ? 2 * stride : stride;
         }
         flush();
     }
