@@ -44,14 +44,6 @@ def _table(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def L_fwd_f32():
-    return lib().jmac_rel_attn_aggregate_fwd_f32
-
-
-def L_fwd_bf16():
-    return lib().jmac_rel_attn_aggregate_fwd_bf16
-
-
 class _RelAttnAggregate(torch.autograd.Function):
     """out = out_scale * ( sqrt(deg) * softmax-weighted sum over in-edges of (Z[j]-Rz[t]) + [Z[i]-Rz[loop]] ).
 
@@ -65,7 +57,6 @@ class _RelAttnAggregate(torch.autograd.Function):
         if PQZ.dtype != RR.dtype:
             raise TypeError("PQZ and RR must share a dtype")
         bf16 = PQZ.dtype == torch.bfloat16
-        fwd = L_fwd_bf16 if bf16 else L_fwd_f32
         N, d3 = PQZ.shape
         d = d3 // 3
         if graph.N != N:
@@ -80,7 +71,8 @@ class _RelAttnAggregate(torch.autograd.Function):
         ws = _ws(ws_bytes, dev)
         esz = PQZ.element_size()
         ev0 = _ev() if PROFILE is not None else None
-        check(fwd()(
+        fwd = L.jmac_rel_attn_aggregate_fwd_bf16 if bf16 else L.jmac_rel_attn_aggregate_fwd_f32
+        check(fwd(
             ptr(PQZ), d3, PQZ.data_ptr() + d * esz, d3, ptr(RR), RR.shape[1], ptr(a),
             ptr(graph.rowptr), ptr(graph.col), ptr(graph.etype), ptr(s.items), ptr(s.splits), ptr(s.counts),
             s.n_items_max, s.n_splits_max, s.n_parts_max, N, d, float(slope), int(loop_rel), 0, float(out_scale),
