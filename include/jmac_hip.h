@@ -211,11 +211,12 @@ int jmac_l1_score_bf16(const uint16_t* er, int64_t lder, const uint16_t* table, 
                        jmac_stream_t stream);
 
 /* rank[b] = 1 + #{n : score[b,n] < score[b,gold] or (== and n < gold[b])}, where entries listed in
- * the filter CSR (filt_ptr [B+1], filt_idx) other than the gold are skipped.  `score` is a DISTANCE
- * (the reference's predictions = -dist, sorted descending).  filt_ptr may be NULL (raw ranking). */
+ * the filter CSR (filt_ptr [B+1], filt_idx) other than the gold are skipped.  descending == 0: `score` is a
+ * DISTANCE (the reference's predictions = -dist, sorted descending); descending != 0: `score` is a SIMILARITY
+ * and `<` reads `>` (alignment ranks, modules/finding/alignment.py:87-112).  filt_ptr may be NULL (raw ranking). */
 int jmac_filtered_rank_f32(const float* score, int64_t lds, const int32_t* gold,
                            const int32_t* filt_ptr, const int32_t* filt_idx, int64_t B, int64_t N,
-                           int32_t* rank, jmac_stream_t stream);
+                           int32_t descending, int32_t* rank, jmac_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Alignment scoring (replaces: get_neg's mm + topk, modules/utils/util.py:52-53; the mm / softmax /
@@ -248,10 +249,22 @@ int jmac_masked_row_softmax_f32(const float* S, int64_t lds, int64_t n1, int64_t
                                 const uint8_t* row_mask, const uint8_t* col_mask, float fill,
                                 float scale, float* out, int64_t ldo, jmac_stream_t stream);
 
+/* The k largest values of every COLUMN of S [n1,n2], descending (val [n2,k]; k <= 16) -- the column term of CSLS
+ * (calculate_nearest_k on sim_mat.T, modules/finding/similarity.py:66-67,81-84) without materialising the transpose. */
+size_t jmac_col_topk_workspace_bytes(int64_t n1, int64_t n2, int32_t k);
+int jmac_col_topk_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, int32_t k, float* val, void* ws,
+                      size_t ws_bytes, jmac_stream_t stream);
+
 /* CSLS rescoring (replaces csls_sim, modules/finding/similarity.py:58-78):
  * out[i,j] = 2*S[i,j] - r1[i] - r2[j], r1/r2 = mean of the k largest entries of row i / column j. */
 int jmac_csls_apply_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, const float* r1,
                         const float* r2, float* out, int64_t ldo, jmac_stream_t stream);
+
+/* rank[i] = 1 + #{j : c(i,j) > c(i,gold[i]) or (== and j < gold[i])} with c(i,j) = 2*S[i,j] - r1[i] - r2[j]:
+ * jmac_csls_apply_f32 followed by the descending rank count, fused (the rescored matrix is neither written nor
+ * re-read; same arithmetic, identical ranks).  Alignment evaluation: alignment.py:87-112 on similarity.py:58-78. */
+int jmac_csls_rank_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, const float* r1, const float* r2,
+                       const int32_t* gold, int32_t* rank, jmac_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Small fp32 GEMM for the relation-side projections (replaces the torch.mm calls on the ~10^3-row

@@ -65,14 +65,17 @@ _SIGS = {
     "jmac_row_normalize_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, f32, vp, i64, vp]),
     "jmac_l1_score_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, vp]),
     "jmac_l1_score_bf16": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, vp]),
-    "jmac_filtered_rank_f32": (C.c_int, [vp, i64, vp, vp, vp, i64, i64, vp, vp]),
+    "jmac_filtered_rank_f32": (C.c_int, [vp, i64, vp, vp, vp, i64, i64, i32, vp, vp]),
     "jmac_sim_matrix_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, vp]),
     "jmac_sim_topk_workspace_bytes": (sz, [i64, i64]),
     "jmac_sim_topk_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, i32, vp, vp, vp, sz, vp]),
+    "jmac_col_topk_workspace_bytes": (sz, [i64, i64, i32]),
+    "jmac_col_topk_f32": (C.c_int, [vp, i64, i64, i64, i32, vp, vp, sz, vp]),
     "jmac_row_topk_f32": (C.c_int, [vp, i64, i64, i64, i32, vp, vp, vp]),
     "jmac_softmax_entropy_workspace_bytes": (sz, [i64, i64]),
     "jmac_softmax_entropy_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, f32, vp, vp, vp, sz, vp]),
     "jmac_masked_row_softmax_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, f32, f32, vp, i64, vp]),
+    "jmac_csls_rank_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, vp]),
     "jmac_csls_apply_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, i64, vp]),
     "jmac_gemm_f32": (C.c_int, [vp, i64, i32, vp, i64, i32, i64, i64, i64, vp, i64, vp]),
     "jmac_triple_l1_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp]),

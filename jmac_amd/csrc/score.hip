@@ -130,24 +130,22 @@ __global__ __launch_bounds__(kBlock) void l1_score_kernel(const TT* __restrict__
 __global__ __launch_bounds__(kBlock) void filtered_rank_kernel(const float* __restrict__ score, int64_t lds,
                                                                const int32_t* __restrict__ gold,
                                                                const int32_t* __restrict__ filt_ptr,
-                                                               const int32_t* __restrict__ filt_idx, int N,
+                                                               const int32_t* __restrict__ filt_idx, int N, int descending,
                                                                int32_t* __restrict__ rank) {
     __shared__ int red[kBlock / 64];
     const int b = blockIdx.x;
     const float* row = score + (int64_t)b * lds;
     const int g = gold[b];
     const float gs = row[g];
+    // ascending: a DISTANCE (smaller ranks first); descending: a SIMILARITY (larger first) -- no negated copy needed
+    auto before = [&](float s, int n) { return (descending ? s > gs : s < gs) || (s == gs && n < g); };
     int cnt = 0;
-    for (int n = threadIdx.x; n < N; n += kBlock) {
-        const float s = row[n];
-        cnt += (s < gs || (s == gs && n < g)) ? 1 : 0;
-    }
+    for (int n = threadIdx.x; n < N; n += kBlock) cnt += before(row[n], n) ? 1 : 0;
     if (filt_ptr) {
         for (int f = filt_ptr[b] + threadIdx.x; f < filt_ptr[b + 1]; f += kBlock) {
             const int n = filt_idx[f];
             if (n == g || n < 0 || n >= N) continue;
-            const float s = row[n];
-            cnt -= (s < gs || (s == gs && n < g)) ? 1 : 0;
+            cnt -= before(row[n], n) ? 1 : 0;
         }
     }
     cnt = wave_sum_i(cnt);
@@ -498,6 +496,75 @@ __global__ __launch_bounds__(kBlock) void row_topk_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// column top-k values (CSLS column term, similarity.py:58-78 on the transposed matrix) without transposing:
+// one lane per column (a wave reads 256 contiguous bytes of a row), rows split over the 4 waves of a block and over
+// gridDim.y row ranges; every (block, wave) keeps its column's k largest values in registers (branch-free bubble
+// insertion, skipped by the whole wave when no lane's value beats its current k-th) and writes them as a candidate
+// list; a second kernel merges the lists of a column.  Output [n2, k] sorted descending.
+// ------------------------------------------------------------------------------------------------
+constexpr int CT_KMAX = 16;
+
+// inserts v into the descending list top[0..k) and returns its new k-th (smallest kept) value; register-only:
+// the list is never indexed with a run-time subscript
+__device__ __forceinline__ float ct_insert(float (&top)[CT_KMAX], int k, float v) {
+    float x = v, kth = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < CT_KMAX; ++j)
+        if (j < k) {
+            const float hi = fmaxf(top[j], x);
+            x = fminf(top[j], x);
+            top[j] = hi;
+            kth = j == k - 1 ? hi : kth;
+        }
+    return kth;
+}
+
+__global__ __launch_bounds__(kBlock) void col_topk_partial_kernel(const float* __restrict__ S, int64_t lds, int n1, int n2, int k,
+                                                                  float* __restrict__ cand) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int rows_per = (n1 + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per, r1 = min(n1, r0 + rows_per);
+    float top[CT_KMAX];
+#pragma unroll
+    for (int j = 0; j < CT_KMAX; ++j) top[j] = -INFINITY;
+    const int cc = min(col, n2 - 1);
+    float kth = -INFINITY;
+    for (int r = r0 + wave; r < r1; r += kBlock / 64) {
+        const float v = col < n2 ? S[(int64_t)r * lds + cc] : -INFINITY;
+        if (__any(v > kth)) kth = ct_insert(top, k, v);
+    }
+    const int part = blockIdx.y * (kBlock / 64) + wave;
+    if (col < n2) {
+        float* o = cand + ((int64_t)part * n2 + col) * k;
+#pragma unroll
+        for (int j = 0; j < CT_KMAX; ++j)
+            if (j < k) o[j] = top[j];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void col_topk_merge_kernel(const float* __restrict__ cand, int parts, int n2, int k,
+                                                                float* __restrict__ out) {
+    const int col = blockIdx.x * kBlock + threadIdx.x;
+    if (col >= n2) return;
+    float top[CT_KMAX];
+#pragma unroll
+    for (int j = 0; j < CT_KMAX; ++j) top[j] = -INFINITY;
+    float kth = -INFINITY;
+    for (int p = 0; p < parts; ++p) {
+        const float* c = cand + ((int64_t)p * n2 + col) * k;
+        for (int j = 0; j < k; ++j) {
+            const float v = c[j];
+            if (!(v > kth)) break;                        // lists are sorted: nothing further of this one can enter
+            kth = ct_insert(top, k, v);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CT_KMAX; ++j)
+        if (j < k) out[(int64_t)col * k + j] = top[j];
+}
+
+// ------------------------------------------------------------------------------------------------
 // softmax entropy of the rows of scale*S;  masked row softmax
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float block_max(float v, float* sh) {
@@ -572,6 +639,32 @@ __global__ __launch_bounds__(kBlock) void csls_apply_kernel(const float* __restr
     }
 }
 
+// rank of column gold[i] in row i of the CSLS-rescored matrix 2 S - r1[i] - r2[j], descending, ties -> lower index first:
+// csls_apply + filtered_rank(descending) without writing or re-reading the rescored matrix.
+__global__ __launch_bounds__(kBlock) void csls_rank_kernel(const float* __restrict__ S, int64_t lds, int n2,
+                                                           const float* __restrict__ r1, const float* __restrict__ r2,
+                                                           const int32_t* __restrict__ gold, int32_t* __restrict__ rank) {
+    __shared__ int red[kBlock / 64];
+    const int i = blockIdx.x;
+    const float* row = S + (int64_t)i * lds;
+    const float a = r1[i];
+    const int g = gold[i];
+    const float gs = 2.f * row[g] - a - r2[g];
+    int cnt = 0;
+    for (int n = threadIdx.x; n < n2; n += kBlock) {
+        const float v = 2.f * row[n] - a - r2[n];
+        cnt += (v > gs || (v == gs && n < g)) ? 1 : 0;
+    }
+    cnt = wave_sum_i(cnt);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < kBlock / 64; ++w) t += red[w];
+        rank[i] = t + 1;
+    }
+}
+
 int launch_sim(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t d, float* C, int64_t ldc,
                hipStream_t st) {
     if (M == 0 || N == 0) return 0;
@@ -636,13 +729,14 @@ int jmac_l1_score_bf16(const uint16_t* er, int64_t lder, const uint16_t* table, 
 }
 
 int jmac_filtered_rank_f32(const float* score, int64_t lds, const int32_t* gold, const int32_t* filt_ptr,
-                           const int32_t* filt_idx, int64_t B, int64_t N, int32_t* rank, jmac_stream_t stream) {
+                           const int32_t* filt_idx, int64_t B, int64_t N, int32_t descending, int32_t* rank,
+                           jmac_stream_t stream) {
     if (B < 0 || N <= 0) return JMAC_EINVAL;
     if (B == 0) return JMAC_OK;
     if (!score || !gold || !rank || (filt_ptr && !filt_idx && false)) return JMAC_EINVAL;
     if (N >= INT32_MAX) return JMAC_ERANGE;
     hipLaunchKernelGGL(filtered_rank_kernel, dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, score, lds, gold, filt_ptr,
-                       filt_idx, (int)N, rank);
+                       filt_idx, (int)N, descending ? 1 : 0, rank);
     return (int)hipGetLastError();
 }
 
@@ -723,6 +817,47 @@ int jmac_masked_row_softmax_f32(const float* S, int64_t lds, int64_t n1, int64_t
     if (!S || !out) return JMAC_EINVAL;
     hipLaunchKernelGGL(masked_row_softmax_kernel, dim3((unsigned)n1), dim3(kBlock), 0, (hipStream_t)stream, S, lds, (int)n2,
                        row_mask, col_mask, fill, scale, out, ldo);
+    return (int)hipGetLastError();
+}
+
+static int col_topk_row_splits(int64_t n1, int64_t n2) {
+    const int64_t strips = (n2 + 63) / 64;
+    int64_t rs = (2048 + strips - 1) / strips;            // ~2k blocks
+    const int64_t max_rs = (n1 + 63) / 64;                // at least 64 rows per block
+    if (rs > max_rs) rs = max_rs;
+    if (rs < 1) rs = 1;
+    return (int)rs;
+}
+
+size_t jmac_col_topk_workspace_bytes(int64_t n1, int64_t n2, int32_t k) {
+    if (n1 < 0 || n2 < 0 || k <= 0) return 0;
+    return align_up((size_t)col_topk_row_splits(n1, n2) * (kBlock / 64) * (size_t)n2 * (size_t)k * 4) + 256;
+}
+
+int jmac_col_topk_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, int32_t k, float* val, void* ws, size_t ws_bytes,
+                      jmac_stream_t stream) {
+    if (n1 <= 0 || n2 <= 0 || k <= 0 || k > n1) return JMAC_EINVAL;
+    if (k > CT_KMAX) return JMAC_EDIM;
+    if (!S || !val) return JMAC_EINVAL;
+    if (n1 >= INT32_MAX || n2 >= INT32_MAX) return JMAC_ERANGE;
+    if (!ws || ws_bytes < jmac_col_topk_workspace_bytes(n1, n2, k)) return JMAC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int rs = col_topk_row_splits(n1, n2);
+    float* cand = (float*)ws;
+    hipLaunchKernelGGL(col_topk_partial_kernel, dim3((unsigned)((n2 + 63) / 64), (unsigned)rs), dim3(kBlock), 0, st, S, lds, (int)n1,
+                       (int)n2, (int)k, cand);
+    hipLaunchKernelGGL(col_topk_merge_kernel, dim3((unsigned)((n2 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, cand,
+                       rs * (kBlock / 64), (int)n2, (int)k, val);
+    return (int)hipGetLastError();
+}
+
+int jmac_csls_rank_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, const float* r1, const float* r2, const int32_t* gold,
+                       int32_t* rank, jmac_stream_t stream) {
+    if (n1 < 0 || n2 <= 0) return JMAC_EINVAL;
+    if (n1 == 0) return JMAC_OK;
+    if (!S || !r1 || !r2 || !gold || !rank) return JMAC_EINVAL;
+    if (n2 >= INT32_MAX) return JMAC_ERANGE;
+    hipLaunchKernelGGL(csls_rank_kernel, dim3((unsigned)n1), dim3(kBlock), 0, (hipStream_t)stream, S, lds, (int)n2, r1, r2, gold, rank);
     return (int)hipGetLastError();
 }
 

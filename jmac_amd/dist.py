@@ -421,7 +421,7 @@ class _HipScoring:
     def rank_of_gold(s, gold):
         """1-based rank of column gold[i] in row i of s, descending, ties -> lower index first."""
         from . import scoring
-        return scoring.filtered_rank(-s, gold.to(torch.int32)).to(torch.int64)
+        return scoring.filtered_rank(s, gold.to(torch.int32), descending=True).to(torch.int64)
 
 
 def shard_rows(n: int, world: int, rank: int) -> Tuple[int, int]:

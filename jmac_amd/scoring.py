@@ -77,17 +77,17 @@ def build_filter_csr(heads, rels, true_tail: Dict, device) -> Tuple[torch.Tensor
 
 
 def filtered_rank(dist: torch.Tensor, gold, filt_ptr: Optional[torch.Tensor] = None,
-                  filt_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """1-based rank of the gold tail under ascending distance; filtered entries are skipped.
-    Ties: an equal score counts as ranked before the gold iff its index is lower."""
+                  filt_idx: Optional[torch.Tensor] = None, descending: bool = False) -> torch.Tensor:
+    """1-based rank of the gold tail under ascending distance (``descending``: under descending similarity); filtered
+    entries are skipped.  Ties: an equal score counts as ranked before the gold iff its index is lower."""
     require_device(dist)
     if dist.dtype != torch.float32 or dist.stride(1) != 1:
         raise TypeError("dist must be fp32 with unit column stride")
     B, N = dist.shape
     gold = torch.as_tensor(gold, device=dist.device).to(torch.int32).contiguous()
     rank = torch.empty(B, dtype=torch.int32, device=dist.device)
-    check(lib().jmac_filtered_rank_f32(ptr(dist), dist.stride(0), ptr(gold), ptr(filt_ptr), ptr(filt_idx), B, N, ptr(rank),
-                                       stream()), "jmac_filtered_rank_f32")
+    check(lib().jmac_filtered_rank_f32(ptr(dist), dist.stride(0), ptr(gold), ptr(filt_ptr), ptr(filt_idx), B, N,
+                                       1 if descending else 0, ptr(rank), stream()), "jmac_filtered_rank_f32")
     return rank
 
 
@@ -129,6 +129,25 @@ def row_topk(s: torch.Tensor, k: int):
     val = torch.empty((L_, k), dtype=torch.float32, device=s.device)
     check(lib().jmac_row_topk_f32(ptr(s), N, L_, N, int(k), ptr(val), ptr(idx), stream()), "jmac_row_topk_f32")
     return val, idx.to(torch.int64)
+
+
+COL_TOPK_KMAX = 16
+
+
+def col_topk_values(s: torch.Tensor, k: int) -> torch.Tensor:
+    """The k largest values of every column of s, [n2, k] descending == ``row_topk(s.t().contiguous(), k)[0]`` without
+    the transpose (k <= 16; larger k takes the transposing path)."""
+    require_device(s)
+    s = s.contiguous()
+    n1, n2 = s.shape
+    if k > COL_TOPK_KMAX:
+        return row_topk(s.t().contiguous(), k)[0]
+    val = torch.empty((n2, k), dtype=torch.float32, device=s.device)
+    L = lib()
+    wsb = int(L.jmac_col_topk_workspace_bytes(n1, n2, int(k)))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=s.device)
+    check(L.jmac_col_topk_f32(ptr(s), n2, n1, n2, int(k), ptr(val), ptr(ws), wsb, stream()), "jmac_col_topk_f32")
+    return val
 
 
 def get_neg(ILL, emb_src: torch.Tensor, emb_dst: torch.Tensor, k: int) -> torch.Tensor:
@@ -190,18 +209,32 @@ def csls_sim(sim: torch.Tensor, k: int) -> torch.Tensor:
     sim = sim.contiguous()
     n1, n2 = sim.shape
     r1 = row_topk(sim, k)[0].mean(1)
-    r2 = row_topk(sim.t().contiguous(), k)[0].mean(1)
+    r2 = col_topk_values(sim, k).mean(1)
     out = torch.empty_like(sim)
     check(lib().jmac_csls_apply_f32(ptr(sim), n2, n1, n2, ptr(r1), ptr(r2), ptr(out), n2, stream()), "jmac_csls_apply_f32")
     return out
+
+
+def csls_rank(sim: torch.Tensor, k: int, gold) -> torch.Tensor:
+    """1-based rank of column gold[i] in row i of ``csls_sim(sim, k)`` (descending, ties -> lower index first) without
+    materialising the rescored matrix: the same r1 / r2 and the same ``2 s - r1 - r2`` arithmetic, consumed by the count."""
+    require_device(sim)
+    sim = sim.contiguous()
+    n1, n2 = sim.shape
+    r1 = row_topk(sim, k)[0].mean(1)
+    r2 = col_topk_values(sim, k).mean(1)
+    gold = torch.as_tensor(gold, device=sim.device).to(torch.int32).contiguous()
+    rank = torch.empty(n1, dtype=torch.int32, device=sim.device)
+    check(lib().jmac_csls_rank_f32(ptr(sim), n2, n1, n2, ptr(r1), ptr(r2), ptr(gold), ptr(rank), stream()), "jmac_csls_rank_f32")
+    return rank
 
 
 def alignment_sim(embed1: torch.Tensor, embed2: torch.Tensor, metric: str = "cosine", normalize: bool = False,
                   csls_k: int = 0) -> torch.Tensor:
     """sim(), similarity.py:13-55, for the metrics train.py uses ('cosine', 'inner')."""
     if normalize or metric == "cosine":
-        embed1 = torch.nn.functional.normalize(embed1, 2, -1)
-        embed2 = torch.nn.functional.normalize(embed2, 2, -1)
+        from .ops import row_normalize
+        embed1, embed2 = row_normalize(embed1.detach()), row_normalize(embed2.detach())
     elif metric != "inner":
         raise NotImplementedError("metric %r (train.py:105-113 uses 'cosine')" % metric)
     s = sim_matrix(embed1, embed2)
@@ -212,9 +245,12 @@ def alignment_test(embeds1: torch.Tensor, embeds2: torch.Tensor, top_k=(1, 5, 10
                    normalize: bool = False, csls_k: int = 10):
     """test() / greedy_alignment() / calculate_rank(accurate=True), evaluation.py:20-28, alignment.py:10-112:
     row i of embeds1 is aligned with row i of embeds2.  Returns (top_k, hits [%], mr, mrr)."""
-    s = alignment_sim(embeds1, embeds2, metric, normalize, csls_k)
+    s = alignment_sim(embeds1, embeds2, metric, normalize, 0)
     n = s.shape[0]
     gold = torch.arange(n, device=s.device, dtype=torch.int32)
-    rank = filtered_rank(-s, gold).to(torch.float64)                  # 1-based; ascending "distance" = descending sim
+    if csls_k > 0:                                                     # CSLS rescoring fused into the rank count
+        rank = csls_rank(s, csls_k, gold).to(torch.float64)
+    else:
+        rank = filtered_rank(s, gold, descending=True).to(torch.float64)   # 1-based position in the descending order
     hits = [float((rank <= k).double().mean().item() * 100.0) for k in top_k]
     return list(top_k), [round(h, 3) for h in hits], float(rank.mean().item()), float((1.0 / rank).mean().item())

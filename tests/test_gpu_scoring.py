@@ -175,3 +175,30 @@ def test_alignment_eval_matches_reference_golden():
     got = scoring.alignment_test(a.cuda(), b.cuda(), (1, 5, 10), "cosine", False, 10)
     want = orc.alignment_test(a, b, (1, 5, 10), 10)
     assert got[1] == want[1] and abs(got[2] - want[2]) < 1e-9 and abs(got[3] - want[3]) < 1e-12
+
+
+@pytest.mark.parametrize("n1,n2,k", [(500, 333, 10), (10500, 1000, 10), (64, 5000, 16), (37, 70, 1), (300, 129, 25)])
+def test_col_topk_values_equal_transposed_row_topk(n1, n2, k):
+    """CSLS column term without the transpose (k > 16 takes the transposing path): same values, bit for bit; ties and
+    -inf padding (fewer rows than one block's waves) included."""
+    from jmac_amd import scoring
+    gen = torch.Generator().manual_seed(n1 + n2)
+    s = torch.randn(n1, n2, generator=gen)
+    s[:, 3] = 0.5                                          # a constant column
+    s[: n1 // 2, 5] = s[n1 // 2: 2 * (n1 // 2), 5]          # every value twice
+    got = scoring.col_topk_values(s.cuda(), k)
+    want = s.t().topk(k, dim=1).values
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(got, scoring.row_topk(s.cuda().t().contiguous(), k)[0])
+
+
+def test_csls_rank_equals_csls_sim_then_rank():
+    from jmac_amd import scoring
+    gen = torch.Generator().manual_seed(9)
+    a = torch.nn.functional.normalize(torch.randn(700, 64, generator=gen))
+    b = torch.nn.functional.normalize(a + 0.5 * torch.randn(700, 64, generator=gen))
+    s = scoring.sim_matrix(a.cuda(), b.cuda())
+    s[5] = 0.25                                                          # a constant row: every entry ties after rescoring? no: r2 differs
+    gold = torch.randint(0, 700, (700,), generator=gen)
+    want = scoring.filtered_rank(scoring.csls_sim(s, 10), gold, descending=True)
+    assert torch.equal(scoring.csls_rank(s, 10, gold), want)
