@@ -418,6 +418,12 @@ class _HipScoring:
         return scoring.row_topk(s, k)[0]
 
     @staticmethod
+    def col_topk_values(s, k):
+        """[n2, k]: the k largest entries of every column of the rank's row block (no transpose)."""
+        from . import scoring
+        return scoring.col_topk_values(s, k)
+
+    @staticmethod
     def rank_of_gold(s, gold):
         """1-based rank of column gold[i] in row i of s, descending, ties -> lower index first."""
         from . import scoring
@@ -486,7 +492,7 @@ def sharded_alignment_test(embeds1: torch.Tensor, embeds2: torch.Tensor, top_k=(
         r1 = kn.row_topk_values(s, csls_k).mean(1)                    # row term: local
         kk = min(csls_k, max(hi - lo, 1))
         if hi > lo:
-            colv = kn.row_topk_values(s.t().contiguous(), kk)         # [n2, kk]: this rank's candidates per column
+            colv = kn.col_topk_values(s, kk)                          # [n2, kk]: this rank's candidates per column
         else:
             colv = s.new_full((n2, kk), float("-inf"))
         if kk < csls_k:

@@ -36,6 +36,10 @@ class _Standin:
         return s.topk(k, dim=1).values
 
     @staticmethod
+    def col_topk_values(s, k):
+        return s.t().topk(k, dim=1).values
+
+    @staticmethod
     def rank_of_gold(s, gold):
         g = s.gather(1, gold.view(-1, 1))
         idx = torch.arange(s.shape[1]).view(1, -1)
