@@ -68,3 +68,14 @@ def test_state_dict_keys_match_reference():
     m = JMAC(args, g["name_emb"], 2 * int(g["nrel"]), int(g["n1"]) + int(g["n2"]))
     assert sorted(m.state_dict().keys()) == ref_keys
     m.load_state_dict({k: torch.from_numpy(g["state." + k]) for k in ref_keys}, strict=True)
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py measures the product path only: on a box without a HIP device it exits with a message instead of
+    timing a CPU stand-in (the cpu_baseline leg is the only place the oracle is timed, beside a GPU run)."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode != 0 and "MI355X" in (res.stderr + res.stdout) and res.stdout.strip() == ""
