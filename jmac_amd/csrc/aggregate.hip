@@ -699,29 +699,31 @@ __global__ __launch_bounds__(kBlock) void colsum_partial_kernel(const float* __r
     }
 }
 
-// out[c] = scale * sum_p partial[p][c]: 64 columns x 16 row lanes per 1024-thread block
+// out[c] = scale * sum_p partial[p][c]: 16 columns x 64 row lanes per 1024-thread block (a block's rows are read as 64-byte
+// segments; 16 columns per block instead of 64 puts 19 blocks instead of 5 on a 300-wide reduction: 6.6 -> ~4 us)
+constexpr int RR_COLS = 16, RR_LANES = 1024 / RR_COLS;
 __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ partial, int nparts, int W, float scale,
                                                            float* __restrict__ outp) {
-    __shared__ float red[16][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
+    __shared__ float red[RR_LANES][RR_COLS];
+    const int cl = threadIdx.x % RR_COLS, rl = threadIdx.x / RR_COLS;
+    const int c = blockIdx.x * RR_COLS + cl;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c < W) {
         int p = rl;
-        for (; p + 48 < nparts; p += 64) {
+        for (; p + 3 * RR_LANES < nparts; p += 4 * RR_LANES) {
             a0 += partial[(int64_t)p * W + c];
-            a1 += partial[(int64_t)(p + 16) * W + c];
-            a2 += partial[(int64_t)(p + 32) * W + c];
-            a3 += partial[(int64_t)(p + 48) * W + c];
+            a1 += partial[(int64_t)(p + RR_LANES) * W + c];
+            a2 += partial[(int64_t)(p + 2 * RR_LANES) * W + c];
+            a3 += partial[(int64_t)(p + 3 * RR_LANES) * W + c];
         }
-        for (; p < nparts; p += 16) a0 += partial[(int64_t)p * W + c];
+        for (; p < nparts; p += RR_LANES) a0 += partial[(int64_t)p * W + c];
     }
-    red[rl][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+    red[rl][cl] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (rl == 0 && c < W) {
-        float s = red[0][threadIdx.x];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) s += red[r][threadIdx.x];
+        float s = red[0][cl];
+#pragma unroll 8
+        for (int r = 1; r < RR_LANES; ++r) s += red[r][cl];
         outp[c] = s * scale;
     }
 }
@@ -793,7 +795,7 @@ inline unsigned split_grid(int64_t n_splits_max) {
 
 namespace jmac {
 void launch_reduce_rows(const float* partial, int nparts, int W, float scale, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((W + 63) / 64)), dim3(1024), 0, st, partial, nparts, W, scale, out);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((W + RR_COLS - 1) / RR_COLS)), dim3(1024), 0, st, partial, nparts, W, scale, out);
 }
 }  // namespace jmac
 
