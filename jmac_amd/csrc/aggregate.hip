@@ -883,7 +883,7 @@ struct BwdWs {
 static BwdWs bwd_ws_layout(int64_t E, int64_t d, int64_t pd, int64_t ps, int64_t pr, int32_t mode) {
     BwdWs w;
     size_t off = 0;
-    w.da_part = off;     off += align_up((size_t)kPersistBlocks * d * 4);
+    w.da_part = off;     off += align_up((size_t)2 * kPersistBlocks * d * 4);   // one partial row per pass-A block (<= 2 x 2048)
     w.colsum_part = off; off += align_up((size_t)kPersistBlocks * d * 4);
     w.part_dst = off;    off += align_up((size_t)(pd > 0 ? pd : 0) * d * 4);
     w.part_src = off;    off += mode ? align_up((size_t)(ps > 0 ? ps : 0) * 2 * d * 4) : 0;
@@ -941,7 +941,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
     a.sign = 1.f; a.add_self = 0;
 
     const int T = 256;
-    const unsigned gridA = persist_grid(by_dst->n_items_max);
+    const unsigned gridA = fwd_grid(by_dst->n_items_max);          // small graphs: one wave per item, like the forward
     const bool slope01 = slope >= 0.f && slope <= 1.f;
     if (mode == 0) {
         // dQZ / dRR are accumulated with atomics: initialise them (dZ half of dQZ starts at the self term)
