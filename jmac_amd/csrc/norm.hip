@@ -86,6 +86,56 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
     }
 }
 
+// reduce_rows over the [nparts, 2d] partial sums and bn_finalize in one launch: a block owns 16 features and sums both
+// their s1 and s2 columns (64 row lanes each), then finalises them
+constexpr int RF_COLS = 16, RF_LANES = 1024 / RF_COLS;
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ partial, int nparts,
+                                                                  const float* __restrict__ x, int64_t N, int d, float eps,
+                                                                  float momentum, float* __restrict__ running_mean,
+                                                                  float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                                  float* __restrict__ save_invstd) {
+    __shared__ float red1[RF_LANES][RF_COLS], red2[RF_LANES][RF_COLS];
+    const int cl = threadIdx.x % RF_COLS, rl = threadIdx.x / RF_COLS;
+    const int c = blockIdx.x * RF_COLS + cl;
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+    if (c < d) {
+        int p = rl;
+        for (; p + RF_LANES < nparts; p += 2 * RF_LANES) {
+            a1 += partial[(int64_t)p * 2 * d + c];
+            a2 += partial[(int64_t)p * 2 * d + d + c];
+            b1 += partial[(int64_t)(p + RF_LANES) * 2 * d + c];
+            b2 += partial[(int64_t)(p + RF_LANES) * 2 * d + d + c];
+        }
+        if (p < nparts) {
+            a1 += partial[(int64_t)p * 2 * d + c];
+            a2 += partial[(int64_t)p * 2 * d + d + c];
+        }
+    }
+    red1[rl][cl] = a1 + b1;
+    red2[rl][cl] = a2 + b2;
+    __syncthreads();
+    if (rl == 0 && c < d) {
+        float s1 = red1[0][cl], s2 = red2[0][cl];
+#pragma unroll 8
+        for (int r = 1; r < RF_LANES; ++r) {
+            s1 += red1[r][cl];
+            s2 += red2[r][cl];
+        }
+        const float n = (float)N;
+        const float mshift = s1 / n;
+        const float mean = x[c] + mshift;
+        float var = s2 / n - mshift * mshift;
+        var = var > 0.f ? var : 0.f;
+        save_mean[c] = mean;
+        save_invstd[c] = rsqrtf(var + eps);
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        if (running_var) {
+            const float unbiased = N > 1 ? var * n / (n - 1.f) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+    }
+}
+
 // local column moments from the shifted sums: mean = K + s1/n, M2 = sum (x - mean)^2 = s2 - s1^2/n
 __global__ void moments_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ x, int64_t N, int d,
                                         float* __restrict__ mean, float* __restrict__ m2) {
@@ -289,10 +339,8 @@ int jmac_bn_tanh_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, cons
         float* partial = (float*)ws;
         const unsigned g = stat_grid(N, D4);
         hipLaunchKernelGGL(col_stats_partial_kernel, dim3(g), dim3(kBlock), stat_smem(D4), st, x, ldx, N, D4, partial);
-        float* sums = partial + (size_t)kStatBlocks * 2 * d;
-        launch_reduce_rows(partial, (int)g, (int)(2 * d), 1.f, sums, st);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, sums, x, N, (int)d,
-                           eps, momentum, running_mean, running_var, save_mean, save_invstd);
+        hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((unsigned)((d + RF_COLS - 1) / RF_COLS)), dim3(1024), 0, st, partial,
+                           (int)g, x, N, (int)d, eps, momentum, running_mean, running_var, save_mean, save_invstd);
     } else {
         if (!running_mean || !running_var) return JMAC_EINVAL;
         hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, running_mean, running_var,
@@ -320,9 +368,13 @@ int jmac_bn_tanh_bwd_f32(const float* x, int64_t ldx, const float* y, int64_t ld
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g), dim3(kBlock), stat_smem(D4), st, x, ldx, y, ldy, gy, ldgy, N, D4,
                            save_mean, save_invstd, partial);
     }
-    float* sums = partial + (size_t)kStatBlocks * 2 * d;
-    launch_reduce_rows(partial, (int)g, (int)(2 * d), 1.f, sums, st);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, sums, (int)d, gweight, gbias);
+    if (gweight == gbias + d) {                  // [gbias | gweight] contiguous: the reduction writes them directly
+        launch_reduce_rows(partial, (int)g, (int)(2 * d), 1.f, gbias, st);
+    } else {
+        float* sums = partial + (size_t)kStatBlocks * 2 * d;
+        launch_reduce_rows(partial, (int)g, (int)(2 * d), 1.f, sums, st);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, sums, (int)d, gweight, gbias);
+    }
     if (N > 0)
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(N * D4)), dim3(kBlock), 0, st, x, ldx, y, ldy, gy, ldgy, N, D4,
                            weight, save_mean, save_invstd, gweight, gbias, training, 1.f / (float)N, gx, ldgx);

@@ -227,8 +227,8 @@ class _BnTanh(torch.autograd.Function):
         dev = x.device
         gy = _f32c(gy).contiguous()
         gx = torch.empty_like(x)
-        gw = torch.empty(d, dtype=torch.float32, device=dev)
-        gb = torch.empty(d, dtype=torch.float32, device=dev)
+        gbw = torch.empty(2 * d, dtype=torch.float32, device=dev)        # [grad bias | grad weight]: one reduction writes both
+        gb, gw = gbw[:d], gbw[d:]
         ws_bytes = int(L.jmac_bn_tanh_workspace_bytes(N, d))
         ws = _ws(ws_bytes, dev)
         check(L.jmac_bn_tanh_bwd_f32(ptr(x), d, ptr(y), d, ptr(gy), d, N, d, ptr(weight), ptr(save_mean), ptr(save_invstd),
