@@ -97,7 +97,67 @@ def parse():
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the library GEMM heuristics as they are")
     ap.add_argument("--bwd-mode", type=int, default=1)
     ap.add_argument("--synth-scale", type=float, default=1.0, help="scale of the config-4 side measurement")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the first pass")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher self-test: every rank prints its RANK/WORLD_SIZE/LOCAL_RANK as one JSON line and exits "
+                         "before touching the GPU")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a):
+    """``python bench.py --gpus N`` without a launcher around it: start N child ranks (one process per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), relay their output, and return non-zero if any
+    of them does.  The parent never initialises the GPU and never re-executes itself; the children are ordinary
+    subprocesses running this same file with the same arguments."""
+    import signal
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL over xGMI between processes)
+    env["WORLD_SIZE"] = str(a.gpus)
+    env["JMAC_BENCH_CHILD"] = "1"
+    procs = []
+    for r in range(a.gpus):
+        e = dict(env)
+        e["RANK"] = e["LOCAL_RANK"] = str(r)
+        # own process group per child: a failed run can be torn down by exact pid / group, never by pattern
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      start_new_session=True))
+    rc = 0
+    pending = set(range(a.gpus))
+    try:
+        while pending:
+            for r in sorted(pending):
+                c = procs[r].poll()
+                if c is None:
+                    continue
+                pending.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, c))
+                    for q in pending:
+                        try:
+                            os.killpg(procs[q].pid, signal.SIGTERM)
+                        except OSError:
+                            pass
+            if pending:
+                time.sleep(0.05)
+    except KeyboardInterrupt:                                   # pragma: no cover
+        for q in pending:
+            try:
+                os.killpg(procs[q].pid, signal.SIGTERM)
+            except OSError:
+                pass
+        rc = 130
+    return rc
 
 
 def make_args(dim, batch, negatives, device):
@@ -110,11 +170,11 @@ def make_args(dim, batch, negatives, device):
 class JaWorkload:
     """Synthetic KG of the DBP-5L ``ja`` shape + the training-step closure."""
 
-    def __init__(self, a, device, seed=1234):
+    def __init__(self, a, device, seed=1234, bidirectional=False):
         from jmac_amd import synth
         from jmac_amd.model import JMAC
         self.a = a
-        ei, et, n, nr = synth.dbp5l_like("ja", seed)
+        ei, et, n, nr = synth.dbp5l_like("ja", seed, bidirectional)
         self.N, self.E, self.nr, self.d = n, ei.shape[1], nr, a.dim
         rng = np.random.default_rng(seed + 1)
         torch.manual_seed(seed)
@@ -159,14 +219,62 @@ class JaWorkload:
             loss = loss + torch.max(pos - neg, -margin).mean() + margin
         return loss + cos(align_out, pairs[:, 0], align_out, pairs[:, 1]).mean()          # :271-273
 
-    def step(self):
+    def forward_loss(self):
+        """(loss, align_out, comp_layers, rel_layers) of one pass of the hot path (no backward, no update)."""
         m = self.model
-        self.opt.zero_grad(set_to_none=True)
         align_out, comp, rel = m.forward_base(self.ei, self.et, [0, self.N], [0, self.nr])
-        loss = self.loss_fn(align_out, comp, rel, self.h, self.r, self.t, self.pairs, m.margin_completion)
+        return self.loss_fn(align_out, comp, rel, self.h, self.r, self.t, self.pairs, m.margin_completion), align_out, comp, rel
+
+    def step(self):
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.forward_loss()[0]
         loss.backward()
         self.opt.step()
         return loss
+
+    # ---- the oracle on this very workload (checker only: parity assertion below, tests/test_gpu_ja_oracle.py) ------
+    def oracle_pass(self, dtype=torch.float32, kink_masks=None, backward=False):
+        """One pass of the same step through oracle/jmac_oracle.py (un-factorised reference formulation, PyTorch CPU,
+        dropout off) from the workload's INITIAL parameters: (loss, align_out, comp_layers, {param: grad})."""
+        import oracle.jmac_oracle as orc
+        skip = ("running", "num_batches", "margin_completion")
+        st = {k: v.clone().to(dtype if v.dtype.is_floating_point else v.dtype) for k, v in self.state_cpu.items()}
+        for k, v in st.items():
+            if backward and v.dtype.is_floating_point and not any(s_ in k for s_ in skip):
+                v.requires_grad_(True)
+        bn = {k: v.clone() for k, v in st.items() if "running" in k}
+        align_out, comp, rel = orc.forward_name(st, self.name_emb.to(dtype), self.ei.cpu(), self.et.cpu(), [0, self.N],
+                                                [0, self.nr], 2, 0.05, "sub", True, bn, kink_masks=kink_masks)
+        loss = self.loss_fn(align_out, comp, rel, self.h.cpu(), self.r.cpu(), self.t.cpu(), self.pairs.cpu(),
+                            st["margin_completion"].detach(), orc.triple_l1_score, orc.pair_cosine_distance)
+        grads = {}
+        if backward:
+            loss.backward()
+            grads = {k: v.grad for k, v in st.items() if v.requires_grad}
+        return loss.detach(), align_out.detach(), [c.detach() for c in comp], grads
+
+    def check_against_oracle(self, tol=1e-4):
+        """Before anything is timed: the step bench.py is about to time must produce the oracle's loss (dropout off for
+        the comparison; nothing has been updated yet, so both sides start from the same parameters)."""
+        p_drop = self.model.completion_dropout.p
+        self.model.completion_dropout.p = 0.0
+        try:
+            with torch.no_grad():
+                loss, align_out, comp, _ = self.forward_loss()
+            torch.cuda.synchronize()
+        finally:
+            self.model.completion_dropout.p = p_drop
+        # train-mode BN moved the running statistics once: restore them so that the timed steps start where they would have
+        self.model.load_state_dict({k: v.to(self.ei.device) for k, v in self.state_cpu.items()}, strict=True)
+        o_loss, o_align, o_comp, _ = self.oracle_pass(torch.float32)
+        def rel(a, b):
+            a, b = a.detach().double().cpu(), b.double()
+            return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        res = {"loss_gpu": float(loss), "loss_oracle": float(o_loss), "loss_rel_err": abs(float(loss) - float(o_loss)) / abs(float(o_loss)),
+               "align_out_rel_err": rel(align_out, o_align), "comp_layer1_rel_err": rel(comp[1], o_comp[1]), "tol": tol,
+               "what": "first pass of the timed workload (dropout off) vs oracle/jmac_oracle.py fp32 on the same inputs"}
+        res["ok"] = bool(res["loss_rel_err"] <= tol and res["align_out_rel_err"] <= tol and res["comp_layer1_rel_err"] <= tol)
+        return res
 
     # ---- CPU baseline: the oracle's un-factorised reference formulation on the same step ------------
     def cpu_step_fn(self):
@@ -424,9 +532,21 @@ def pmc_mfma_util():
 
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # no launcher around us: become the launcher (before anything touches the GPU)
+        raise SystemExit(launch_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != a.gpus and not os.environ.get("JMAC_BENCH_FORCE_DIST"):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or drop the launcher and let "
+                         "bench.py start the ranks itself)" % (a.gpus, world))
+    if a.dry_launch:
+        print(json.dumps({"dry_launch": True, "rank": rank, "world": world, "local_rank": local,
+                          "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}), flush=True)
+        return
     dist_on = world > 1 or bool(os.environ.get("JMAC_BENCH_FORCE_DIST"))   # env: exercise the N>1 path on one GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
@@ -463,6 +583,11 @@ def main():
     # path is measured on config 4 and reported beside it ("sharded").
     tuned = (not a.no_gemm_tuning) and enable_gemm_tuning(rank)
     w = JaWorkload(a, device, seed=1234 + rank)
+    parity = None
+    if rank == 0 and not a.no_parity_check:
+        parity = w.check_against_oracle()
+        if not parity["ok"]:
+            raise SystemExit("bench.py: the workload's first pass does not match the oracle: %s" % json.dumps(parity))
     exec_mode = "eager"
     fn = w.step
     if tuned:
@@ -545,7 +670,7 @@ def main():
                        "exec": exec_mode, "bwd_mode": "deterministic" if a.bwd_mode else "atomic",
                        "library_gemm": "torch.mm (hipBLASLt/rocBLAS), TunableOp %s" % ("on" if tuned else "off"),
                        "edges_counted_per_step": layer_calls * w.E},
-            "roofline": roof, "roofline_bwd": roof_bwd}
+            "roofline": roof, "roofline_bwd": roof_bwd, "parity": parity}
     line["scoring"] = scoring_bench(w)
     try:
         line["sim"] = sim_bench(device)

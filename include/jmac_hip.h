@@ -55,9 +55,18 @@ int jmac_version(void);
 /* Bytes of scratch needed by jmac_csr_build / jmac_group_build for E entries and S segments. */
 size_t jmac_graph_workspace_bytes(int64_t E, int64_t S);
 
+/* Range check of an index array (elem_bytes = 4: int32, 8: int64): *bad (device int32, zeroed by the caller) +=
+ * number of entries outside [lo, hi).  The reference raises IndexError on such an id (torch indexing); the kernels
+ * of this library TRUST their indices, so a host that cannot vouch for them runs this first and reads *bad back
+ * (jmac_amd does: once per graph at build time, once per index tensor for the loss / ranking entry points). */
+int jmac_index_check(const void* idx, int32_t elem_bytes, int64_t n, int64_t lo, int64_t hi, int32_t* bad,
+                     jmac_stream_t stream);
+
 /* COO (edge_index [2,E] int64: row 0 = aggregation destination, row 1 = message source;
  * edge_type [E] int64) -> CSR by destination with a STABLE order inside each row.
- *   rowptr [N+1], col [E] (source of each CSR slot), etype [E], perm [E] (original edge id). */
+ *   rowptr [N+1], col [E] (source of each CSR slot), etype [E], perm [E] (original edge id).
+ * Precondition: destinations in [0,N) (check with jmac_index_check; sources / types are range-checked against the
+ * tables by the caller the same way). */
 int jmac_csr_build(const int64_t* edge_index, const int64_t* edge_type, int64_t E, int64_t N,
                    int32_t* rowptr, int32_t* col, int32_t* etype, int32_t* perm,
                    void* ws, size_t ws_bytes, jmac_stream_t stream);
@@ -248,6 +257,21 @@ int jmac_softmax_entropy_f32(const float* A, int64_t lda, const float* B, int64_
 int jmac_masked_row_softmax_f32(const float* S, int64_t lds, int64_t n1, int64_t n2,
                                 const uint8_t* row_mask, const uint8_t* col_mask, float fill,
                                 float scale, float* out, int64_t ldo, jmac_stream_t stream);
+
+/* Generalisations of the call above on an existing score matrix S [n1,n2] (row-major): the entries kept by the masks
+ * are scaled, every other entry is `fill` * scale (NULL mask = keep all), then
+ *   jmac_row_softmax_f32: softmax over each ROW    -> out [n1,n2] (may be NULL), ent [n1] = entropy of the row (may be NULL)
+ *   jmac_col_softmax_f32: softmax over each COLUMN -> out_t [n2,n1] = the TRANSPOSED probabilities, i.e.
+ *                         softmax(scale * S^T, dim=1) (may be NULL), ent [n2] (may be NULL)
+ * so that both orientations of compute_alignment_quality (train.py:241-257; DBPv1 trainer/jmac_trainer.py:281-300:
+ * softmax(simi) and softmax(simi.t())) come from ONE similarity GEMM. */
+int jmac_row_softmax_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, const uint8_t* row_mask,
+                         const uint8_t* col_mask, float fill, float scale, float* out, int64_t ldo, float* ent,
+                         jmac_stream_t stream);
+size_t jmac_col_softmax_workspace_bytes(int64_t n1, int64_t n2);
+int jmac_col_softmax_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, const uint8_t* row_mask,
+                         const uint8_t* col_mask, float fill, float scale, float* out_t, int64_t ldo, float* ent,
+                         void* ws, size_t ws_bytes, jmac_stream_t stream);
 
 /* The k largest values of every COLUMN of S [n1,n2], descending (val [n2,k]; k <= 16) -- the column term of CSLS
  * (calculate_nearest_k on sim_mat.T, modules/finding/similarity.py:66-67,81-84) without materialising the transpose. */

@@ -34,6 +34,7 @@ _SIGS = {
     "jmac_strerror": (C.c_char_p, [C.c_int]),
     "jmac_version": (C.c_int, []),
     "jmac_graph_workspace_bytes": (sz, [i64, i64]),
+    "jmac_index_check": (C.c_int, [vp, i32, i64, i64, i64, vp, vp]),
     "jmac_csr_build": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
     "jmac_group_build": (C.c_int, [vp, i64, i64, vp, vp, vp, sz, vp]),
     "jmac_items_max": (i64, [i64, i64, i32]),
@@ -75,6 +76,9 @@ _SIGS = {
     "jmac_softmax_entropy_workspace_bytes": (sz, [i64, i64]),
     "jmac_softmax_entropy_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, f32, vp, vp, vp, sz, vp]),
     "jmac_masked_row_softmax_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, f32, f32, vp, i64, vp]),
+    "jmac_row_softmax_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, f32, f32, vp, i64, vp, vp]),
+    "jmac_col_softmax_workspace_bytes": (sz, [i64, i64]),
+    "jmac_col_softmax_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, f32, f32, vp, i64, vp, vp, sz, vp]),
     "jmac_csls_rank_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, vp]),
     "jmac_csls_apply_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, i64, vp]),
     "jmac_gemm_f32": (C.c_int, [vp, i64, i32, vp, i64, i32, i64, i64, i64, vp, i64, vp]),
@@ -128,6 +132,58 @@ def require_device(*tensors) -> None:
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise JmacError("jmac_amd ops need tensors on a HIP device (got %s); there is no CPU path" % t.device)
+
+
+# ---- index validation (the reference raises IndexError on an out-of-range id; the kernels trust theirs) -----------
+_CHECKED: "dict" = {}
+_CHECKED_CAP = 64
+
+
+def check_index_range(idx, n: int, what: str = "index"):
+    """Raise IndexError unless every entry of ``idx`` lies in [0, n).  Host data (lists, numpy, CPU tensors) is
+    checked on the host; a device tensor is checked once per (storage, version) by jmac_index_check -- one host read
+    the first time a tensor is seen, nothing afterwards, and nothing while a stream is being captured."""
+    import numpy as np
+    import torch
+    n = int(n)
+    if not isinstance(idx, torch.Tensor):
+        a = np.asarray(idx)
+        if a.size and (a.min() < 0 or a.max() >= n):
+            raise IndexError("%s out of range: values in [%s, %s], valid range [0, %d)" % (what, a.min(), a.max(), n))
+        return
+    if idx.numel() == 0:
+        return
+    if not idx.is_cuda:
+        lo, hi = int(idx.min()), int(idx.max())
+        if lo < 0 or hi >= n:
+            raise IndexError("%s out of range: values in [%d, %d], valid range [0, %d)" % (what, lo, hi, n))
+        return
+    if idx.dtype not in (torch.int32, torch.int64):
+        raise TypeError("%s must be int32 or int64 (got %s)" % (what, idx.dtype))
+    ok = getattr(idx, "_jmac_range_ok", None)             # set by a host-side check before the upload (mark_index_range)
+    if ok is not None and ok <= n:
+        return
+    key = (idx.data_ptr(), idx._version, idx.numel(), idx.dtype, n)
+    if key in _CHECKED:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return                                             # cannot read back inside a capture; eager warm-up has checked
+    t = idx if idx.is_contiguous() else idx.contiguous()
+    bad = torch.zeros(1, dtype=torch.int32, device=idx.device)
+    check(lib().jmac_index_check(ptr(t), t.element_size(), t.numel(), 0, n, ptr(bad), stream()), "jmac_index_check")
+    nbad = int(bad.item())
+    if nbad:
+        raise IndexError("%s out of range: %d of %d entries outside [0, %d)" % (what, nbad, t.numel(), n))
+    if len(_CHECKED) >= _CHECKED_CAP:
+        _CHECKED.pop(next(iter(_CHECKED)))
+    _CHECKED[key] = idx            # keeps the tensor alive: a recycled data_ptr can never alias a validated entry
+
+
+def mark_index_range(t, n: int):
+    """Record on a (device) index tensor that its values are known to lie in [0, n) -- checked on the host before the
+    upload -- so that the entry points do not check it again."""
+    t._jmac_range_ok = int(n)
+    return t
 
 
 def stream() -> int:

@@ -25,6 +25,18 @@ __global__ void coo_keys_kernel(const int64_t* __restrict__ edge_index, int64_t 
     }
 }
 
+// bad[0] += number of entries outside [lo, hi)  (the reference raises IndexError on such an id; the kernels trust them)
+template <typename IT>
+__global__ void index_check_kernel(const IT* __restrict__ idx, int64_t n, int64_t lo, int64_t hi, int32_t* __restrict__ bad) {
+    int cnt = 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = (int64_t)idx[e];
+        cnt += (v < lo || v >= hi) ? 1 : 0;
+    }
+    cnt = jmac::wave_sum_i(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(bad, cnt);
+}
+
 __global__ void iota_kernel(int64_t E, int32_t* __restrict__ iota) {
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < E) iota[e] = (int32_t)e;
@@ -153,6 +165,21 @@ size_t jmac_graph_workspace_bytes(int64_t E, int64_t S) {
     size_t a = 3 * align_up((size_t)E * 4) + sort_temp_bytes(E);
     size_t b = 6 * align_up((size_t)(S + 1) * 4) + scan_temp_bytes(S + 1);
     return (a > b ? a : b) + 1024;
+}
+
+int jmac_index_check(const void* idx, int32_t elem_bytes, int64_t n, int64_t lo, int64_t hi, int32_t* bad,
+                     jmac_stream_t stream) {
+    if (n < 0 || !bad || (n > 0 && !idx) || (elem_bytes != 4 && elem_bytes != 8)) return JMAC_EINVAL;
+    if (n == 0) return JMAC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int T = 256;
+    int64_t nb = (n + T - 1) / T;
+    if (nb > 2048) nb = 2048;
+    if (elem_bytes == 8)
+        hipLaunchKernelGGL(index_check_kernel<int64_t>, dim3((unsigned)nb), dim3(T), 0, st, (const int64_t*)idx, n, lo, hi, bad);
+    else
+        hipLaunchKernelGGL(index_check_kernel<int32_t>, dim3((unsigned)nb), dim3(T), 0, st, (const int32_t*)idx, n, lo, hi, bad);
+    return (int)hipGetLastError();
 }
 
 int jmac_csr_build(const int64_t* edge_index, const int64_t* edge_type, int64_t E, int64_t N, int32_t* rowptr,

@@ -605,14 +605,14 @@ __global__ __launch_bounds__(kBlock) void row_entropy_kernel(const float* __rest
     if (threadIdx.x == 0) ent[blockIdx.x] = logf(z) - y / z;
 }
 
+// softmax over a ROW of the masked, scaled matrix; out (the probabilities) and ent (the row's softmax entropy) are optional
 __global__ __launch_bounds__(kBlock) void masked_row_softmax_kernel(const float* __restrict__ S, int64_t lds, int N,
                                                                     const uint8_t* __restrict__ row_mask,
                                                                     const uint8_t* __restrict__ col_mask, float fill, float scale,
-                                                                    float* __restrict__ out, int64_t ldo) {
+                                                                    float* __restrict__ out, int64_t ldo, float* __restrict__ ent) {
     __shared__ float sh[kBlock / 64];
     const int i = blockIdx.x;
     const float* row = S + (int64_t)i * lds;
-    float* orow = out + (int64_t)i * ldo;
     const bool rk = row_mask ? row_mask[i] != 0 : true;
     auto val = [&](int n) -> float {
         const bool keep = rk && (col_mask ? col_mask[n] != 0 : true);
@@ -621,11 +621,124 @@ __global__ __launch_bounds__(kBlock) void masked_row_softmax_kernel(const float*
     float m = -INFINITY;
     for (int n = threadIdx.x; n < N; n += kBlock) m = fmaxf(m, val(n));
     m = block_max(m, sh);
-    float z = 0.f;
-    for (int n = threadIdx.x; n < N; n += kBlock) z += expf(val(n) - m);
+    float z = 0.f, y = 0.f;
+    for (int n = threadIdx.x; n < N; n += kBlock) {
+        const float x = val(n) - m;
+        const float e = expf(x);
+        z += e;
+        y = fmaf(e, x, y);
+    }
     z = block_sum(z, sh);
-    const float iz = 1.f / z;
-    for (int n = threadIdx.x; n < N; n += kBlock) orow[n] = expf(val(n) - m) * iz;
+    if (ent) {
+        y = block_sum(y, sh);
+        if (threadIdx.x == 0) ent[i] = logf(z) - y / z;
+    }
+    if (out) {
+        float* orow = out + (int64_t)i * ldo;
+        const float iz = 1.f / z;
+        for (int n = threadIdx.x; n < N; n += kBlock) orow[n] = expf(val(n) - m) * iz;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax over the COLUMNS of the same masked, scaled matrix, from the one row-major S (no second, transposed GEMM):
+//   stats   one lane per column (a wave reads 256 contiguous bytes of a row), rows split over the 4 waves of a block and
+//           over gridDim.y row ranges; online (max, sum e^x, sum e^x x) per lane, one partial triple per (part, column)
+//   merge   combines the partials of a column in part order -> (max, 1/sum) per column and the column's entropy
+//   apply   64x64 tile through LDS: p = exp(x - max_j) / sum_j, written TRANSPOSED ([n2, n1], coalesced both ways)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cs_push(float& m, float& z, float& y, float x) {
+    // running (m, z = sum e^(x-m), y = sum e^(x-m) (x-m)) with a new element x
+    const float mn = fmaxf(m, x);
+    const float f = expf(m - mn);                  // m = -inf: f = 0 (z = y = 0 there)
+    const float dm = m - mn;                       // <= 0; -inf - finite = -inf only while z = y = 0
+    y = f * (y + (z > 0.f ? dm * z : 0.f));
+    z = f * z;
+    const float xe = x - mn;
+    const float e = expf(xe);
+    z += e;
+    y = fmaf(e, xe, y);
+    m = mn;
+}
+
+__global__ __launch_bounds__(kBlock) void col_softmax_stats_kernel(const float* __restrict__ S, int64_t lds, int n1, int n2,
+                                                                   const uint8_t* __restrict__ row_mask,
+                                                                   const uint8_t* __restrict__ col_mask, float fill, float scale,
+                                                                   float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int rows_per = (n1 + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per, r1 = min(n1, r0 + rows_per);
+    const int cc = min(col, n2 - 1);
+    const bool ck = col_mask ? col_mask[cc] != 0 : true;
+    float m = -INFINITY, z = 0.f, y = 0.f;
+    for (int r = r0 + wave; r < r1; r += kBlock / 64) {
+        const bool keep = ck && (row_mask ? row_mask[r] != 0 : true);
+        const float v = S[(int64_t)r * lds + cc];
+        cs_push(m, z, y, (keep ? v : fill) * scale);
+    }
+    const int p = blockIdx.y * (kBlock / 64) + wave;
+    if (col < n2) {
+        float* o = part + ((int64_t)p * n2 + col) * 3;
+        o[0] = m;
+        o[1] = z;
+        o[2] = y;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void col_softmax_merge_kernel(const float* __restrict__ part, int parts, int n2,
+                                                                   float* __restrict__ cmax, float* __restrict__ cinv,
+                                                                   float* __restrict__ ent) {
+    const int col = blockIdx.x * kBlock + threadIdx.x;
+    if (col >= n2) return;
+    float m = -INFINITY, z = 0.f, y = 0.f;
+    for (int p = 0; p < parts; ++p) {
+        const float* q = part + ((int64_t)p * n2 + col) * 3;
+        const float pm = q[0], pz = q[1], py = q[2];
+        if (!(pz > 0.f)) continue;                                  // a part without rows
+        const float mn = fmaxf(m, pm);
+        const float fa = expf(m - mn), fb = expf(pm - mn);
+        const float da = m - mn, db = pm - mn;
+        const float ya = z > 0.f ? fa * (y + da * z) : 0.f;
+        const float yb = fb * (py + db * pz);
+        y = ya + yb;
+        z = fa * z + fb * pz;
+        m = mn;
+    }
+    cmax[col] = m;
+    cinv[col] = 1.f / z;
+    if (ent) ent[col] = logf(z) - y / z;
+}
+
+__global__ __launch_bounds__(kBlock) void col_softmax_apply_kernel(const float* __restrict__ S, int64_t lds, int n1, int n2,
+                                                                   const uint8_t* __restrict__ row_mask,
+                                                                   const uint8_t* __restrict__ col_mask, float fill, float scale,
+                                                                   const float* __restrict__ cmax, const float* __restrict__ cinv,
+                                                                   float* __restrict__ out_t, int64_t ldo) {
+    __shared__ float tile[64][65];
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = j0 + tx;
+    const bool jin = j < n2;
+    const int jc = min(j, n2 - 1);
+    const bool ck = col_mask ? col_mask[jc] != 0 : true;
+    const float mj = cmax[jc], zj = cinv[jc];
+    for (int r = ty; r < 64; r += kBlock / 64) {
+        const int i = i0 + r;
+        float p = 0.f;
+        if (i < n1 && jin) {
+            const bool keep = ck && (row_mask ? row_mask[i] != 0 : true);
+            const float x = (keep ? S[(int64_t)i * lds + j] : fill) * scale;
+            p = expf(x - mj) * zj;
+        }
+        tile[r][tx] = p;
+    }
+    __syncthreads();
+    const int i = i0 + tx;
+    for (int c = ty; c < 64; c += kBlock / 64) {
+        const int jj = j0 + c;
+        if (jj < n2 && i < n1) out_t[(int64_t)jj * ldo + i] = tile[tx][c];
+    }
 }
 
 // out[i][j] = 2*S[i][j] - r1[i] - r2[j]   (CSLS, modules/finding/similarity.py:58-78)
@@ -777,7 +890,7 @@ int jmac_sim_topk_f32(const float* A, int64_t lda, const float* B, int64_t ldb, 
 
 size_t jmac_softmax_entropy_workspace_bytes(int64_t n1, int64_t n2) {
     if (n1 < 0 || n2 < 0) return 0;
-    return 2 * align_up((size_t)n1 * (size_t)n2 * 4) + 256;
+    return align_up((size_t)n1 * (size_t)n2 * 4) + jmac_col_softmax_workspace_bytes(n1, n2) + 256;
 }
 
 int jmac_softmax_entropy_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t n1, int64_t n2, int64_t d,
@@ -788,13 +901,14 @@ int jmac_softmax_entropy_f32(const float* A, int64_t lda, const float* B, int64_
     if (lda % 4 || ldb % 4) return JMAC_EDIM;
     if (!ws || ws_bytes < jmac_softmax_entropy_workspace_bytes(n1, n2)) return JMAC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    // ONE GEMM: the column entropies come from a column-wise pass over the same row-major S (the reference's
+    // softmax(simi.t()) of train.py:245 reads the transpose of the same matrix, not a second product)
     float* S = (float*)ws;
-    float* St = (float*)((char*)ws + align_up((size_t)n1 * (size_t)n2 * 4));
+    const size_t soff = align_up((size_t)n1 * (size_t)n2 * 4);
     if (int rc = launch_sim(A, lda, B, ldb, n1, n2, d, S, n2, st)) return rc;
-    if (int rc = launch_sim(B, ldb, A, lda, n2, n1, d, St, n1, st)) return rc;
     hipLaunchKernelGGL(row_entropy_kernel, dim3((unsigned)n1), dim3(kBlock), 0, st, S, n2, (int)n2, scale, ent_rows);
-    hipLaunchKernelGGL(row_entropy_kernel, dim3((unsigned)n2), dim3(kBlock), 0, st, St, n1, (int)n1, scale, ent_cols);
-    return (int)hipGetLastError();
+    return jmac_col_softmax_f32(S, n2, n1, n2, nullptr, nullptr, 0.f, scale, nullptr, 0, ent_cols, (char*)ws + soff,
+                                ws_bytes - soff, stream);
 }
 
 int jmac_csls_apply_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, const float* r1, const float* r2, float* out,
@@ -809,14 +923,60 @@ int jmac_csls_apply_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, con
     return (int)hipGetLastError();
 }
 
+int jmac_row_softmax_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, const uint8_t* row_mask,
+                         const uint8_t* col_mask, float fill, float scale, float* out, int64_t ldo, float* ent,
+                         jmac_stream_t stream) {
+    if (n1 < 0 || n2 <= 0) return JMAC_EINVAL;
+    if (n1 == 0) return JMAC_OK;
+    if (!S || (!out && !ent)) return JMAC_EINVAL;
+    if (n2 >= INT32_MAX) return JMAC_ERANGE;
+    hipLaunchKernelGGL(masked_row_softmax_kernel, dim3((unsigned)n1), dim3(kBlock), 0, (hipStream_t)stream, S, lds, (int)n2,
+                       row_mask, col_mask, fill, scale, out, ldo, ent);
+    return (int)hipGetLastError();
+}
+
 int jmac_masked_row_softmax_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, const uint8_t* row_mask,
                                 const uint8_t* col_mask, float fill, float scale, float* out, int64_t ldo,
                                 jmac_stream_t stream) {
-    if (n1 < 0 || n2 <= 0) return JMAC_EINVAL;
-    if (n1 == 0) return JMAC_OK;
-    if (!S || !out) return JMAC_EINVAL;
-    hipLaunchKernelGGL(masked_row_softmax_kernel, dim3((unsigned)n1), dim3(kBlock), 0, (hipStream_t)stream, S, lds, (int)n2,
-                       row_mask, col_mask, fill, scale, out, ldo);
+    if (!out) return JMAC_EINVAL;
+    return jmac_row_softmax_f32(S, lds, n1, n2, row_mask, col_mask, fill, scale, out, ldo, nullptr, stream);
+}
+
+static int col_softmax_row_splits(int64_t n1, int64_t n2) {
+    const int64_t strips = (n2 + 63) / 64;
+    int64_t rs = (2048 + strips - 1) / strips;            // ~2k blocks
+    const int64_t max_rs = (n1 + 63) / 64;                // at least 64 rows per block
+    if (rs > max_rs) rs = max_rs;
+    if (rs < 1) rs = 1;
+    return (int)rs;
+}
+
+size_t jmac_col_softmax_workspace_bytes(int64_t n1, int64_t n2) {
+    if (n1 < 0 || n2 < 0) return 0;
+    return align_up((size_t)col_softmax_row_splits(n1, n2) * (kBlock / 64) * (size_t)n2 * 12) + 2 * align_up((size_t)n2 * 4) + 256;
+}
+
+int jmac_col_softmax_f32(const float* S, int64_t lds, int64_t n1, int64_t n2, const uint8_t* row_mask,
+                         const uint8_t* col_mask, float fill, float scale, float* out_t, int64_t ldo, float* ent,
+                         void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    if (n1 <= 0 || n2 < 0) return JMAC_EINVAL;
+    if (n2 == 0) return JMAC_OK;
+    if (!S || (!out_t && !ent)) return JMAC_EINVAL;
+    if (n1 >= INT32_MAX || n2 >= INT32_MAX) return JMAC_ERANGE;
+    if (!ws || ws_bytes < jmac_col_softmax_workspace_bytes(n1, n2)) return JMAC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int rs = col_softmax_row_splits(n1, n2);
+    const int parts = rs * (kBlock / 64);
+    float* part = (float*)ws;
+    float* cmax = (float*)((char*)ws + align_up((size_t)parts * (size_t)n2 * 12));
+    float* cinv = (float*)((char*)cmax + align_up((size_t)n2 * 4));
+    hipLaunchKernelGGL(col_softmax_stats_kernel, dim3((unsigned)((n2 + 63) / 64), (unsigned)rs), dim3(kBlock), 0, st, S, lds,
+                       (int)n1, (int)n2, row_mask, col_mask, fill, scale, part);
+    hipLaunchKernelGGL(col_softmax_merge_kernel, dim3((unsigned)((n2 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, part, parts,
+                       (int)n2, cmax, cinv, ent);
+    if (out_t)
+        hipLaunchKernelGGL(col_softmax_apply_kernel, dim3((unsigned)((n2 + 63) / 64), (unsigned)((n1 + 63) / 64)), dim3(kBlock), 0, st,
+                           S, lds, (int)n1, (int)n2, row_mask, col_mask, fill, scale, cmax, cinv, out_t, ldo);
     return (int)hipGetLastError();
 }
 

@@ -187,6 +187,14 @@ def allreduce_grads(params, group=None) -> None:
         off += g.numel()
 
 
+def _bn_momentum(bn: nn.BatchNorm1d) -> float:
+    """nn.BatchNorm1d(momentum=None) keeps a cumulative moving average (factor 1/num_batches_tracked, a device-side
+    count); the reference never builds such a module (src/jmac_model.py:27) and the sharded path does not carry it."""
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative moving average) is not supported on the sharded path")
+    return float(bn.momentum)
+
+
 def sync_batch_norm(x: torch.Tensor, n_global: int, bn: nn.BatchNorm1d, group=None) -> torch.Tensor:
     """BatchNorm1d(x) with batch statistics over the rows of ALL ranks (the bn of src/jmac_model.py:52):
     the [2,d] column sums are all-reduced; running statistics are updated like nn.BatchNorm1d."""
@@ -198,7 +206,7 @@ def sync_batch_norm(x: torch.Tensor, n_global: int, bn: nn.BatchNorm1d, group=No
     var = (sums[1] / n_global - mean * mean).clamp_min(0)
     if bn.track_running_stats:
         with torch.no_grad():
-            m = bn.momentum if bn.momentum is not None else 0.1
+            m = _bn_momentum(bn)
             bn.running_mean.mul_(1 - m).add_(mean.detach(), alpha=m)
             unb = var.detach() * (n_global / max(n_global - 1, 1))
             bn.running_var.mul_(1 - m).add_(unb, alpha=m)
@@ -314,7 +322,7 @@ def sync_bn_tanh(x: torch.Tensor, bn: nn.BatchNorm1d, n_global: int, group=None,
         return _EvalBnTanh.apply(x, bn.weight, bn.bias, bn.running_mean, inv, kernels)
     track = bn.track_running_stats
     return _SyncBnTanh.apply(x, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
-                             bn.num_batches_tracked if track else None, bn.momentum if bn.momentum is not None else 0.1,
+                             bn.num_batches_tracked if track else None, _bn_momentum(bn),
                              bn.eps, int(n_global), group, kernels)
 
 

@@ -14,7 +14,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import View, check, lib, ptr, require_device, stream
+from ._lib import View, check, check_index_range, lib, ptr, require_device, stream
 
 DEFAULT_CHUNK = None          # None -> auto_chunk()
 
@@ -84,6 +84,12 @@ class RelGraph:
         ei = edge_index.contiguous().to(torch.int64)
         et = edge_type.contiguous().to(torch.int64)
         E, N = self.E, self.N
+        # the reference's torch indexing raises IndexError on a bad id; here an unchecked id would corrupt device memory
+        # (rowptr writes, table gathers, gradient scatters): validate once per graph (build time, never on the hot path)
+        if E > 0:
+            check_index_range(ei[0], N, "edge_index[0] (aggregation destination)")
+            check_index_range(ei[1], self.num_src, "edge_index[1] (message source)")
+            check_index_range(et, self.num_rel, "edge_type")
         self.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         self.col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
         self.etype = torch.empty(max(E, 1), dtype=torch.int32, device=dev)

@@ -94,7 +94,7 @@ def evaluate_completion(model: JMAC, kg: KnowledgeGraph, ei, et, args, split="va
     for s in range(0, len(data), args.batch_size):
         b = data[s:s + args.batch_size]
         h, r, t = b[:, 0].tolist(), b[:, 1].tolist(), b[:, 2].tolist()
-        dist = model.forward_linkpred(h, r, ei, et, list(range(kg.num_entity)), eb, rb, cached=cached)
+        dist = model.forward_linkpred(h, r, ei, et, range(kg.num_entity), eb, rb, cached=cached)
         fp = fi = None
         if filtered:
             fp, fi = scoring.build_filter_csr(h, r, kg.true_tail, dist.device)

@@ -177,12 +177,13 @@ class RelationAwareLayer(nn.Module):
         pre = self.pre_bn(ent_emb, rel_emb, edge_index, edge_type)
         bn = self.bn
         d = self.out_channels
-        if self.layer_act is torch.tanh and d % 4 == 0:
+        # momentum=None means a cumulative moving average (factor 1/num_batches_tracked) in nn.BatchNorm1d; the reference
+        # never sets it (src/jmac_model.py:27): such a module takes torch's own BatchNorm below
+        if self.layer_act is torch.tanh and d % 4 == 0 and bn.momentum is not None:
             if bn.training and bn.track_running_stats:
                 bn.num_batches_tracked.add_(1)
             use_batch = bn.training or not bn.track_running_stats
-            return ops.bn_tanh(pre, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch,
-                               bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+            return ops.bn_tanh(pre, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, bn.momentum, bn.eps)
         return self.layer_act(bn(pre))                                    # jmac_model.py:52
 
 

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import torch
 
-from ._lib import check, lib, ptr, require_device, stream
+from ._lib import check, check_index_range, lib, ptr, require_device, stream
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:
@@ -18,7 +18,10 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
     return t if t.stride(-1) == 1 and t.dim() == 2 else t.contiguous()
 
 
-def _index(i: torch.Tensor, n: int, device) -> torch.Tensor:
+def _index(i: torch.Tensor, n: int, device, what: str = "index") -> torch.Tensor:
+    """int64, contiguous, on ``device`` and range-checked against the n rows it addresses (the backward scatters into
+    those rows with float atomics: the reference raises IndexError on a bad id, so does this)."""
+    check_index_range(i, n, what)                      # host tensors on the host; device tensors once per tensor
     i = i.reshape(-1)
     if i.dtype != torch.int64 or i.device != device:
         i = i.to(device=device, dtype=torch.int64)
@@ -59,8 +62,8 @@ def triple_l1_score(ent: torch.Tensor, rel: torch.Tensor, h: torch.Tensor, r: to
     ``period``: hint that triples x, x+period, ... share (h, r), as in the reference's batches
     (train.py:347-352, period = batch size); results do not depend on it."""
     dev = ent.device
-    return _TripleL1.apply(ent, rel, _index(h, ent.shape[0], dev), _index(r, rel.shape[0], dev), _index(t, ent.shape[0], dev),
-                           int(period))
+    return _TripleL1.apply(ent, rel, _index(h, ent.shape[0], dev, "batch_h"), _index(r, rel.shape[0], dev, "batch_r"),
+                           _index(t, ent.shape[0], dev, "batch_t"), int(period))
 
 
 class _PairCosine(torch.autograd.Function):

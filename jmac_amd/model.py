@@ -14,14 +14,30 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import losses, ops, scoring
+from ._lib import check_index_range, mark_index_range
 from .layer import RelationAwareLayer, get_param
 
 
-def _idx(x, device):
-    """Index lists arrive as python lists, int64 tensors or float64 numpy arrays (train.py:190-193)."""
+def _idx(x, device, n=None):
+    """Index lists arrive as python lists, int64 tensors or float64 numpy arrays (train.py:190-193).  With ``n`` host
+    data is range-checked against [0, n) before the upload (IndexError, as torch indexing in the reference) and the
+    device tensor is marked so that the kernels' entry points do not check it again."""
     if isinstance(x, torch.Tensor):
         return x.reshape(-1).to(device=device, dtype=torch.long)
-    return torch.as_tensor(np.asarray(x).reshape(-1).astype(np.int64), device=device)
+    a = np.asarray(x).reshape(-1).astype(np.int64)
+    if n is None:
+        return torch.as_tensor(a, device=device)
+    check_index_range(a, n, "index")
+    return mark_index_range(torch.as_tensor(a, device=device), n)
+
+
+def _link_columns(links, device, n1, n2):
+    """[L,2] seed links -> two int64 device index vectors (host data checked before the upload)."""
+    if isinstance(links, torch.Tensor):
+        lk = links.to(device=device, dtype=torch.long)
+        return lk[:, 0], lk[:, 1]
+    a = np.asarray(links).astype(np.int64).reshape(-1, 2)
+    return _idx(a[:, 0], device, n1), _idx(a[:, 1], device, n2)
 
 
 class JMAC(nn.Module):
@@ -124,8 +140,19 @@ class JMAC(nn.Module):
             cached = self.forward_base(edge_index, edge_type, ent_bases, rel_bases)
         _, comp_layers, comp_rel_layers = cached
         n = comp_layers[0].shape[0]
-        if not (len(all_index) == n and (n == 0 or (all_index[0] == 0 and all_index[-1] == n - 1))):
-            ai = _idx(all_index, comp_layers[0].device)
+        # the reference always gathers ent[all_index] (:312); its only caller passes list(range(N)) (src/validate.py:43-44).
+        # The gather is skipped only for an all_index that IS the identity: None, range(n), or host data (list / numpy)
+        # compared element by element on the host -- no device sync, and a permuted list is never mistaken for it.
+        # A device tensor is always gathered.
+        if all_index is None or (isinstance(all_index, range) and all_index == range(n)):
+            identity = True
+        elif isinstance(all_index, torch.Tensor):
+            identity = False
+        else:
+            ai_host = np.asarray(all_index)
+            identity = ai_host.shape == (n,) and bool((ai_host == np.arange(n)).all())
+        if not identity:
+            ai = _idx(all_index, comp_layers[0].device, n)
             comp_layers = [c.index_select(0, ai) for c in comp_layers]
         layers = range(self.args.num_gcn_layer)
         return scoring.linkpred_dist([comp_layers[l] for l in layers], [comp_rel_layers[l] for l in layers],
@@ -141,8 +168,8 @@ class JMAC(nn.Module):
         if not len(links):
             return 0
         dev = ent_embeddings1.device
-        links = torch.as_tensor(np.asarray(links), dtype=torch.long, device=dev)
-        return self._cos_dist(ent_embeddings1, links[:, 0], ent_embeddings2, links[:, 1]).mean()
+        l0, l1 = _link_columns(links, dev, ent_embeddings1.shape[0], ent_embeddings2.shape[0])
+        return self._cos_dist(ent_embeddings1, l0, ent_embeddings2, l1).mean()
 
     def alignment_loss(self, feeddict, edge_index1, edge_type1, edge_index2, edge_type2):
         links = feeddict["links"]
@@ -151,12 +178,12 @@ class JMAC(nn.Module):
         e1, _, _ = self.forward_base(edge_index1, edge_type1, feeddict["ent_bases1"], feeddict["rel_bases1"])
         e2, _, _ = self.forward_base(edge_index2, edge_type2, feeddict["ent_bases2"], feeddict["rel_bases2"])
         dev = e1.device
-        lk = torch.as_tensor(np.asarray(links), dtype=torch.long, device=dev)
-        n = len(lk)
-        d = (self._cos_dist(e1, lk[:, 0], e2, lk[:, 1]) + self.margin_align).view(n, 1)
+        l0, l1 = _link_columns(links, dev, e1.shape[0], e2.shape[0])
+        n = int(l0.numel())
+        d = (self._cos_dist(e1, l0, e2, l1) + self.margin_align).view(n, 1)
         total = 0
         for left, right in (("neg_left", "neg_right"), ("neg2_left", "neg2_right")):
-            b = self._cos_dist(e1, _idx(feeddict[left], dev), e2, _idx(feeddict[right], dev))
+            b = self._cos_dist(e1, _idx(feeddict[left], dev, e1.shape[0]), e2, _idx(feeddict[right], dev, e2.shape[0]))
             total = total + F.relu(d - b.view(n, -1)).sum()
         return total / (2 * self.k * n)
 

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from . import losses, ops
 from .layer import RelationalAwareLayer, get_param
-from .model import _idx
+from .model import _idx, _link_columns
 
 
 class JMAC_MODEL(nn.Module):
@@ -74,19 +74,21 @@ class JMAC_MODEL(nn.Module):
 
     def alignment_loss_simple(self, links, ent_embeddings):
         """:192-199 (both sides index ONE table)."""
-        lk = torch.as_tensor(np.asarray(links), dtype=torch.long, device=ent_embeddings.device)
-        return losses.pair_cosine_distance(ent_embeddings, lk[:, 0], ent_embeddings, lk[:, 1]).mean()
+        n = ent_embeddings.shape[0]
+        l0, l1 = _link_columns(links, ent_embeddings.device, n, n)
+        return losses.pair_cosine_distance(ent_embeddings, l0, ent_embeddings, l1).mean()
 
     def alignment_loss(self, feeddict, edge_index, edge_type):
         """:202-232."""
         e, _, _ = self.forward_base(edge_index, edge_type)
         dev = e.device
-        lk = torch.as_tensor(np.asarray(feeddict["links"]), dtype=torch.long, device=dev)
-        n = len(lk)
-        d = (losses.pair_cosine_distance(e, lk[:, 0], e, lk[:, 1]) + self.margin_align).view(n, 1)
+        ne = e.shape[0]
+        l0, l1 = _link_columns(feeddict["links"], dev, ne, ne)
+        n = int(l0.numel())
+        d = (losses.pair_cosine_distance(e, l0, e, l1) + self.margin_align).view(n, 1)
         total = 0
         for left, right in (("neg_left", "neg_right"), ("neg2_left", "neg2_right")):
-            b = losses.pair_cosine_distance(e, _idx(feeddict[left], dev), e, _idx(feeddict[right], dev))
+            b = losses.pair_cosine_distance(e, _idx(feeddict[left], dev, ne), e, _idx(feeddict[right], dev, ne))
             total = total + F.relu(d - b.view(n, -1)).sum()
         return total / (2 * self.k * n)
 

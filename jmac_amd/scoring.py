@@ -14,7 +14,7 @@ from typing import Dict, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from ._lib import check, lib, ptr, require_device, stream
+from ._lib import check, check_index_range, lib, ptr, require_device, stream
 
 
 def _rows16(t: torch.Tensor, allow_bf16: bool = False) -> torch.Tensor:
@@ -84,6 +84,7 @@ def filtered_rank(dist: torch.Tensor, gold, filt_ptr: Optional[torch.Tensor] = N
     if dist.dtype != torch.float32 or dist.stride(1) != 1:
         raise TypeError("dist must be fp32 with unit column stride")
     B, N = dist.shape
+    check_index_range(gold, N, "gold")
     gold = torch.as_tensor(gold, device=dist.device).to(torch.int32).contiguous()
     rank = torch.empty(B, dtype=torch.int32, device=dist.device)
     check(lib().jmac_filtered_rank_f32(ptr(dist), dist.stride(0), ptr(gold), ptr(filt_ptr), ptr(filt_idx), B, N,
@@ -185,9 +186,48 @@ def masked_row_softmax(s: torch.Tensor, row_mask: Optional[torch.Tensor], col_ma
     return out
 
 
+def _mask8(m: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return m.to(torch.uint8).contiguous() if m is not None else None
+
+
+def row_softmax(s: torch.Tensor, row_mask=None, col_mask=None, fill: float = -1.0, scale: float = 20.0,
+                want_out: bool = True, want_entropy: bool = False):
+    """softmax over each row of ``where(keep, s, fill) * scale`` (keep = row_mask[i] & col_mask[j]; None = all):
+    (probabilities [n1,n2] or None, row entropies [n1] or None)."""
+    require_device(s)
+    s = s.contiguous()
+    n1, n2 = s.shape
+    out = torch.empty_like(s) if want_out else None
+    ent = torch.empty(n1, dtype=torch.float32, device=s.device) if want_entropy else None
+    rm, cm = _mask8(row_mask), _mask8(col_mask)
+    check(lib().jmac_row_softmax_f32(ptr(s), n2, n1, n2, ptr(rm), ptr(cm), float(fill), float(scale), ptr(out), n2, ptr(ent),
+                                     stream()), "jmac_row_softmax_f32")
+    return out, ent
+
+
+def col_softmax(s: torch.Tensor, row_mask=None, col_mask=None, fill: float = -1.0, scale: float = 20.0,
+                want_out: bool = True, want_entropy: bool = False):
+    """softmax over each COLUMN of the same masked, scaled matrix, returned transposed:
+    ``torch.softmax(where(keep, s, fill).t() * scale, dim=1)`` [n2,n1] (or None) and the column entropies [n2] (or None)
+    -- from the row-major ``s`` itself, i.e. without the second, transposed similarity GEMM."""
+    require_device(s)
+    s = s.contiguous()
+    n1, n2 = s.shape
+    out_t = torch.empty((n2, n1), dtype=torch.float32, device=s.device) if want_out else None
+    ent = torch.empty(n2, dtype=torch.float32, device=s.device) if want_entropy else None
+    rm, cm = _mask8(row_mask), _mask8(col_mask)
+    L = lib()
+    wsb = int(L.jmac_col_softmax_workspace_bytes(n1, n2))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=s.device)
+    check(L.jmac_col_softmax_f32(ptr(s), n2, n1, n2, ptr(rm), ptr(cm), float(fill), float(scale), ptr(out_t), n1, ptr(ent),
+                                 ptr(ws), wsb, stream()), "jmac_col_softmax_f32")
+    return out_t, ent
+
+
 def alignment_quality(emb1: torch.Tensor, emb2: torch.Tensor, list1, list2, scale: float = 20.0):
     """compute_alignment_quality, train.py:231-259: (entropy, softmax rows [N1,N2], softmax cols [N2,N1]).
-    The O(N*T) python membership scans of :252-253 become boolean masks."""
+    The O(N*T) python membership scans of :252-253 become boolean masks; each of the two similarity matrices
+    (:239 and :250) is ONE GEMM, its transposed softmax (:245, :257) is a column pass over the same matrix."""
     dev = emb1.device
     l1 = torch.as_tensor(list1, dtype=torch.long, device=dev)
     l2 = torch.as_tensor(list2, dtype=torch.long, device=dev)
@@ -197,8 +237,28 @@ def alignment_quality(emb1: torch.Tensor, emb2: torch.Tensor, list1, list2, scal
     m2 = torch.zeros(emb2.shape[0], dtype=torch.bool, device=dev)
     m2[l2] = True
     simi = sim_matrix(emb1, emb2)
-    simi_t = sim_matrix(emb2, emb1)
-    return entropy, masked_row_softmax(simi, m1, m2, -1.0, scale), masked_row_softmax(simi_t, m2, m1, -1.0, scale)
+    return entropy, row_softmax(simi, m1, m2, -1.0, scale)[0], col_softmax(simi, m1, m2, -1.0, scale)[0]
+
+
+# ---- DBPv1 call sites (row a18): ONE embedding table on both sides ------------------------------------------------
+def get_neg_dbpv1(ILL, output_layer: torch.Tensor, k: int) -> torch.Tensor:
+    """get_neg(ILL, output_layer, k), JMAC_DBPv1/modules/utils/util.py:35-58: the k most similar rows of the WHOLE
+    table (own KG and the entity itself included) for every entity of ILL, flattened [len(ILL)*k] int64."""
+    return get_neg(ILL, output_layer, output_layer, k)
+
+
+def alignment_quality_dbpv1(embedding: torch.Tensor, list1, list2, scale: float = 20.0):
+    """Trainer.compute_alignment_quality(embedding, list1, list2), JMAC_DBPv1/trainer/jmac_trainer.py:281-300:
+    (entropy, softmax(simi*20, dim=1) [T1,T2], softmax(simi.t()*20, dim=1) [T2,T1]) with simi = E[list1] E[list2]^T.
+    One similarity GEMM; the row pass yields softmax + row entropies, the column pass the transposed softmax +
+    column entropies."""
+    dev = embedding.device
+    l1 = torch.as_tensor(list1, dtype=torch.long, device=dev)
+    l2 = torch.as_tensor(list2, dtype=torch.long, device=dev)
+    simi = sim_matrix(embedding.index_select(0, l1), embedding.index_select(0, l2))
+    p_rows, h_rows = row_softmax(simi, None, None, 0.0, scale, True, True)
+    p_cols, h_cols = col_softmax(simi, None, None, 0.0, scale, True, True)
+    return h_rows.mean() + h_cols.mean(), p_rows, p_cols
 
 
 # ---- alignment evaluation (next row f1: modules/finding/similarity.py:13-84, alignment.py:10-112) -------------
@@ -223,6 +283,7 @@ def csls_rank(sim: torch.Tensor, k: int, gold) -> torch.Tensor:
     n1, n2 = sim.shape
     r1 = row_topk(sim, k)[0].mean(1)
     r2 = col_topk_values(sim, k).mean(1)
+    check_index_range(gold, n2, "gold")
     gold = torch.as_tensor(gold, device=sim.device).to(torch.int32).contiguous()
     rank = torch.empty(n1, dtype=torch.int32, device=sim.device)
     check(lib().jmac_csls_rank_f32(ptr(sim), n2, n1, n2, ptr(r1), ptr(r2), ptr(gold), ptr(rank), stream()), "jmac_csls_rank_f32")

@@ -96,10 +96,16 @@ def edge_norm(edge_index: Tensor, num_ent: int) -> Tensor:
 
 def _message_and_aggregate(x: Tensor, rel: Tensor, edge_index: Tensor, edge_type: Tensor,
                            norm: Optional[Tensor], p: Dict[str, Tensor], slope: float,
-                           comp_op: str) -> Tensor:
+                           comp_op: str, kink_mask: Optional[Tensor] = None) -> Tensor:
     """propagate + message + scatter_ (message_passing.py:55-90, :4-29; jmac_model.py:56-89).
 
     Aggregation destination is edge_index[0]; the message source is edge_index[1].
+
+    ``kink_mask`` ([E, d] bool, tests only): evaluate the attention LeakyReLU (:76) as ``where(mask, h, slope*h)``
+    instead of by the sign of this evaluation's own h.  The forward is continuous at h = 0, its derivative is not
+    (1 vs slope), so two correct evaluations in different precisions (fp32 on the GPU, float64 here) legitimately
+    disagree in the gradient wherever a pre-activation of magnitude ~1e-7 rounds to the other side of zero.
+    Passing the other evaluation's side of the kink makes the two gradients comparable at full tolerance.
     """
     n = x.shape[0]
     dst, src = edge_index[0], edge_index[1]
@@ -111,7 +117,11 @@ def _message_and_aggregate(x: Tensor, rel: Tensor, edge_index: Tensor, edge_type
         m = x_j * r
     else:
         raise NotImplementedError(comp_op)
-    hidden = F.leaky_relu(torch.cat((x_i, m), dim=1) @ p["w_att"], slope)    # :75-76
+    pre_att = torch.cat((x_i, m), dim=1) @ p["w_att"]                       # :75
+    if kink_mask is None:
+        hidden = F.leaky_relu(pre_att, slope)                               # :76
+    else:
+        hidden = torch.where(kink_mask, pre_att, pre_att * slope)
     score = hidden @ p["a_att"]                                 # [E,1]
     o = m @ p["gcn_weight"]                                     # :88
     alpha = scatter_softmax(score, dst, n)                      # message_passing.py:24
@@ -130,7 +140,7 @@ def transform_relations(p: Dict[str, Tensor], rel_emb: Tensor, slope: float, rel
 
 def layer_pre_bn(p: Dict[str, Tensor], ent_emb: Tensor, rel_emb: Tensor, edge_index: Tensor,
                  edge_type: Tensor, slope: float = 0.05, comp_op: str = "sub",
-                 rel_act: str = "leaky_relu") -> Tuple[Tensor, Tensor, Tensor]:
+                 rel_act: str = "leaky_relu", kink_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """(message_neighbors, message_self, (nb+self)/2) of jmac_model.py:39-52, before BN/tanh."""
     n = ent_emb.shape[0]
     rel = transform_relations(p, rel_emb, slope, rel_act)
@@ -138,7 +148,7 @@ def layer_pre_bn(p: Dict[str, Tensor], ent_emb: Tensor, rel_emb: Tensor, edge_in
     loop_index = torch.stack([loop, loop])                      # :44
     loop_type = torch.full((n,), rel.shape[0] - 1, dtype=torch.long)   # :45
     norm = edge_norm(edge_index, n)                             # :47
-    nb = _message_and_aggregate(ent_emb, rel, edge_index, edge_type, norm, p, slope, comp_op)   # :49
+    nb = _message_and_aggregate(ent_emb, rel, edge_index, edge_type, norm, p, slope, comp_op, kink_mask)   # :49
     sl = _message_and_aggregate(ent_emb, rel, loop_index, loop_type, None, p, slope, comp_op)   # :50
     return nb, sl, (nb + sl) / 2
 
@@ -147,17 +157,18 @@ def layer_forward(p: Dict[str, Tensor], ent_emb: Tensor, rel_emb: Tensor, edge_i
                   edge_type: Tensor, slope: float = 0.05, comp_op: str = "sub",
                   rel_act: str = "leaky_relu", training: bool = True,
                   running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None,
-                  momentum: float = 0.1, eps: float = 1e-5, act=torch.tanh) -> Tensor:
+                  momentum: float = 0.1, eps: float = 1e-5, act=torch.tanh,
+                  kink_mask: Optional[Tensor] = None) -> Tensor:
     """RelationAwareLayer.forward, jmac_model.py:33-53: act(BatchNorm1d((nb+self)/2)).
 
     ``running_mean/var`` are updated in place in training mode exactly like nn.BatchNorm1d.
     """
-    _, _, pre = layer_pre_bn(p, ent_emb, rel_emb, edge_index, edge_type, slope, comp_op, rel_act)
+    _, _, pre = layer_pre_bn(p, ent_emb, rel_emb, edge_index, edge_type, slope, comp_op, rel_act, kink_mask)
     d = pre.shape[1]
     if running_mean is None:
-        running_mean = torch.zeros(d)
+        running_mean = torch.zeros(d, dtype=pre.dtype)
     if running_var is None:
-        running_var = torch.ones(d)
+        running_var = torch.ones(d, dtype=pre.dtype)
     y = F.batch_norm(pre, running_mean, running_var, p["bn.weight"], p["bn.bias"], training,
                      momentum, eps)
     return act(y)
@@ -174,19 +185,22 @@ def _sub(params: Dict[str, Tensor], prefix: str) -> Dict[str, Tensor]:
 def forward_name(params: Dict[str, Tensor], name_emb: Tensor, edge_index: Tensor, edge_type: Tensor,
                  ent_bases: Sequence[int], rel_bases: Sequence[int], num_gcn_layer: int = 2,
                  slope: float = 0.05, comp_op: str = "sub", training: bool = False,
-                 bn_state: Optional[Dict[str, Tensor]] = None):
+                 bn_state: Optional[Dict[str, Tensor]] = None,
+                 kink_masks: Optional[Dict[str, Tensor]] = None):
     """JMAC.forward_name, jmac_model.py:172-204, with dropout p=0 (eval / deterministic parity).
 
     ``params`` uses the reference's state_dict names. ``bn_state`` maps e.g.
     'conv1_alignment.bn.running_mean' -> tensor (defaults to fresh BN statistics).
+    ``kink_masks`` (tests only) maps a layer name to the ``kink_mask`` of ``_message_and_aggregate``.
     """
     bn_state = bn_state if bn_state is not None else {}
+    kink_masks = kink_masks if kink_masks is not None else {}
 
     def conv(name: str, x: Tensor, r: Tensor) -> Tensor:
         return layer_forward(_sub(params, name), x, r, edge_index, edge_type, slope, comp_op,
                              "leaky_relu", training,
                              bn_state.get(name + ".bn.running_mean"),
-                             bn_state.get(name + ".bn.running_var"))
+                             bn_state.get(name + ".bn.running_var"), kink_mask=kink_masks.get(name))
 
     e0, e1 = ent_bases
     r0, r1 = rel_bases
@@ -494,6 +508,27 @@ def dbpv1_completion_loss(comp, rel, batch_h, batch_r, batch_t, links, batch_siz
 # --------------------------------------------------------------------------------------------
 # EnTr bookkeeping (next row f4): train.py:297-325
 # --------------------------------------------------------------------------------------------
+def dbpv1_get_neg(ill: Sequence[int], output_layer: Tensor, k: int) -> Tensor:
+    """get_neg(ILL, output_layer, k), JMAC_DBPv1/modules/utils/util.py:35-58: ONE table on both sides, so the top-k of a
+    seed runs over all entities of both KGs, the seed itself included (:53-56); flattened [t*k]."""
+    ill = torch.as_tensor(np.asarray(ill), dtype=torch.long)
+    sim = output_layer[ill] @ output_layer.t()                               # :54-56
+    return sim.topk(k, dim=1)[1].reshape(-1)                                 # :57
+
+
+def dbpv1_alignment_quality(embedding: Tensor, list1: Sequence[int], list2: Sequence[int], scale: float = 20.0):
+    """Trainer.compute_alignment_quality, JMAC_DBPv1/trainer/jmac_trainer.py:281-300: (entropy, softmax(simi*20, 1),
+    softmax(simi.t()*20, 1)) on the [T1, T2] block of the one embedding table."""
+    e1 = embedding[torch.as_tensor(np.asarray(list1), dtype=torch.long)]     # :286-287
+    e2 = embedding[torch.as_tensor(np.asarray(list2), dtype=torch.long)]
+    simi = e1 @ e2.t()                                                       # :289
+    p1 = torch.softmax(simi * scale, dim=1)                                  # :291
+    h1 = (-torch.log(p1) * p1).sum(1).mean()                                 # :292-293
+    p2 = torch.softmax(simi.t() * scale, dim=1)                              # :295
+    h2 = (-torch.log(p2) * p2).sum(1).mean()                                 # :296-297
+    return h1 + h2, p1, p2                                                   # :299-300
+
+
 def transfer_knowledge(triples_src, triples_dst, pairs, keys1: set, keys2: set):
     """transfer_knowledge, train.py:297-325, with the dict of train.py:202 built from the [L,2] pair list.
     Loop restatement (small cases only).  keys*: sets of (h, r, t) tuples, updated in place like the reference's

@@ -79,3 +79,50 @@ def test_bench_refuses_to_run_without_a_gpu():
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1"], stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, text=True, timeout=300)
     assert res.returncode != 0 and "MI355X" in (res.stderr + res.stdout) and res.stdout.strip() == ""
+
+
+def _bench(*args, env=None):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(args), stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, env=e, timeout=300)
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus N` with no launcher around it starts N ranks itself (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, one rendezvous address shared by all) -- the dry launch stops each rank before it touches a GPU."""
+    import json
+    res = _bench("--gpus", "2", "--dry-launch")
+    assert res.returncode == 0, res.stderr
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    assert sorted(l["rank"] for l in lines) == [0, 1]
+    assert all(l["world"] == 2 and l["local_rank"] == l["rank"] for l in lines)
+    assert len({l["master"] for l in lines}) == 1 and lines[0]["master"].startswith("127.0.0.1:")
+
+
+def test_bench_fails_when_a_rank_fails_or_the_world_disagrees():
+    # a launcher that started a different number of ranks than --gpus says: refuse instead of reporting n_gpus wrongly
+    res = _bench("--gpus", "4", "--dry-launch", env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert res.returncode != 0 and "WORLD_SIZE" in res.stderr
+    # no HIP device here: every child exits non-zero, and so must the parent
+    res = _bench("--gpus", "2", "--steps", "1")
+    assert res.returncode != 0
+
+
+def test_index_range_check_on_host_data():
+    """Out-of-range ids raise IndexError like torch indexing in the reference (host data is checked on the host)."""
+    import numpy as np
+    _lib.check_index_range([0, 3, 2], 4)
+    _lib.check_index_range(np.array([], dtype=np.int64), 0)
+    _lib.check_index_range(torch.tensor([1, 2]), 3)
+    with pytest.raises(IndexError):
+        _lib.check_index_range([0, 4], 4, "edge_type")
+    with pytest.raises(IndexError):
+        _lib.check_index_range(torch.tensor([-1, 2]), 3)
+    from jmac_amd.model import _idx
+    with pytest.raises(IndexError):
+        _idx(np.array([5.0, 1.0]), "cpu", 5)
+    assert getattr(_idx([1, 2], "cpu", 5), "_jmac_range_ok") == 5

@@ -55,3 +55,35 @@ def test_csr_and_schedules(n, nr, e, chunk):
         to = g.by_rel.order[:e].cpu().numpy()
         assert (to == np.argsort(typ, kind="stable")).all()
         assert (np.diff(g.by_rel.ptr.cpu().numpy()) == np.bincount(typ, minlength=nr + 1)).all()
+
+
+def test_out_of_range_ids_raise_index_error():
+    """The reference's torch indexing raises IndexError on a bad entity / relation id; unchecked, the kernels would write
+    outside rowptr or scatter gradients outside the tables.  Graph build, loss gathers and the ranking entry point
+    validate their indices (device tensors: one jmac_index_check per tensor, cached)."""
+    from jmac_amd import losses, scoring
+    from jmac_amd.graph import RelGraph
+    ei = torch.tensor([[0, 5, 2], [1, 2, 3]]).cuda()
+    et = torch.tensor([0, 1, 1]).cuda()
+    RelGraph(ei, et, 6, 2)                                            # fine
+    with pytest.raises(IndexError):
+        RelGraph(ei, et, 5, 2)                                        # destination 5 >= N
+    with pytest.raises(IndexError):
+        RelGraph(ei, torch.tensor([0, 2, 1]).cuda(), 6, 2)            # relation 2 >= nrel
+    with pytest.raises(IndexError):
+        RelGraph(torch.tensor([[0, 1, 2], [1, -1, 3]]).cuda(), et, 6, 2)
+    ent, rel = torch.randn(10, 8).cuda(), torch.randn(3, 8).cuda()
+    h, r, t_ = torch.tensor([1, 2]).cuda(), torch.tensor([0, 2]).cuda(), torch.tensor([9, 3]).cuda()
+    losses.triple_l1_score(ent, rel, h, r, t_)
+    with pytest.raises(IndexError):
+        losses.triple_l1_score(ent, rel, h, torch.tensor([0, 3]).cuda(), t_)
+    with pytest.raises(IndexError):
+        losses.pair_cosine_distance(ent, torch.tensor([10]).cuda(), ent, torch.tensor([0]).cuda())
+    with pytest.raises(IndexError):
+        scoring.filtered_rank(torch.randn(2, 10).cuda(), [3, 10])
+    # an in-place edit invalidates the cached verdict
+    h2 = torch.tensor([1, 2]).cuda()
+    losses.triple_l1_score(ent, rel, h2, r, t_)
+    h2[0] = 11
+    with pytest.raises(IndexError):
+        losses.triple_l1_score(ent, rel, h2, r, t_)

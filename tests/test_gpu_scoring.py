@@ -202,3 +202,50 @@ def test_csls_rank_equals_csls_sim_then_rank():
     gold = torch.randint(0, 700, (700,), generator=gen)
     want = scoring.filtered_rank(scoring.csls_sim(s, 10), gold, descending=True)
     assert torch.equal(scoring.csls_rank(s, 10, gold), want)
+
+
+def test_dbpv1_get_neg_and_alignment_quality_match_reference_golden():
+    """Row a18 on the HIP kernels: get_neg(ILL, output_layer, k) (JMAC_DBPv1/modules/utils/util.py:35-58) bit-exact,
+    Trainer.compute_alignment_quality (trainer/jmac_trainer.py:281-300) at 1e-4 -- fixture from the reference's own
+    functions; entropy + both softmax orientations come from ONE similarity GEMM."""
+    from jmac_amd import scoring
+    g = load_golden("scoring_dbpv1")
+    emb, k, links = t(g["emb"], "cuda"), int(g["k"]), g["links"]
+    assert (scoring.get_neg_dbpv1(links[:, 1].tolist(), emb, k).cpu().numpy() == g["neg2_left"]).all()
+    assert (scoring.get_neg_dbpv1(links[:, 0].tolist(), emb, k).cpu().numpy() == g["neg_right"]).all()
+    ent, p1, p2 = scoring.alignment_quality_dbpv1(emb, g["list1"].tolist(), g["list2"].tolist())
+    assert abs(ent.item() - float(g["entropy"])) < 1e-4 * abs(float(g["entropy"]))
+    assert_close(p1, g["softmax_simi"], 1e-4)
+    assert_close(p2, g["softmax_simi2"], 1e-4)
+
+
+@pytest.mark.parametrize("n1,n2", [(90, 90), (257, 1000), (2265, 2265), (64, 4097), (3000, 65)])
+def test_row_and_col_softmax_against_torch(n1, n2):
+    """jmac_row_softmax_f32 / jmac_col_softmax_f32 (masked, scaled; probabilities + entropies) against float64 torch:
+    the column form must equal softmax of the TRANSPOSED matrix (train.py:245,257) without a transposed GEMM."""
+    from jmac_amd import scoring
+    gen = torch.Generator().manual_seed(n1 + n2)
+    s = torch.randn(n1, n2, generator=gen) * 0.3
+    m1 = torch.rand(n1, generator=gen) < 0.7
+    m2 = torch.rand(n2, generator=gen) < 0.6
+    m1[0], m2[0] = True, True
+    for rm, cm, fill in ((None, None, 0.0), (m1, m2, -1.0)):
+        x = s.double()
+        if rm is not None:
+            keep = rm.view(-1, 1) & cm.view(1, -1)
+            x = torch.where(keep, x, torch.full_like(x, fill))
+        x = x * 20.0
+        pr = torch.softmax(x, dim=1)
+        pc = torch.softmax(x.t(), dim=1)
+        hr = -(torch.log(pr.clamp_min(1e-300)) * pr).sum(1)
+        hc = -(torch.log(pc.clamp_min(1e-300)) * pc).sum(1)
+        rmg = rm.cuda() if rm is not None else None
+        cmg = cm.cuda() if cm is not None else None
+        o, e = scoring.row_softmax(s.cuda(), rmg, cmg, fill, 20.0, True, True)
+        assert_close(o, pr, 1e-5, 1e-9, "row softmax")
+        assert_close(e, hr, 1e-4, 1e-6, "row entropy")
+        o, e = scoring.col_softmax(s.cuda(), rmg, cmg, fill, 20.0, True, True)
+        assert o.shape == (n2, n1)
+        assert_close(o, pc, 1e-5, 1e-9, "col softmax")
+        assert_close(e, hc, 1e-4, 1e-6, "col entropy")
+        assert scoring.col_softmax(s.cuda(), rmg, cmg, fill, 20.0, False, True)[0] is None

@@ -176,3 +176,19 @@ def test_dbpv1_model_oracle_matches_reference_golden():
     loss = orc.dbpv1_completion_loss(comp_t, rel_t, torch.from_numpy(g["batch_h"]), torch.from_numpy(g["batch_r"]),
                                      torch.from_numpy(g["batch_t"]), g["links"], 30, 5.0)
     assert abs(float(loss) - float(g["completion_loss"])) < 2e-6 * abs(float(g["completion_loss"]))
+
+
+def test_dbpv1_scoring_call_sites():
+    """Row a18: the oracle's restatements of JMAC_DBPv1/modules/utils/util.py:35-58 and trainer/jmac_trainer.py:281-300
+    against the fixture captured from the reference's own functions (tests/golden/gen_golden.py:gen_dbpv1_scoring)."""
+    g = load_golden("scoring_dbpv1")
+    emb, k, links = t(g["emb"]), int(g["k"]), g["links"]
+    assert float(g["min_topk_gap"]) > 1e-5                       # index parity is well defined on this fixture
+    assert (orc.dbpv1_get_neg(links[:, 1], emb, k).numpy() == g["neg2_left"]).all()
+    assert (orc.dbpv1_get_neg(links[:, 0], emb, k).numpy() == g["neg_right"]).all()
+    # the seed itself is its own nearest neighbour (one table on both sides)
+    assert (g["neg_right"].reshape(len(links), k)[:, 0] == links[:, 0]).all()
+    ent, p1, p2 = orc.dbpv1_alignment_quality(emb, g["list1"], g["list2"])
+    assert abs(float(ent) - float(g["entropy"])) < 1e-6 * abs(float(g["entropy"]))
+    assert_close(p1, g["softmax_simi"], 1e-6)
+    assert_close(p2, g["softmax_simi2"], 1e-6)
