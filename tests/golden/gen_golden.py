@@ -309,6 +309,154 @@ def gen_root():
     _save("model_small", **arrays)
 
 
+def _induced_subgraph(lang, m):
+    """The m highest-degree entities of a DBP-5L KG (train + val + test degree, ties -> lower id) and the triples
+    among them, entities relabelled 0..m-1 in that order; relation ids are kept.  Returns (train, val, test, old_ids)."""
+    import pandas as pd
+    root = os.path.join(REF, "datasetdbp5l", "kg")
+    parts = {sp: pd.read_csv(os.path.join(root, "%s-%s.tsv" % (lang, sp)), sep="\t", header=None).values.astype(np.int64)
+             for sp in ("train", "val", "test")}
+    allt = np.concatenate(list(parts.values()))
+    n = int(max(allt[:, 0].max(), allt[:, 2].max())) + 1
+    deg = np.bincount(allt[:, 0], minlength=n) + np.bincount(allt[:, 2], minlength=n)
+    keep = np.argsort(-deg, kind="stable")[:m]
+    new = -np.ones(n, dtype=np.int64)
+    new[keep] = np.arange(m)
+    out = []
+    for sp in ("train", "val", "test"):
+        t = parts[sp]
+        ok = (new[t[:, 0]] >= 0) & (new[t[:, 2]] >= 0)
+        t = t[ok]
+        out.append(np.stack([new[t[:, 0]], t[:, 1], new[t[:, 2]]], 1))
+    return out[0], out[1], out[2], keep
+
+
+def gen_e2e():
+    """End-to-end parity fixture (BASELINE metric "Hits@1 parity"): the REFERENCE's JMAC trained for a fixed, seeded
+    number of steps (dropout 0, captured batches) on sub-graphs derived from the real DBP-5L ja / el KGs, then scored by the
+    reference's own CompletionEvaluator.test (src/validate.py:22-80, filtered, validation split of the target KG).
+    Stored: the initial state_dict, graphs, every batch, the per-step losses, Hits@1 / Hits@10 / MRR before and after
+    and the final ranks -- so that the same steps can be replayed through the oracle (CPU) and the HIP path (GPU)."""
+    from src.jmac_model import JMAC
+    from src.knowledgegraph import KnowledgeGraph
+    from src.validate import CompletionEvaluator
+    import pandas as pd
+    import oracle.jmac_oracle as orc
+    rng = np.random.default_rng(2024)
+    torch.manual_seed(2024)
+    n1, n2, d, nrel = 700, 500, 32, 961                      # nrel: relations.txt lines + 1 (src/data_loader.py:214-215)
+    tr1, va1, te1, old1 = _induced_subgraph("ja", n1)        # target KG (trained on train only)
+    tr2, va2, te2, old2 = _induced_subgraph("el", n2)        # supporter KG (train + val, knowledgegraph.py:18-19)
+    seeds = pd.read_csv(os.path.join(REF, "datasetdbp5l", "seed_train_pairs", "el-ja.tsv"), sep="\t", header=None).values
+    seeds = seeds.astype(np.int64)                           # (el id, ja id), float-formatted on disk
+    m2 = -np.ones(int(max(old2.max(), seeds[:, 0].max())) + 1, np.int64); m2[old2] = np.arange(n2)
+    m1 = -np.ones(int(max(old1.max(), seeds[:, 1].max())) + 1, np.int64); m1[old1] = np.arange(n1)
+    ok = (m2[seeds[:, 0]] >= 0) & (m1[seeds[:, 1]] >= 0)
+    links = np.stack([m1[seeds[ok, 1]], m2[seeds[ok, 0]]], 1)        # (kg1 = ja, kg2 = el), LOCAL ids like train.py:183
+    margs = types.SimpleNamespace(dim=d, dropout=0.0, leaky_relu_w=0.05, comp_op="sub", num_gcn_layer=2, num_negative=5,
+                                  margin_align=1.0, margin_completion=5.0, batch_size=64, no_name_info=False,
+                                  device=torch.device("cpu"))
+    name_emb = rng.standard_normal((n1 + n2, 20)).astype(np.float32)
+    model = JMAC(margs, name_emb, 2 * nrel, n1 + n2)
+    # loop_rel is frozen for this run.  Its gradient is mathematically ZERO under train-mode BatchNorm (it only shifts
+    # every pre-BN row by the same vector, which the batch mean removes), so what Adam sees is fp32 rounding noise -- and
+    # Adam turns any noise above its eps into full +-lr steps.  The walk is invisible in train mode but moves the
+    # running means the evaluator then uses, i.e. it makes the final ranks a function of rounding order rather than of
+    # the algorithm.  Freezing it (a legitimate use of the reference's own module) makes the run reproducible by any
+    # correct fp32 implementation; everything else is exactly train.py's procedure.
+    for lay in (model.conv1_alignment, model.conv2_alignment, model.conv1_completion):
+        lay.loop_rel.requires_grad_(False)
+    kg1 = KnowledgeGraph("ja", tr1, va1, te1, n1, nrel, False, 0, 0, "cpu")
+    kg1.upper_entity_base, kg1.upper_relation_base = n1, nrel
+    kg2 = KnowledgeGraph("el", tr2, va2, te2, n2, nrel, True, n1, nrel, "cpu")
+    kg2.upper_entity_base, kg2.upper_relation_base = n1 + n2, 2 * nrel
+
+    def train_graph(tr):                                      # align_data_processing, train.py:116-135: head <- tail
+        return np.stack([tr[:, 0], tr[:, 2]]).astype(np.int64), tr[:, 1].astype(np.int64)
+    ei1, et1 = train_graph(kg1.train_data)
+    ei2, et2 = train_graph(kg2.train_data)
+    kg1.edge_index, kg1.edge_type = ei1, et1                  # the evaluator scores on the graph it is handed
+    e1i, e1t, e2i, e2t = (torch.from_numpy(x) for x in (ei1, et1, ei2, et2))
+    eb1, rb1, eb2, rb2 = [0, n1], [0, nrel], [n1, n1 + n2], [nrel, 2 * nrel]
+    K, B = margs.num_negative, margs.batch_size
+    neg_l = np.repeat(links[:, 0], K); neg2_r = np.repeat(links[:, 1], K)
+    feed = {"links": links, "neg_left": neg_l.astype(np.float64), "neg_right": torch.from_numpy(rng.integers(0, n2, len(links) * K)),
+            "neg2_left": torch.from_numpy(rng.integers(0, n1, len(links) * K)), "neg2_right": neg2_r.astype(np.float64),
+            "ent_bases1": eb1, "ent_bases2": eb2, "rel_bases1": rb1, "rel_bases2": rb2}
+    arrays = {"n1": n1, "n2": n2, "d": d, "nrel": nrel, "name_emb": name_emb, "links": links, "e1_index": ei1, "e1_type": et1,
+              "e2_index": ei2, "e2_type": et2, "train1": kg1.train_data, "val1": kg1.val_data, "test1": kg1.test_data,
+              "train2": kg2.train_data, "neg_right": _np(feed["neg_right"]), "neg2_left": _np(feed["neg2_left"]),
+              "lr": np.float64(5e-3), "batch_size": B, "num_negative": K}
+    for k, v in model.state_dict().items():
+        arrays["state0." + k] = _np(v)
+    lg = logging.getLogger("golden"); lg.setLevel(logging.ERROR)
+    ev = CompletionEvaluator(kg1, model, "cpu", None)
+    model.eval()
+    with torch.no_grad():
+        arrays["metrics_before"] = np.array(ev.test(margs, is_val=True, filterr=True, logger=lg), dtype=np.float64)
+    hb, rb, tb = kg1.h_val.tolist(), kg1.r_val.tolist(), kg1.t_val.tolist()
+    fp, fi = orc.build_filter_csr(hb, rb, kg1.true_tail)
+    arrays.update(filt_ptr=fp, filt_idx=fi)
+
+    def evaluate(tag):
+        """The reference's evaluator on the validation split (filtered) + the ranks behind its metrics + how decisive each
+        rank is: the distance gap between the gold tail and its nearest unfiltered competitor."""
+        model.eval()
+        with torch.no_grad():
+            arrays["metrics_" + tag] = np.array(ev.test(margs, is_val=True, filterr=True, logger=lg), dtype=np.float64)
+            dist = model.forward_linkpred(hb, rb, e1i, e1t, list(range(n1)), eb1, rb1)
+        ranks = orc.filtered_ranks(dist, tb, fp, fi)
+        assert np.allclose(np.array(orc.ranking_metrics(ranks)), arrays["metrics_" + tag], atol=1e-12)
+        dn = dist.numpy().astype(np.float64)
+        gap = np.empty(len(tb))
+        for j in range(len(tb)):
+            comp = np.ones(n1, bool)
+            comp[fi[fp[j]:fp[j + 1]]] = False
+            comp[tb[j]] = False
+            gap[j] = np.abs(dn[j, comp] - dn[j, tb[j]]).min()
+        arrays["ranks_" + tag] = ranks
+        arrays["rank_gap_" + tag] = gap
+        model.train()
+
+    # train.py:406-407: two Adam optimisers over ALL parameters
+    opt_a = torch.optim.Adam(model.parameters(), lr=float(arrays["lr"]))
+    opt_c = torch.optim.Adam(model.parameters(), lr=float(arrays["lr"]))
+    model.train()
+    # schedule: per epoch 6 completion steps on the target KG, 3 on the supporter KG, 1 alignment step (train.py:486-489)
+    sched, bh, br, bt, losses = [], [], [], [], []
+    CKPT = 3                                                   # epochs before the first evaluation (30 steps)
+    arrays["ckpt_steps"] = CKPT * 10
+    for epoch in range(12):
+        if epoch == CKPT:
+            evaluate("ckpt")
+        for kind, tr, nent in [("c1", kg1.train_data, n1)] * 6 + [("c2", kg2.train_data, n2)] * 3 + [("a", None, 0)]:
+            if kind == "a":
+                opt_a.zero_grad()
+                loss = model.alignment_loss(feed, e1i, e1t, e2i, e2t)
+                loss.backward(); opt_a.step()
+                h = r = t = np.zeros(B * (K + 1), np.int64)
+            else:
+                trip = torch.from_numpy(tr[rng.permutation(len(tr))[:B]].astype(np.int64))
+                neg = torch.from_numpy(rng.integers(0, nent, (B, K)).astype(np.int64))
+                data = {"batch_h": trip[:, 0].repeat(K + 1), "batch_r": trip[:, 1].repeat(K + 1),
+                        "batch_t": torch.cat((trip[:, 2], neg.view(-1)))}            # train.py:347-352
+                opt_c.zero_grad()
+                loss = model.completion_loss(data, e1i, e1t, e2i, e2t, feed, kind == "c1")
+                loss.backward(); opt_c.step()
+                h, r, t = (_np(data[x]) for x in ("batch_h", "batch_r", "batch_t"))
+            sched.append({"c1": 0, "c2": 1, "a": 2}[kind]); bh.append(h); br.append(r); bt.append(t)
+            losses.append(loss.item())
+    arrays.update(sched=np.array(sched), batch_h=np.stack(bh), batch_r=np.stack(br), batch_t=np.stack(bt),
+                  losses=np.array(losses, dtype=np.float64))
+    evaluate("after")
+    for k, v in model.state_dict().items():
+        arrays["state1." + k] = _np(v)
+    print("e2e: n1=%d E1=%d val=%d | n2=%d E2=%d | links=%d | steps=%d | loss %.4f -> %.4f | H@1/H@10/MRR %s -> %s -> %s" % (
+        n1, ei1.shape[1], len(kg1.val_data), n2, ei2.shape[1], len(links), len(sched), losses[0], losses[-1],
+        np.round(arrays["metrics_before"], 4), np.round(arrays["metrics_ckpt"], 4), np.round(arrays["metrics_after"], 4)))
+    _save("e2e_ja_sub", **arrays)
+
+
 def gen_aligneval():
     """modules.finding.evaluation.test on the model_small embeddings (train.py:105-113 settings)."""
     from modules.finding.evaluation import test
@@ -550,12 +698,13 @@ def gen_dbpv1():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variant", default="all", choices=["all", "root", "dbpv1", "aligneval", "entr", "dataset"])
+    ap.add_argument("--variant", default="all", choices=["all", "root", "dbpv1", "aligneval", "entr", "dataset", "e2e"])
     a = ap.parse_args()
     if a.variant == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for v in ("root", "dbpv1", "aligneval", "entr", "dataset"):
+        for v in ("root", "dbpv1", "aligneval", "entr", "dataset", "e2e"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--variant", v], env=env)
     else:
         _paths(a.variant)
-        {"root": gen_root, "dbpv1": gen_dbpv1, "aligneval": gen_aligneval, "entr": gen_entr, "dataset": gen_dataset}[a.variant]()
+        {"root": gen_root, "dbpv1": gen_dbpv1, "aligneval": gen_aligneval, "entr": gen_entr, "dataset": gen_dataset,
+         "e2e": gen_e2e}[a.variant]()

@@ -1,0 +1,56 @@
+"""CPU: the oracle replays the reference's 120 training steps (tests/golden/e2e_ja_sub.npz) and must land on the
+reference's losses, ranks and Hits@1 / Hits@10 / MRR (src/validate.py:22-80) -- the end-to-end pin of the oracle."""
+import numpy as np
+import torch
+
+import oracle.jmac_oracle as orc
+from e2e_replay import check_outcome, feeddict, fixture
+
+
+def test_oracle_replays_reference_training_run():
+    torch.set_num_threads(4)
+    g, m = fixture()
+    st = {k[len("state0."):]: torch.from_numpy(v).clone() for k, v in g.items() if k.startswith("state0.")}
+    no_grad = ("running", "num_batches", "margin_completion", "loop_rel")
+    leaf = {k: (v.requires_grad_(True) if v.dtype.is_floating_point and not any(x in k for x in no_grad) else v)
+            for k, v in st.items()}
+    bn = {k: v for k, v in st.items() if "running" in k}
+    params = [v for v in leaf.values() if v.requires_grad]
+    # train.py:406-407: two Adam optimisers over all parameters (an unused parameter has no gradient and is skipped)
+    opt_c = torch.optim.Adam(params, lr=m["lr"])
+    opt_a = torch.optim.Adam(params, lr=m["lr"])
+    name = torch.from_numpy(g["name_emb"])
+    e1i, e1t, e2i, e2t = (torch.from_numpy(g[k]) for k in ("e1_index", "e1_type", "e2_index", "e2_type"))
+    feed = feeddict(g, m)
+    margin = float(st["margin_completion"])
+
+    def enc():
+        o1 = orc.forward_name(leaf, name, e1i, e1t, m["eb1"], m["rb1"], 2, 0.05, "sub", True, bn)
+        o2 = orc.forward_name(leaf, name, e2i, e2t, m["eb2"], m["rb2"], 2, 0.05, "sub", True, bn)
+        return o1, o2
+
+    def val_ranks():
+        with torch.no_grad():
+            _, comp, rel = orc.forward_name(leaf, name, e1i, e1t, m["eb1"], m["rb1"], 2, 0.05, "sub", False, bn)
+            val = g["val1"]
+            dist = orc.linkpred_dist(comp, rel, val[:, 0].tolist(), val[:, 1].tolist())
+            return orc.filtered_ranks(dist, val[:, 2].tolist(), g["filt_ptr"], g["filt_idx"])
+
+    losses, ranks_ckpt = [], None
+    for s, kind in enumerate(g["sched"]):
+        if s == int(g["ckpt_steps"]):
+            ranks_ckpt = val_ranks()
+        opt = opt_a if kind == 2 else opt_c
+        opt.zero_grad(set_to_none=True)
+        (a1, c1, r1), (a2, c2, r2) = enc()
+        if kind == 2:
+            loss = orc.alignment_loss(a1, a2, feed["links"], feed["neg_left"], feed["neg_right"], feed["neg2_left"],
+                                      feed["neg2_right"], m["K"], 1.0)
+        else:
+            loss = orc.completion_loss(c1, r1, c2, r2, torch.from_numpy(g["batch_h"][s]), torch.from_numpy(g["batch_r"][s]),
+                                       torch.from_numpy(g["batch_t"][s]), feed["links"], m["B"], margin, kind == 0)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    check_outcome(g, losses, ranks_ckpt, val_ranks(), "oracle")
+    assert (ranks_ckpt == g["ranks_ckpt"]).all()        # same arithmetic as the reference on the same CPU: exact at 30 steps
