@@ -400,7 +400,90 @@ def raw_kernel_timing(N, E, nr, d, ei, et, device, iters=20, bwd_mode=1):
     return res
 
 
-def scoring_bench(w, iters=10):
+def _median_ms(fn, n=20, warm=5):
+    """Device-synchronised wall time of fn: median of n after warm warm-ups."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+
+
+def _cpu_median_s(fn, n=5, warm=1, budget_s=15.0):
+    for _ in range(warm):
+        fn()
+    ts, t_start = [], time.perf_counter()
+    while len(ts) < n and (not ts or time.perf_counter() - t_start < budget_s):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), len(ts)
+
+
+def layer_bench(w, device, cpu=True):
+    """SURVEY 8d's per-layer figures: E / wall time of ONE RelationAwareLayer forward, and of forward + backward, on the
+    ja graph (device-synchronised, median of 20 after 5 warm-ups; python + launch overhead included, no hipGraph), the
+    CSR / schedule build that is cached across calls, and the oracle's layer on the host cores beside it."""
+    from jmac_amd.graph import RelGraph
+    lay = w.model.conv1_completion
+    gen = torch.Generator(device=device).manual_seed(3)
+    X = (torch.randn(w.N, w.d, device=device, generator=gen) * 0.2).requires_grad_(True)
+    R = torch.randn(w.nr, w.d, device=device, generator=gen) * 0.2
+    G = torch.randn(w.N, w.d, device=device, generator=gen)
+
+    def fwd():
+        with torch.no_grad():
+            return lay(X, R, w.ei, w.et)
+
+    def fwdbwd():
+        out = lay(X, R, w.ei, w.et)
+        torch.autograd.grad(out, [X] + [p for p in lay.parameters() if p.requires_grad], G, allow_unused=True)
+
+    f_ms, fb_ms = _median_ms(fwd), _median_ms(fwdbwd)
+
+    def build():
+        g = RelGraph(w.ei, w.et, w.N, w.nr + 1)
+        g.ensure_backward_views()
+    csr_ms = _median_ms(build, n=5, warm=1)
+    res = {"what": "one RelationAwareLayer call on the ja graph (projection GEMMs + aggregation + BN + tanh), eager",
+           "fwd_ms": f_ms, "fwd_edges_per_s": w.E / (f_ms * 1e-3), "fwdbwd_ms": fb_ms, "fwdbwd_edges_per_s": w.E / (fb_ms * 1e-3),
+           "csr_build_ms": csr_ms, "csr_build": "COO -> CSR + by-source / by-relation views + schedules (cached per edge list)"}
+    if cpu:
+        import oracle.jmac_oracle as orc
+        p = {k: v.detach().cpu() for k, v in lay.named_parameters()}
+        Xc, Rc, Gc = X.detach().cpu().requires_grad_(True), R.cpu(), G.cpu()
+        ei, et = w.ei.cpu(), w.et.cpu()
+
+        def cf():
+            with torch.no_grad():
+                orc.layer_forward(p, Xc, Rc, ei, et, 0.05, "sub", "leaky_relu", True)
+
+        def cfb():
+            pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+            out = orc.layer_forward(pp, Xc, Rc, ei, et, 0.05, "sub", "leaky_relu", True)
+            torch.autograd.grad(out, [Xc] + list(pp.values()), Gc, allow_unused=True)
+        cf_s, n1 = _cpu_median_s(cf)
+        cfb_s, n2 = _cpu_median_s(cfb)
+        res["cpu"] = {"kind": "port", "cores": torch.get_num_threads(), "fwd_edges_per_s": w.E / cf_s, "fwdbwd_edges_per_s": w.E / cfb_s,
+                      "sample": "median of %d / %d calls of the oracle's layer on the same inputs" % (n1, n2)}
+        res["gpu_over_cpu_fwd"] = cf_s / (f_ms * 1e-3)
+        res["gpu_over_cpu_fwdbwd"] = cfb_s / (fb_ms * 1e-3)
+    return res
+
+
+# fp32 vector issue peak: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz = 78.6 T lane-instructions/s (a wave64 VALU
+# instruction issues over 2 cycles on a SIMD-32, MI355X_MICROARCH.md "CU = 4 x SIMD-32"); an FMA counts 2 flops per lane
+# instruction, which is the guide's 157.3 TFLOP/s vector peak.  Packed fp32 forms run at half rate: no extra flops.
+VALU_ISSUE_PEAK = 256 * 4 * 32 * 2.4e9
+VALU_FP32_PEAK_TFLOPS = 157.3
+
+
+def scoring_bench(w, iters=10, cpu=True):
     from jmac_amd import scoring
     m = w.model
     m.eval()
@@ -408,9 +491,11 @@ def scoring_bench(w, iters=10):
     B = w.a.batch
     hb = rng.integers(0, w.N, B)
     rb = rng.integers(0, w.nr - 1, B)
-    gold = torch.from_numpy(rng.integers(0, w.N, B)).to(w.ei.device)
-    fptr = torch.arange(0, 3 * B + 1, 3, dtype=torch.int32, device=w.ei.device)
-    fidx = torch.from_numpy(rng.integers(0, w.N, 3 * B).astype(np.int32)).to(w.ei.device)
+    gold_h = rng.integers(0, w.N, B)
+    gold = torch.from_numpy(gold_h).to(w.ei.device)
+    fptr_h = np.arange(0, 3 * B + 1, 3, dtype=np.int32)
+    fidx_h = rng.integers(0, w.N, 3 * B).astype(np.int32)
+    fptr, fidx = torch.from_numpy(fptr_h).to(w.ei.device), torch.from_numpy(fidx_h).to(w.ei.device)
     with torch.no_grad():
         cached = m.forward_base(w.ei, w.et, [0, w.N], [0, w.nr])
         def once():
@@ -424,20 +509,50 @@ def scoring_bench(w, iters=10):
             once()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / iters
+        # the L1 kernel alone: HIP events around back-to-back launches on the launch stream, preallocated output
+        er = (cached[1][1][torch.from_numpy(hb).to(w.ei.device)] + cached[2][1][torch.from_numpy(rb).to(w.ei.device)]).contiguous()
+        tab = cached[1][1].contiguous()
+        out = torch.empty((B, w.N), device=w.ei.device)
+        for _ in range(3):
+            scoring.l1_scores(er, tab, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nl = 50
+        e0.record()
+        for _ in range(nl):
+            scoring.l1_scores(er, tab, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / nl
     m.train()
-    # the L1 kernel issues 2 full-rate VALU instructions per (b, n, k): v_sub_f32 and v_add_f32 with the |.| source
-    # modifier (|.| has no packed form).  Issue peak = 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s;
-    # 157.3 TFLOP/s is the packed-FMA figure (4 flops per lane slot) that SURVEY 8d's "3 ops per element" is priced against.
-    elems = float(B) * w.N * w.d * 2
-    return {"scored_triples_per_s": B / dt, "pair_scores_per_s": B * w.N * 2 / dt, "ms_per_batch": dt * 1e3,
-            "B": B, "N": w.N, "layers": 2, "valu_frac_of_peak": (3.0 * elems / dt) / 157.3e12,
-            "valu_issue_frac": (2.0 * elems / dt) / 39.3e12}
+    # L1 distance is not a contraction (no MFMA form).  The kernel issues 2 full-rate VALU instructions per (b, n, k):
+    # v_sub_f32 and v_add_f32 with the |.| source modifier; SURVEY 8d prices it at 3 flops per element (sub, abs, add)
+    # against the fp32 vector peak.
+    elems_layer = float(B) * w.N * w.d
+    res = {"scored_triples_per_s": B / dt, "pair_scores_per_s": B * w.N * 2 / dt, "ms_per_batch": dt * 1e3,
+           "B": B, "N": w.N, "layers": 2,
+           "l1_kernel_ms": k_ms, "l1_kernel": "l1_score_kernel<float>, one layer (B x N x d), back-to-back launches",
+           "valu_issue_frac": (2.0 * elems_layer / (k_ms * 1e-3)) / VALU_ISSUE_PEAK, "valu_issue_peak_lane_insts_per_s": VALU_ISSUE_PEAK,
+           "valu_frac_of_fp32_peak": (3.0 * elems_layer / (k_ms * 1e-3)) / (VALU_FP32_PEAK_TFLOPS * 1e12),
+           "end_to_end_valu_frac_of_fp32_peak": (3.0 * 2 * elems_layer / dt) / (VALU_FP32_PEAK_TFLOPS * 1e12)}
+    if cpu:
+        import oracle.jmac_oracle as orc
+        comp = [c.detach().cpu() for c in cached[1]]
+        rel = [r.detach().cpu() for r in cached[2]]
+
+        def cpu_once():
+            d_ = orc.linkpred_dist(comp, rel, hb.tolist(), rb.tolist())
+            return orc.filtered_ranks(d_, gold_h.tolist(), fptr_h, fidx_h)
+        cs, n = _cpu_median_s(cpu_once, n=3)
+        res["cpu"] = {"kind": "port", "cores": torch.get_num_threads(), "scored_triples_per_s": B / cs,
+                      "sample": "median of %d batches: torch.cdist(p=1) x 2 layers + filter + rank count, same B / N / d" % n}
+        res["gpu_over_cpu"] = cs / dt
+    return res
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md)
 
 
-def sim_bench(device, iters=10):
+def sim_bench(device, iters=10, cpu=True):
     """Config 5 (OpenEA 15K shape): the fp32 MFMA similarity GEMM + fused top-k of get_neg, and the CSLS alignment test."""
     from jmac_amd import scoring
     gen = torch.Generator(device=device).manual_seed(0)
@@ -461,13 +576,54 @@ def sim_bench(device, iters=10):
     tf = 2.0 * 12000 * 12000 * 300 / (gemm_ms * 1e-3) / 1e12
     neg_ms = t(lambda: scoring.sim_topk(q, tab, 25))
     test_ms = t(lambda: scoring.alignment_test(tab[:10500], tab[10500:21000], (1, 5, 10), csls_k=10), 3)
-    return {"workload": "config 5 shape: N=30000 d=300; quality GEMM 12000x12000, get_neg 3000x30000 k=25, CSLS test 10500^2",
-            "sim_gemm_ms": gemm_ms, "sim_gemm_tflops": tf, "mfma_frac_of_f32_peak": tf / MFMA_F32_PEAK_TFLOPS,
-            "mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS, "mfma_util_pmc_percent": pmc_mfma_util(), "get_neg_ms": neg_ms, "get_neg_pairs_per_s": 3000 * 30000 / (neg_ms * 1e-3),
-            "alignment_test_ms": test_ms}
+    ent_ms = t(lambda: scoring.align_entropy(big[0], big[1]), 3)
+    res = {"workload": "config 5 shape: N=30000 d=300; quality GEMM 12000x12000, get_neg 3000x30000 k=25, CSLS test 10500^2",
+           "sim_gemm_ms": gemm_ms, "sim_gemm_tflops": tf, "mfma_frac_of_f32_peak": tf / MFMA_F32_PEAK_TFLOPS,
+           "mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS, "mfma_util_pmc_percent": pmc_mfma_util(),
+           "mfma_util_source": "profiles/r1_pmc_simgemm.json (committed rocprofv3 --pmc pass; not collected by this run)",
+           "get_neg_ms": neg_ms, "get_neg_pairs_per_s": 3000 * 30000 / (neg_ms * 1e-3),
+           "alignment_test_ms": test_ms, "align_entropy_12000sq_ms": ent_ms}
+    if cpu:
+        import oracle.jmac_oracle as orc
+        tc, qc = tab.cpu(), q.cpu()
+        ill = list(range(3000))
+        cs, n = _cpu_median_s(lambda: orc.get_neg(ill, qc, tc, 25), n=3)
+        res["cpu"] = {"kind": "port", "cores": torch.get_num_threads(), "get_neg_ms": cs * 1e3,
+                      "sample": "median of %d calls of mm + topk on the same 3000 x 30000 x 300 inputs" % n}
+        res["gpu_over_cpu_get_neg"] = cs * 1e3 / neg_ms
+    return res
 
 
-def synth_measure(a, device):
+def synth_cpu_layer(scale, d):
+    """config 4 down-scaled (E = 20M x scale) through the oracle's layer on the host cores, fwd and
+    fwd+bwd, one call each; the full-size figure is the linear extrapolation in E (stated in the output)."""
+    import types
+    import oracle.jmac_oracle as orc
+    from jmac_amd import synth
+    from jmac_amd.layer import RelationAwareLayer
+    n, e = int(1_000_000 * scale), int(20_000_000 * scale)
+    ei, et, n, nrel = synth.power_law_graph(n, e, 1000, seed=1234)
+    torch.manual_seed(0)
+    lay = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=types.SimpleNamespace(leaky_relu_w=0.05, comp_op="sub"))
+    p = {k: v.detach() for k, v in lay.named_parameters()}
+    X = (torch.randn(n, d) * 0.05).requires_grad_(True)
+    R, G = torch.randn(nrel - 1, d) * 0.05, torch.randn(n, d)
+    eit, ett = torch.from_numpy(ei), torch.from_numpy(et)
+    t0 = time.perf_counter()
+    out = orc.layer_forward(p, X, R, eit, ett, 0.05, "sub", "leaky_relu", True)
+    torch.autograd.grad(out, [X], G)
+    tfb = time.perf_counter() - t0
+    del out
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        orc.layer_forward(p, X, R, eit, ett, 0.05, "sub", "leaky_relu", True)
+    tf = time.perf_counter() - t0
+    return {"kind": "port", "cores": torch.get_num_threads(), "E": e, "N": n, "fwd_edges_per_s": e / tf, "fwdbwd_edges_per_s": e / tfb,
+            "sample": "one fwd and one fwd+bwd call of the oracle's layer on config 4 down-scaled x%.2f (N=%d, E=%d); per-edge "
+                      "cost is size-independent, so the 20M-edge figure is this rate (linear extrapolation)" % (scale, n, e)}
+
+
+def synth_measure(a, device, cpu=True):
     """Config 4 at HBM scale: the aggregation kernel on 1M entities / 20M triples / 1k relations, d=300."""
     from jmac_amd import synth
     n, e, nr = int(1_000_000 * a.synth_scale), int(20_000_000 * a.synth_scale), 1000
@@ -500,12 +656,22 @@ def synth_measure(a, device):
         del PQZ, RR, g
     except Exception as ex:                            # pragma: no cover
         bf = {"fwd_bf16_error": str(ex)}
-    return {**bf, "workload": "synthetic power-law 1M entities / 20M triples / 1k relations (config 4) x%.2f" % a.synth_scale,
-            "N": n, "E": e, "max_in_degree": int(deg.max()), "d": a.dim,
-            "fwd_ms": r["fwd_ms"], "fwd_edges_per_s": e / (r["fwd_ms"] * 1e-3),
-            "fwd_GBps": fb / (r["fwd_ms"] * 1e-3) / 1e9, "fwd_frac_hbm": fb / (r["fwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "bwd_ms": r["bwd_ms"], "bwd_GBps": bb / (r["bwd_ms"] * 1e-3) / 1e9,
-            "bwd_frac_hbm": bb / (r["bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    res = {**bf, "workload": "synthetic power-law 1M entities / 20M triples / 1k relations (config 4) x%.2f" % a.synth_scale,
+           "N": n, "E": e, "max_in_degree": int(deg.max()), "d": a.dim,
+           "fwd_ms": r["fwd_ms"], "fwd_edges_per_s": e / (r["fwd_ms"] * 1e-3),
+           "fwd_GBps": fb / (r["fwd_ms"] * 1e-3) / 1e9, "fwd_frac_hbm": fb / (r["fwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "fwd_traffic_bytes": pmc_traffic("config4", "rel_attn_fwd_kernel") if (a.dim == 300 and a.synth_scale == 1.0) else None,
+           "fwd_traffic_source": "profiles/r1_pmc_config4.json (committed rocprofv3 --pmc passes; not collected by this run)",
+           "bwd_ms": r["bwd_ms"], "bwd_GBps": bb / (r["bwd_ms"] * 1e-3) / 1e9,
+           "bwd_frac_hbm": bb / (r["bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bwd_bytes": "SURVEY 8d backward formula",
+           "bwd_edges_per_s": e / (r["bwd_ms"] * 1e-3)}
+    if cpu:
+        try:
+            res["cpu"] = synth_cpu_layer(0.1 * a.synth_scale, a.dim)
+            res["gpu_over_cpu_fwd"] = res["fwd_edges_per_s"] / res["cpu"]["fwd_edges_per_s"]
+        except Exception as ex:                            # pragma: no cover
+            res["cpu"] = {"error": str(ex)}
+    return res
 
 
 def pmc_traffic(key, kernel_prefix):
@@ -609,35 +775,32 @@ def main():
     ms = el / a.steps * 1e3
     layer_calls = 3
     value = world * layer_calls * w.E * a.steps / el
+    roof_src = "profiles/r1_pmc_ja.json (committed rocprofv3 --pmc passes; not collected by this run)"
     if dist_on:
+        # N > 1: the headline is the path that actually shards -- BASELINE config 4 weak-scaled, destination-sharded, RCCL
+        # all-gather / reduce-scatter per layer (north_star: "Partition ... across the 8 GPUs ... only when the graph
+        # shards"; DBP-5L-size graphs do not: SURVEY 8e "replicas only").  The replica figure of the ja workload is kept
+        # as an extra; the N = 1 line carries the same sharded step at one rank ("sharded"), which is the base a scaling
+        # efficiency of this value has to be computed against.
         import torch.distributed as dist
-        sharded = None
-        if not a.no_synth:
-            from bench_dist import run_sharded
-            sa = argparse.Namespace(**vars(a))
-            sa.steps, sa.warmup = max(3, min(a.steps, 10)), 2
-            try:
-                sl = run_sharded(sa, rank, world, device)
-                sharded = {k: sl[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "roofline_bwd")}
-            except Exception as ex:                  # pragma: no cover
-                sharded = {"error": str(ex)}
+        from bench_dist import run_sharded
+        sa = argparse.Namespace(**vars(a))
+        sa.steps, sa.warmup = max(3, min(a.steps, 10)), 2
+        line = run_sharded(sa, rank, world, device)
         if rank == 0:
-            line = {"metric": "gnn_layer_edges_per_s", "value": value, "unit": "edges/s", "n_gpus": world, "steps": a.steps,
-                    "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                    "dtype": "f32", "data": "synthetic",
-                    "config": {"workload": "one DBP-5L ja-shaped KG per GPU (replicas, no collective): N=%d E=%d nr=%d d=%d; "
-                                           "forward_base fwd+bwd + Adam, batch %dx(1+%d)" % (w.N, w.E, w.nr, w.d, a.batch, a.negatives),
-                               "exec": exec_mode, "parallelism": "replicas x%d" % world,
-                               "library_gemm": "torch.mm (hipBLASLt/rocBLAS), TunableOp %s" % ("on" if tuned else "off"),
-                               "edges_counted_per_step": world * layer_calls * w.E},
-                    "roofline": None, "cpu_baseline": None, "sharded": sharded}
+            line["config"]["scaling_base"] = "the 'sharded' object of the --gpus 1 line (same step, one rank, no collective)"
+            line["replicas"] = {"value": value, "unit": "edges/s", "ms_per_step": ms, "steps": a.steps, "exec": exec_mode,
+                                "workload": "one DBP-5L ja-shaped KG per GPU, independent replicas, no collective "
+                                            "(N=%d E=%d d=%d; forward_base fwd+bwd + Adam)" % (w.N, w.E, w.d),
+                                "edges_counted_per_step": world * layer_calls * w.E}
+            line["parity"] = parity
             from jmac_amd import synth as _synth
             fb = _synth.fwd_algorithmic_bytes(w.N, w.E, w.d)
             fms = raw_kernel_timing(w.N, w.E, w.nr, w.d, w.ei, w.et, device, iters=25, bwd_mode=a.bwd_mode)["fwd_ms"]
-            line["roofline"] = {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<3, 2, 75, float> (rank 0)", "achieved": fb / (fms * 1e-3) / 1e9,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "traffic": pmc_traffic("ja", "rel_attn_fwd_kernel") if w.d == 300 else None,
-                                "algorithmic_bytes_per_launch": fb, "avg_launch_ms": fms}
+            line["roofline_ja"] = {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<3, 2, 75, float> (rank 0, ja shape)",
+                                   "achieved": fb / (fms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": fb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                   "algorithmic_bytes_per_launch": fb, "avg_launch_ms": fms}
         dist.barrier()
         dist.destroy_process_group()
         if rank == 0:                                   # after the teardown: RCCL's banner lines come first
@@ -653,14 +816,17 @@ def main():
     roof = {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<3, 2, 75, float>", "achieved": fbytes / (fwd_ms * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fbytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": pmc_traffic("ja", "rel_attn_fwd_kernel") if (w.d == 300 and a.workload == "dbp5l-ja") else None,
+            "traffic_source": roof_src,
             "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": fwd_ms, "launches": raw["fwd_launches"],
             "timing": "HIP events around %d back-to-back C-ABI launches on the launch stream" % raw["fwd_launches"],
             "in_step_op_ms": prof["rel_attn_fwd"][0],
             "note": "ja-scale working set (72 MB) is Infinity-Cache resident; HBM-scale figure is in 'synth'"}
     roof_bwd = {"bound": "hbm", "kernels": "rel_attn_bwd_dst + 2x rel_attn_bwd_gather (+reductions)",
+                "bytes": "SURVEY 8d backward formula E(2ds+8) + E*2d*4 + N(3d*4+16)", "algorithmic_bytes": bbytes,
                 "achieved": bbytes / (prof["rel_attn_bwd"][0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": bbytes / (prof["rel_attn_bwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "avg_launch_ms": prof["rel_attn_bwd"][0], "back_to_back_ms": raw["bwd_ms"]}
+                "avg_launch_ms": prof["rel_attn_bwd"][0], "back_to_back_ms": raw["bwd_ms"],
+                "implementation_bytes": synth.bwd_implementation_bytes(w.N, w.E, w.d)}
 
     line = {"metric": "gnn_layer_edges_per_s", "value": value, "unit": "edges/s", "n_gpus": 1, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -671,13 +837,17 @@ def main():
                        "library_gemm": "torch.mm (hipBLASLt/rocBLAS), TunableOp %s" % ("on" if tuned else "off"),
                        "edges_counted_per_step": layer_calls * w.E},
             "roofline": roof, "roofline_bwd": roof_bwd, "parity": parity}
-    line["scoring"] = scoring_bench(w)
+    cpu_on = not a.no_cpu_baseline
+    ncpu_small = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(ncpu_small)
+    line["layer"] = layer_bench(w, device, cpu_on)
+    line["scoring"] = scoring_bench(w, cpu=cpu_on)
     try:
-        line["sim"] = sim_bench(device)
+        line["sim"] = sim_bench(device, cpu=cpu_on)
     except Exception as ex:                          # pragma: no cover
         line["sim"] = {"error": str(ex)}
 
-    if not a.no_cpu_baseline:
+    if cpu_on:
         # PyTorch-CPU scales poorly past one socket's worth of cores on these small ops (256 threads ran 30x
         # slower than 32): time the port at two thread counts and keep the faster, i.e. the CPU's best case
         cstep = w.cpu_step_fn()
@@ -701,9 +871,18 @@ def main():
         line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
     if not a.no_synth:
         try:
-            line["synth"] = synth_measure(a, device)
+            line["synth"] = synth_measure(a, device, cpu=cpu_on)
         except Exception as ex:                      # pragma: no cover
             line["synth"] = {"error": str(ex)}
+        # the destination-sharded config-4 step at ONE rank (no collective runs): the base of the N > 1 lines' value
+        try:
+            from bench_dist import run_sharded
+            sa = argparse.Namespace(**vars(a))
+            sa.steps, sa.warmup = 5, 2
+            sl = run_sharded(sa, 0, 1, device)
+            line["sharded"] = {k: sl[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "roofline_bwd", "comm")}
+        except Exception as ex:                      # pragma: no cover
+            line["sharded"] = {"error": str(ex)}
     emit(line)
 
 

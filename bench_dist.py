@@ -83,17 +83,30 @@ def run_sharded(a, rank, world, device):
     e_total = e_loc * world
     value = 2 * e_total * a.steps / el
 
-    # per-kernel timing of the rank-local aggregation (HIP events on the launch stream), rank 0
-    ops.PROFILE = []
-    for _ in range(3):
+    # per-kernel timing of the rank-local aggregation and of the data-path collectives (HIP events on the launch
+    # stream, which waits for RCCL's stream), rank 0
+    import jmac_amd.dist as jdist
+    ops.PROFILE, jdist.COMM_PROFILE = [], []
+    nprof = 3
+    for _ in range(nprof):
         step()
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
+    crec, jdist.COMM_PROFILE = jdist.COMM_PROFILE, None
     fwd = [e0.elapsed_time(e1) for n, e0, e1 in rec if n == "rel_attn_fwd"]
     bwd = [e0.elapsed_time(e1) for n, e0, e1 in rec if n == "rel_attn_bwd"]
-    fb = synth.fwd_algorithmic_bytes(n_loc, e_loc, d) - n_loc * d * 4     # no fused self term: Z[i] is not read
+    fb = synth.fwd_algorithmic_bytes(n_loc, e_loc, d)
     bb = synth.bwd_algorithmic_bytes(n_loc, e_loc, d)
     fms, bms = float(np.mean(fwd)), float(np.mean(bwd))
+    comm = {"rccl_world": world, "layers": len(layers)}
+    for cname in ("all_gather_qz", "reduce_scatter_dqz"):
+        ts = [e0.elapsed_time(e1) for n, e0, e1, _ in crec if n == cname]
+        by = [b for n, _, _, b in crec if n == cname]
+        # the all-gather is started before the P-side GEMM and the relation transforms and waited for after them: its
+        # figure is launch-to-arrival on the compute stream, i.e. includes the work it overlaps
+        comm[cname + "_ms_per_layer"] = float(np.mean(ts)) if ts else 0.0
+        comm[cname + "_bytes_per_layer"] = int(np.mean(by)) if by else 0
+    comm["collective_ms_per_step"] = len(layers) * (comm["all_gather_qz_ms_per_layer"] + comm["reduce_scatter_dqz_ms_per_layer"])
     line = {"metric": "gnn_layer_edges_per_s", "value": value, "unit": "edges/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -106,6 +119,7 @@ def run_sharded(a, rank, world, device):
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": fb, "avg_launch_ms": fms, "launches": len(fwd)},
             "roofline_bwd": {"bound": "hbm", "achieved": bb / (bms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": bb / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": bms},
-            "cpu_baseline": None}
+                             "frac": bb / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": bms,
+                             "bytes": "SURVEY 8d backward formula"},
+            "comm": comm, "rccl_world": world, "cpu_baseline": None}
     return line

@@ -91,6 +91,25 @@ class ShardedGraph:
 # single-GPU box); the product leaves it False and short-circuits world == 1
 FORCE_COLLECTIVES = False
 
+# bench.py sets this to a list to collect (name, start_event, end_event) around the data-path collectives; the events are
+# recorded on the compute stream, which waits for the collective's completion (RCCL runs on its own stream)
+COMM_PROFILE = None
+
+
+def _cev(x: torch.Tensor):
+    if COMM_PROFILE is None or not x.is_cuda:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _cdone(name: str, e0, x: torch.Tensor) -> None:
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        COMM_PROFILE.append((name, e0, e1, x.numel() * x.element_size()))
+
 
 def _world(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -111,38 +130,60 @@ def _all_reduce(t: torch.Tensor, group=None) -> None:
 
 
 class _AllGatherRows(torch.autograd.Function):
-    """[n_max, w] per rank -> [world*n_max, w]; backward = reduce-scatter (sum) of the gradient."""
+    """[n_max, w] per rank -> [world*n_max, w]; backward = reduce-scatter (sum) of the gradient.
+
+    ``defer``: start the collective and return at once -- RCCL runs it on its own stream; the caller enqueues independent
+    work on the compute stream and calls ``pending_wait()`` before the first kernel that reads the gathered table."""
+
+    pending = None          # (work handle, profile start event, output) of a deferred all-gather
 
     @staticmethod
-    def forward(ctx, x, group):
+    def forward(ctx, x, group, defer=False):
         ctx.group = group
         world = _world(group)
         if _skip(group):
             return x
         x = x.contiguous()
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        e0 = _cev(x)
         if x.is_cuda and dist.get_backend(group) == "gloo":           # tests only: stage through the host
             h = torch.empty(out.shape, dtype=x.dtype)
             dist.all_gather_into_tensor(h, x.cpu(), group=group)
             out.copy_(h)
+        elif defer:
+            work = dist.all_gather_into_tensor(out, x, group=group, async_op=True)
+            _AllGatherRows.pending = (work, e0, out)
+            return out
         else:
             dist.all_gather_into_tensor(out, x, group=group)
+        _cdone("all_gather_qz", e0, out)
         return out
+
+    @staticmethod
+    def pending_wait() -> None:
+        """Make the compute stream wait for the deferred all-gather (no host block under RCCL)."""
+        p, _AllGatherRows.pending = _AllGatherRows.pending, None
+        if p is not None:
+            work, e0, out = p
+            work.wait()
+            _cdone("all_gather_qz", e0, out)
 
     @staticmethod
     def backward(ctx, g):
         world = _world(ctx.group)
         if _skip(ctx.group):
-            return g, None
+            return g, None, None
         g = g.contiguous()
         n = g.shape[0] // world
         if dist.get_backend(ctx.group) == "gloo":          # gloo has no reduce_scatter: all-reduce + slice
             _all_reduce(g, ctx.group)
             r = dist.get_rank(ctx.group)
-            return g[r * n:(r + 1) * n].clone(), None
+            return g[r * n:(r + 1) * n].clone(), None, None
         out = torch.empty((n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        e0 = _cev(g)
         dist.reduce_scatter_tensor(out, g, group=ctx.group)
-        return out, None
+        _cdone("reduce_scatter_dqz", e0, g)
+        return out, None, None
 
 
 class _AllReduceSum(torch.autograd.Function):
@@ -164,8 +205,8 @@ class _AllReduceSum(torch.autograd.Function):
         return g, None
 
 
-def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
-    return _AllGatherRows.apply(x, group)
+def all_gather_rows(x: torch.Tensor, group=None, defer: bool = False) -> torch.Tensor:
+    return _AllGatherRows.apply(x, group, bool(defer))
 
 
 def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
@@ -383,12 +424,21 @@ class ShardedRelationAwareLayer(nn.Module):
         d = L.out_channels
         if d % 4:
             raise NotImplementedError("sharded path needs out_channels % 4 == 0")
-        rel = L.transform_relations(rel_emb)
-        PQZ, RR, a, _ = L._tables(x_local, rel)                      # own rows only: 1/world of the GEMM
-        P, QZ_loc, Z_loc = PQZ[:, :d], PQZ[:, d:], PQZ[:, 2 * d:]
+        # The exchange goes first: [Q|Z] of the rank's own rows (1/world of that GEMM), then its all-gather over xGMI is
+        # STARTED, and everything that does not read the gathered table -- the P projection, the relation transforms and
+        # the [Rq|Rz] projection -- is enqueued behind it on the compute stream and runs while the links are busy.
+        d_in = L.in_channels
+        wqz = torch.cat([L.w_att[d_in:], L.gcn_weight], dim=1)       # [Wb | Wg]   (w_att = [Wt; Wb], src/jmac_model.py:24)
+        QZ_loc = torch.mm(x_local, wqz)                              # [n_r, 2d]
+        Z_loc = QZ_loc[:, d:]
         if sg.n_local < sg.n_max:                                    # pad to the common slab height
             QZ_loc = F.pad(QZ_loc, (0, 0, 0, sg.n_max - sg.n_local))
-        QZ = all_gather_rows(QZ_loc.contiguous(), self.group)        # [world*n_max, 2d]
+        QZ = all_gather_rows(QZ_loc.contiguous(), self.group, defer=True)   # [world*n_max, 2d], in flight
+        P = torch.mm(x_local, L.w_att[:d_in])
+        rel = L.transform_relations(rel_emb)
+        RR = L._rel_mm(rel, wqz)
+        a = L.a_att.reshape(-1).float()
+        _AllGatherRows.pending_wait()
         slope = L.atv_mlp.negative_slope
         if self.local_aggregate is None:
             pre = hip_local_layer(P.contiguous(), QZ, RR, a, sg, slope)

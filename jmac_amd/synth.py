@@ -73,9 +73,16 @@ def fwd_algorithmic_bytes(n: int, e: int, d: int, elem: int = 4) -> int:
 
 
 def bwd_algorithmic_bytes(n: int, e: int, d: int, elem: int = 4) -> int:
-    """Deterministic three-pass backward: pass A re-gathers [Q|Z] and writes 72 B of per-edge
-    records; passes B and C each gather one G row (d) + the record per edge; per node: P, G, out, Z in,
-    dP out (pass A) and the [dQ|dZ] row out (pass B)."""
+    """SURVEY.md section 8d, backward: E*(2*d*s + 8) [re-gather of the [Q|Z] rows + col + type]
+    + E*2*d*4 [the dQ / dZ contributions, counted once as a write] + N*(3*d*4 + 16) [G and out in, dP out, max/den/rowptr]."""
+    return e * (2 * d * elem + 8) + e * 2 * d * 4 + n * (3 * d * 4 + 16)
+
+
+def bwd_implementation_bytes(n: int, e: int, d: int, elem: int = 4) -> int:
+    """What the deterministic three-pass backward of this library actually moves: pass A re-gathers [Q|Z]
+    and writes 72 B of per-edge records; passes B and C each gather one G row (d) + the record per edge; per node: P, G,
+    out, Z in, dP out (pass A) and the [dQ|dZ] row out (pass B).  Diagnostic only: fractions are quoted on
+    bwd_algorithmic_bytes."""
     per_edge = (2 * d * elem + 8 + 72) + 2 * (d * elem + 72 + 8)
     per_node = 5 * d * elem + 16 + 2 * d * elem
     return e * per_edge + n * per_node
