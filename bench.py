@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import ctypes as C
 import numpy as np
 import torch
 
@@ -372,8 +373,7 @@ def raw_kernel_timing(N, E, nr, d, ei, et, device, iters=20, bwd_mode=1):
     wsb = int(L.jmac_rel_attn_fwd_workspace_bytes(sc.n_parts_max, d))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=device)
     Pd = PQZ.detach()
-    args = (ptr(Pd), 3 * d, Pd.data_ptr() + d * 4, 3 * d, ptr(RR), 2 * d, ptr(a), ptr(g.rowptr), ptr(g.col), ptr(g.etype),
-            ptr(sc.items), ptr(sc.splits), ptr(sc.counts), sc.n_items_max, sc.n_splits_max, sc.n_parts_max, N, d, 0.05,
+    args = (ptr(Pd), 3 * d, Pd.data_ptr() + d * 4, 3 * d, ptr(RR), 2 * d, ptr(a), ptr(g.col), ptr(g.etype), C.byref(sc.view()), N, d, 0.05,
             nr - 1, 0, 0.5, ptr(out_b), d, ptr(smax), ptr(sden), ptr(ws), wsb, stream())
     nf = max(iters, 5) * 4
     for _ in range(5):
@@ -723,6 +723,9 @@ def main():
     def init_dist():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("JMAC_BENCH_SHARE_GPU"):         # RCCL refuses two ranks on one device: the debugging aid runs
+            dist.init_process_group("gloo", rank=rank, world_size=world)   # the collectives through gloo (host staging)
+            return
         try:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         except TypeError:                                  # older signature without device_id

@@ -76,17 +76,48 @@ int jmac_csr_build(const int64_t* edge_index, const int64_t* edge_type, int64_t 
 int jmac_group_build(const int32_t* keys, int64_t E, int64_t S, int32_t* ptr, int32_t* order,
                      void* ws, size_t ws_bytes, jmac_stream_t stream);
 
-/* Upper bounds for the arrays jmac_items_build fills. */
-int64_t jmac_items_max(int64_t S, int64_t E, int32_t chunk);      /* items                  */
-int64_t jmac_splits_max(int64_t E, int32_t chunk);                /* split segments         */
-int64_t jmac_parts_max(int64_t E, int32_t chunk);                 /* partial slots          */
+/* Upper bounds for the arrays jmac_items_build fills (coop_min as passed to it; 0 = no cooperative splits). */
+int64_t jmac_items_max(int64_t S, int64_t E, int32_t chunk, int32_t coop_min);   /* items          */
+int64_t jmac_splits_max(int64_t E, int32_t chunk, int32_t coop_min);             /* split segments */
+int64_t jmac_parts_max(int64_t E, int32_t chunk, int32_t coop_min);              /* partial slots  */
 
-/* Cut segments (ptr [S+1]) into items of at most `chunk` entries.
- *   items [jmac_items_max], splits [jmac_splits_max], counts [4] = {n_items, n_splits, n_parts, 0}
- *   (device ints: kernels read the counts, the host never has to). */
-int jmac_items_build(const int32_t* ptr, int64_t S, int32_t chunk, jmac_item_t* items,
-                     jmac_split_t* splits, int32_t* counts, void* ws, size_t ws_bytes,
+/* Cut segments (ptr [S+1]) into items (one wavefront's unit of work each).
+ *   items [jmac_items_max], splits [jmac_splits_max],
+ *   counts [8] = {n_items, n_splits, n_parts, n_empty, n_coop, 0, 0, 0}  (device ints: kernels read the counts, the
+ *   host never has to).
+ * Segment classes: empty (no entries); plain (<= chunk entries: one item, finalised by its wave); split (> chunk
+ * entries: items of <= chunk entries each, merged by the combine pass); and, when coop_max > 0, cooperative
+ * (coop_min < len <= coop_max: exactly 4 items of ceil(len/4) entries -- the four wavefronts of one workgroup, whose
+ * partial results the forward kernel merges through LDS; for every other consumer they are ordinary split segments
+ * with 4 partial slots).  coop_max = 0 disables the class (schedules of the backward's by-source / by-relation views,
+ * large graphs).
+ * Item order: [cooperative items, 4 per segment][split items][plain segments in segment order][the n_empty empty
+ * segments]; the splits array lists the n_coop cooperative segments first (their .pad = 1). */
+int jmac_items_build(const int32_t* ptr, int64_t S, int32_t chunk, int32_t coop_min, int32_t coop_max,
+                     jmac_item_t* items, jmac_split_t* splits, int32_t* counts, void* ws, size_t ws_bytes,
                      jmac_stream_t stream);
+
+/* item_edges [n_items_max][4] int32 = {col[beg], etype[beg], col[beg+1], etype[beg+1]} per item of the by-destination
+ * schedule (-1 where the item is shorter): optional input of the forward kernels (small graphs). */
+int jmac_item_edges_build(const jmac_item_t* items, const int32_t* counts, int64_t n_items_max,
+                          const int32_t* col, const int32_t* etype, int32_t* item_edges,
+                          jmac_stream_t stream);
+
+/* One schedule over the CSR slots: the CSR by destination itself (order = NULL) or a regrouping of its slots by source /
+ * by relation (jmac_group_build), cut into items by jmac_items_build.  n_*_max: array bounds (the exact counts after a
+ * host read of `counts`, or the jmac_*_max upper bounds).  n_empty / n_coop: HOST copies of counts[3] / counts[4] -- exact
+ * values (read `counts` back once after jmac_items_build; 0 / 0 for a schedule built with coop_max = 0 whose empty
+ * segments need not be packed): they fix the launch geometry of the forward kernel without a device-side wait. */
+typedef struct {
+    const int32_t* ptr;          /* [S+1]                         */
+    const int32_t* order;        /* [E] CSR slot per entry, or NULL for the CSR itself */
+    const jmac_item_t* items;
+    const jmac_split_t* splits;
+    const int32_t* counts;       /* device {n_items,n_splits,n_parts,n_empty,n_coop,0,0,0} */
+    int64_t n_items_max, n_splits_max, n_parts_max;
+    const int32_t* item_edges;   /* jmac_item_edges_build's array for `items`, or NULL */
+    int64_t n_empty, n_coop;
+} jmac_view_t;
 
 /* ---------------------------------------------------------------------------------------------
  * Relation-aware attention aggregation (replaces: MessagePassing.propagate + message + scatter_,
@@ -101,16 +132,15 @@ int jmac_items_build(const int32_t* ptr, int64_t S, int32_t chunk, jmac_item_t* 
  * different index spaces (destination-sharded multi-GPU: P holds the rank's rows, QZ the all-gathered
  * table); the fused self term (loop_rel >= 0) reads QZ[self_off + i]: self_off = 0 when the two spaces coincide,
  * = the row of the gathered table that holds the rank's destination 0 when the destinations are a slice of it.
+ * by_dst: the schedule over the CSR rows (by_dst->ptr = rowptr [N+1], order = NULL).
  * --------------------------------------------------------------------------------------------- */
 size_t jmac_rel_attn_fwd_workspace_bytes(int64_t n_parts_max, int64_t d);
 
 int jmac_rel_attn_aggregate_fwd_f32(
     const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR, int64_t ldrr,
-    const float* a_att, const int32_t* rowptr, const int32_t* col, const int32_t* etype,
-    const jmac_item_t* items, const jmac_split_t* splits, const int32_t* counts,
-    int64_t n_items_max, int64_t n_splits_max, int64_t n_parts_max, int64_t N, int64_t d,
-    float slope, int32_t loop_rel, int64_t self_off, float out_scale, float* out, int64_t ldo, float* seg_max,
-    float* seg_den,
+    const float* a_att, const int32_t* col, const int32_t* etype, const jmac_view_t* by_dst,
+    int64_t N, int64_t d, float slope, int32_t loop_rel, int64_t self_off, float out_scale,
+    float* out, int64_t ldo, float* seg_max, float* seg_den,
     void* ws, size_t ws_bytes, jmac_stream_t stream);
 
 /* Same op with bf16 TABLES (P, QZ, RR: raw bf16 bits, rows 8-byte aligned: ld % 4 == 0, d % 4 == 0);
@@ -119,11 +149,9 @@ int jmac_rel_attn_aggregate_fwd_f32(
  * the HBM-bound kernel; forward only (BASELINE config 3: bf16 union-graph scoring is inference). */
 int jmac_rel_attn_aggregate_fwd_bf16(
     const uint16_t* P, int64_t ldp, const uint16_t* QZ, int64_t ldqz, const uint16_t* RR, int64_t ldrr,
-    const float* a_att, const int32_t* rowptr, const int32_t* col, const int32_t* etype,
-    const jmac_item_t* items, const jmac_split_t* splits, const int32_t* counts,
-    int64_t n_items_max, int64_t n_splits_max, int64_t n_parts_max, int64_t N, int64_t d,
-    float slope, int32_t loop_rel, int64_t self_off, float out_scale, float* out, int64_t ldo, float* seg_max,
-    float* seg_den,
+    const float* a_att, const int32_t* col, const int32_t* etype, const jmac_view_t* by_dst,
+    int64_t N, int64_t d, float slope, int32_t loop_rel, int64_t self_off, float out_scale,
+    float* out, int64_t ldo, float* seg_max, float* seg_den,
     void* ws, size_t ws_bytes, jmac_stream_t stream);
 
 /* Backward of the op above (replaces autograd through the same reference lines).
@@ -138,15 +166,6 @@ int jmac_rel_attn_aggregate_fwd_bf16(
 size_t jmac_rel_attn_bwd_workspace_bytes(int64_t N, int64_t E, int64_t nrel, int64_t d,
                                          int64_t n_parts_max_dst, int64_t n_parts_max_src,
                                          int64_t n_parts_max_rel, int32_t mode);
-
-typedef struct {
-    const int32_t* ptr;          /* [S+1]                         */
-    const int32_t* order;        /* [E] CSR slot per entry, or NULL for the CSR itself */
-    const jmac_item_t* items;
-    const jmac_split_t* splits;
-    const int32_t* counts;       /* device {n_items,n_splits,n_parts,0} */
-    int64_t n_items_max, n_splits_max, n_parts_max;
-} jmac_view_t;
 
 int jmac_rel_attn_aggregate_bwd_f32(
     const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR, int64_t ldrr,

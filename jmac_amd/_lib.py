@@ -26,7 +26,8 @@ class JmacError(RuntimeError):
 class View(C.Structure):
     """jmac_view_t"""
     _fields_ = [("ptr", vp), ("order", vp), ("items", vp), ("splits", vp), ("counts", vp),
-                ("n_items_max", i64), ("n_splits_max", i64), ("n_parts_max", i64)]
+                ("n_items_max", i64), ("n_splits_max", i64), ("n_parts_max", i64),
+                ("item_edges", vp), ("n_empty", i64), ("n_coop", i64)]
 
 
 # name -> (restype, argtypes); mirrors include/jmac_hip.h one to one
@@ -37,17 +38,16 @@ _SIGS = {
     "jmac_index_check": (C.c_int, [vp, i32, i64, i64, i64, vp, vp]),
     "jmac_csr_build": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
     "jmac_group_build": (C.c_int, [vp, i64, i64, vp, vp, vp, sz, vp]),
-    "jmac_items_max": (i64, [i64, i64, i32]),
-    "jmac_splits_max": (i64, [i64, i32]),
-    "jmac_parts_max": (i64, [i64, i32]),
-    "jmac_items_build": (C.c_int, [vp, i64, i32, vp, vp, vp, vp, sz, vp]),
+    "jmac_items_max": (i64, [i64, i64, i32, i32]),
+    "jmac_splits_max": (i64, [i64, i32, i32]),
+    "jmac_parts_max": (i64, [i64, i32, i32]),
+    "jmac_items_build": (C.c_int, [vp, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "jmac_rel_attn_fwd_workspace_bytes": (sz, [i64, i64]),
-    "jmac_rel_attn_aggregate_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp,
-                                                  i64, i64, i64, i64, i64, f32, i32, i64, f32, vp, i64, vp, vp,
-                                                  vp, sz, vp]),
-    "jmac_rel_attn_aggregate_fwd_bf16": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp,
-                                                   i64, i64, i64, i64, i64, f32, i32, i64, f32, vp, i64, vp, vp,
-                                                   vp, sz, vp]),
+    "jmac_item_edges_build": (C.c_int, [vp, vp, i64, vp, vp, vp, vp]),
+    "jmac_rel_attn_aggregate_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, C.POINTER(View),
+                                                  i64, i64, f32, i32, i64, f32, vp, i64, vp, vp, vp, sz, vp]),
+    "jmac_rel_attn_aggregate_fwd_bf16": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, C.POINTER(View),
+                                                   i64, i64, f32, i32, i64, f32, vp, i64, vp, vp, vp, sz, vp]),
     "jmac_rel_attn_bwd_workspace_bytes": (sz, [i64, i64, i64, i64, i64, i64, i64, i32]),
     "jmac_rel_attn_aggregate_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp,
                                                   C.POINTER(View), C.POINTER(View), C.POINTER(View),

@@ -24,6 +24,10 @@ namespace {
 constexpr int kBlock = 256;            // 4 waves
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kPersistBlocks = 2048;   // 256 CUs x 8
+#ifndef JMAC_EMPTY_PACK
+#define JMAC_EMPTY_PACK 4
+#endif
+constexpr int kEmptyPack = JMAC_EMPTY_PACK;          // empty segments handled by one wave of the forward kernel
 // (non-temporal gathers were measured and rejected: 13.4 vs 12.3 ms on config 4, 36 vs 26 us on ja)
 
 // IGroupLP pipeline for the machine scheduler: first the group's n vector-memory reads, then the vector ALU work.
@@ -42,7 +46,9 @@ struct FwdArgs {
     const jmac_item_t* items;
     const jmac_split_t* splits;
     const int32_t* counts;
+    const int4* item_edges;   // optional: {col, type} of the first two entries of every item (small graphs)
     int32_t N, D4, loop_rel, n_items_max;
+    int32_t n_coop;       // cooperative segments (host copy of counts[4], exact): the launch geometry depends on it
     int64_t self_off;     // row of QZ that holds destination 0 (fused self term; 0 unless destinations are a slice of the sources)
     float slope, out_scale;
     float *out, *seg_max, *seg_den;
@@ -100,6 +106,9 @@ __device__ __forceinline__ float4 sel4(bool c, float4 a) { return c ? a : f4zero
 template <int NCH, int U, int D4T, typename TT>
 __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
     typedef typename RawOf<TT>::type raw_t;
+    // cooperative segments: the partial softmax states of the block's four waves meet here
+    __shared__ float4 coop_acc[kWavesPerBlock][NCH][64];
+    __shared__ float coop_ml[kWavesPerBlock][2];
     const TT* const tP = static_cast<const TT*>(a.P);
     const TT* const tQZ = static_cast<const TT*>(a.QZ);
     const TT* const tRR = static_cast<const TT*>(a.RR);
@@ -107,6 +116,9 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = gridDim.x * kWavesPerBlock;
     const int n_items = a.counts[0];
+    const int n_empty = a.counts[3];
+    const int n_coop = a.n_coop;                  // == counts[4]; from the host so that no address below waits for it
+    const int n_reg = n_items - n_empty;          // items with entries come first, the empty segments are the tail of the list
     Lanes<NCH, D4T> L;
     L.init(lane, a.D4);
     const int voff = 4 * L.D4();
@@ -116,51 +128,24 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
     const bool has_loop = a.loop_rel >= 0;
     const TT* rloop = tRR + (int64_t)(has_loop ? a.loop_rel : 0) * a.ldrr;
 
+    // Work units of a launch, in this order for every block / wave:
+    //   1. cooperative segments (block cb = blockIdx, blockIdx + grid, ...): four waves, one quarter of the entries each
+    //   2. items (wave-strided over the item list behind the cooperative items)
+    //   3. packs of kEmptyPack empty segments
     // Items are software-pipelined: while item k computes, the header of item k+2 and the first col/type
     // batch of item k+1 are already in flight, so a wave's critical path per item is one gather round trip
     // instead of header -> col/type -> gather (measured: 65k rows of degree 1 took 114 us serialised).
-    // The first header is fetched at a clamped index so that it does not wait for the device-side item count.
-    int it = blockIdx.x * kWavesPerBlock + wave;
-    jmac_item_t item = a.items[min(it, a.n_items_max - 1)];
+    // The first header is fetched at a clamped index so that it does not wait for the device-side counts.
+    const int it0 = blockIdx.x * kWavesPerBlock + wave;
     // the loop relation's Rz row is the same for every destination: one read per wave
     float4 rl[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) rl[k] = (L.any_v(k) && has_loop) ? cvt4(ldraw(rloop + L.coffc[k])) : f4zero();
-    if (it >= n_items) return;
-    jmac_item_t nitem = a.items[min(it + nwaves, n_items - 1)];
-    int ccol, ctyp;
-    {
-        const int cnb = min(64, item.end - item.beg);
-        const int idx = cnb > 0 ? item.beg + min(lane, cnb - 1) : 0;
-        ccol = a.col[idx];
-        ctyp = a.etype[idx];
-    }
-    for (;;) {
-        const jmac_item_t nnitem = a.items[min(it + 2 * nwaves, n_items - 1)];
-        int ncol, ntyp;
-        {
-            const int nnb = min(64, nitem.end - nitem.beg);
-            const int idx = nnb > 0 ? nitem.beg + min(lane, nnb - 1) : 0;
-            ncol = a.col[idx];
-            ntyp = a.etype[idx];
-        }
-        const int i = item.seg;
-        float4 pv[NCH], acc[NCH], zs[NCH];
-        // a destination without in-edges needs no P row: re-read row 0 (cache hit) instead of its own
-        const TT* prow = tP + (int64_t)(item.end > item.beg ? i : 0) * a.ldp;
-        const TT* zrow = tQZ + ((int64_t)i + a.self_off) * a.ldqz;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            pv[k] = L.any_h(k) ? cvt4(ldraw(prow + (L.is_h[k] ? L.coff[k] : 0))) : f4zero();
-            // self-loop term Z[i] (v-role lanes), fetched with the header-dependent loads rather than after the edges
-            zs[k] = (L.any_v(k) && has_loop) ? cvt4(ldraw(zrow + L.coffc[k])) : f4zero();
-            acc[k] = f4zero();
-        }
-#pragma unroll
-        for (int k = 0; k < NCH; ++k)
-            if (L.any_h(k) && L.any_v(k)) pv[k] = sel4(L.is_h[k], pv[k]);
-        float m = -INFINITY, l = 0.f;
-        int my_col = ccol, my_typ = ctyp;
+
+    // ---- the edges [item.beg, item.end) of destination item.seg: online softmax over them into (m, l, acc) ----------
+    // my_col / my_typ: source and type of entry item.beg + lane (first batch of up to 64), supplied by the caller
+    auto edge_loop = [&](const jmac_item_t& item, int my_col, int my_typ, const float4 (&pv)[NCH], float& m, float& l,
+                         float4 (&acc)[NCH]) {
         for (int e0 = item.beg; e0 < item.end; e0 += 64) {
             const int nb = min(64, item.end - e0);
             if (e0 != item.beg) {
@@ -236,20 +221,159 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
             }
             if (u0 < nb) group(std::integral_constant<int, 1>{}, u0);
         }
-        if (item.pslot < 0) {
-            const int deg = item.end - item.beg;
-            const float scale = l > 0.f ? sqrtf((float)deg) / l : 0.f;
+    };
+    // ---- out[i] = out_scale * ( sqrt(deg) / l * acc  +  Z[i] - Rz[loop] ),  softmax statistics for the backward ---------
+    auto finish = [&](int i, int deg, float m, float l, const float4 (&acc)[NCH], const float4 (&zs)[NCH]) {
+        const float scale = l > 0.f ? sqrtf((float)deg) / l : 0.f;
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                if (L.any_v(k) && L.is_v(k)) {
-                    const float4 o = add4(mul4(acc[k], scale), sub4(zs[k], rl[k]));   // + Z[i] - Rz[loop]
-                    st4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff), mul4(o, a.out_scale));
+        for (int k = 0; k < NCH; ++k) {
+            if (L.any_v(k) && L.is_v(k)) {
+                const float4 o = add4(mul4(acc[k], scale), sub4(zs[k], rl[k]));   // + Z[i] - Rz[loop]
+                st4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff), mul4(o, a.out_scale));
+            }
+        }
+        if (lane == 0) {
+            a.seg_max[i] = m;
+            a.seg_den[i] = l;
+        }
+    };
+    auto first_batch = [&](const jmac_item_t& item, int& c, int& t) {
+        const int cnb = min(64, item.end - item.beg);
+        const int idx = cnb > 0 ? item.beg + min(lane, cnb - 1) : 0;
+        c = a.col[idx];
+        t = a.etype[idx];
+    };
+
+    // ---- 1. cooperative segments: one workgroup per segment -----------------------------------------------------------
+    for (int cb = blockIdx.x; cb < n_coop; cb += gridDim.x) {
+        const jmac_item_t item = a.items[cb * kWavesPerBlock + wave];
+        const int i = item.seg;
+        int ccol, ctyp;
+        first_batch(item, ccol, ctyp);
+        float4 pv[NCH], acc[NCH], zs[NCH];
+        const TT* prow = tP + (int64_t)i * a.ldp;
+        const TT* zrow = tQZ + ((int64_t)i + a.self_off) * a.ldqz;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            pv[k] = L.any_h(k) ? cvt4(ldraw(prow + (L.is_h[k] ? L.coff[k] : 0))) : f4zero();
+            zs[k] = (L.any_v(k) && has_loop && wave == 0) ? cvt4(ldraw(zrow + L.coffc[k])) : f4zero();
+            acc[k] = f4zero();
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+            if (L.any_h(k) && L.any_v(k)) pv[k] = sel4(L.is_h[k], pv[k]);
+        float m = -INFINITY, l = 0.f;
+        edge_loop(item, ccol, ctyp, pv, m, l, acc);
+        if (wave != 0) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if (L.any_v(k)) coop_acc[wave][k][lane] = acc[k];
+            if (lane == 0) {
+                coop_ml[wave][0] = m;
+                coop_ml[wave][1] = l;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // merge in wave order (fixed summation order): M = max m_w, state_w scaled by e^(m_w - M)
+            float M = m;
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) M = fmaxf(M, coop_ml[w][0]);
+            float f = fast_exp(m - M);               // a wave without entries: m = -inf, l = 0 -> factor 0
+            float lsum = l * f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) acc[k] = mul4(acc[k], f);
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) {
+                f = fast_exp(coop_ml[w][0] - M);
+                lsum = fmaf(coop_ml[w][1], f, lsum);
+#pragma unroll
+                for (int k = 0; k < NCH; ++k)
+                    if (L.any_v(k)) acc[k] = fma4(coop_acc[w][k][lane], f, acc[k]);
+            }
+            finish(i, a.rowptr[i + 1] - a.rowptr[i], M, lsum, acc, zs);
+        }
+        __syncthreads();
+    }
+
+    // ---- 3. (defined here, used below) empty segments, kEmptyPack to a wave: out = out_scale * (Z[i] - Rz[loop]) -------
+    auto empties = [&](int p0) {
+        const int n_packs = (n_empty + kEmptyPack - 1) / kEmptyPack;
+        for (int p = p0; p < n_packs; p += nwaves) {
+            int seg[kEmptyPack];
+            float4 zs[kEmptyPack][NCH];
+#pragma unroll
+            for (int u = 0; u < kEmptyPack; ++u) seg[u] = a.items[min(n_reg + p * kEmptyPack + u, n_items - 1)].seg;
+#pragma unroll
+            for (int u = 0; u < kEmptyPack; ++u) {
+                const TT* zrow = tQZ + ((int64_t)seg[u] + a.self_off) * a.ldqz;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k)
+                    zs[u][k] = (L.any_v(k) && has_loop) ? cvt4(ldraw(zrow + L.coffc[k])) : f4zero();
+            }
+#pragma unroll
+            for (int u = 0; u < kEmptyPack; ++u) {
+                if (p * kEmptyPack + u >= n_empty) break;
+                const int i = seg[u];
+#pragma unroll
+                for (int k = 0; k < NCH; ++k)
+                    if (L.any_v(k) && L.is_v(k))
+                        st4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff), mul4(sub4(zs[u][k], rl[k]), a.out_scale));
+                if (lane == 0) {
+                    a.seg_max[i] = -INFINITY;
+                    a.seg_den[i] = 0.f;
                 }
             }
-            if (lane == 0) {
-                a.seg_max[i] = m;
-                a.seg_den[i] = l;
-            }
+        }
+    };
+
+    // ---- 2. items ---------------------------------------------------------------------------------------------------------
+    const int it_base = n_coop * kWavesPerBlock;           // the cooperative items occupy the head of the item list
+    int it = it_base + it0;
+    jmac_item_t item = a.items[min(it, a.n_items_max - 1)];     // clamped: does not wait for the device-side counts
+    // the first two entries of the item arrive WITH its header (item_edges): a short item starts its row gathers one
+    // dependent round trip earlier
+    int4 e4 = make_int4(0, 0, 0, 0);
+    if (a.item_edges) e4 = a.item_edges[min(it, a.n_items_max - 1)];
+    if (it >= n_reg) {                                     // this wave owns no item with entries
+        empties(it - n_reg);
+        return;
+    }
+    jmac_item_t nitem = a.items[min(it + nwaves, n_items - 1)];
+    int ccol, ctyp;
+    {
+        const int cnb = min(64, item.end - item.beg);
+        if (a.item_edges && cnb <= 2) {
+            ccol = lane == 0 ? e4.x : e4.z;
+            ctyp = lane == 0 ? e4.y : e4.w;
+            ccol = cnb > lane ? ccol : e4.x;             // lanes past the item re-use entry 0 (clamped, like the loads)
+            ctyp = cnb > lane ? ctyp : e4.y;
+        } else {
+            first_batch(item, ccol, ctyp);
+        }
+    }
+    for (;;) {
+        const jmac_item_t nnitem = a.items[min(it + 2 * nwaves, n_items - 1)];
+        int ncol, ntyp;
+        first_batch(nitem, ncol, ntyp);
+        const int i = item.seg;
+        float4 pv[NCH], acc[NCH], zs[NCH];
+        const TT* prow = tP + (int64_t)i * a.ldp;
+        const TT* zrow = tQZ + ((int64_t)i + a.self_off) * a.ldqz;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            pv[k] = L.any_h(k) ? cvt4(ldraw(prow + (L.is_h[k] ? L.coff[k] : 0))) : f4zero();
+            // self-loop term Z[i] (v-role lanes), fetched with the header-dependent loads rather than after the edges
+            zs[k] = (L.any_v(k) && has_loop) ? cvt4(ldraw(zrow + L.coffc[k])) : f4zero();
+            acc[k] = f4zero();
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+            if (L.any_h(k) && L.any_v(k)) pv[k] = sel4(L.is_h[k], pv[k]);
+        float m = -INFINITY, l = 0.f;
+        edge_loop(item, ccol, ctyp, pv, m, l, acc);
+        if (item.pslot < 0) {
+            finish(i, item.end - item.beg, m, l, acc, zs);
         } else {
 #pragma unroll
             for (int k = 0; k < NCH; ++k)
@@ -260,12 +384,13 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
             }
         }
         it += nwaves;
-        if (it >= n_items) break;
+        if (it >= n_reg) break;
         item = nitem;
         nitem = nnitem;
         ccol = ncol;
         ctyp = ntyp;
     }
+    empties(it - n_reg);                    // persistent grids: the waves share the empty segments after their items
 }
 
 // merges the partial (max, denominator, accumulator) triples of destinations that were split: one BLOCK per split
@@ -277,10 +402,11 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_combine_kernel(FwdArgs a)
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n_splits = a.counts[1];
+    const int n_coop = a.counts[4];          // cooperative segments (head of the splits array) were merged in LDS already
     Lanes<NCH, 0> L;
     L.init(lane, a.D4);
     const int voff = 4 * a.D4;
-    for (int sp = blockIdx.x; sp < n_splits; sp += gridDim.x) {
+    for (int sp = n_coop + blockIdx.x; sp < n_splits; sp += gridDim.x) {
         const jmac_split_t s = a.splits[sp];
         const int i = s.seg;
         float M = -INFINITY;
@@ -801,24 +927,28 @@ void launch_reduce_rows(const float* partial, int nparts, int W, float scale, fl
 
 template <typename TT>
 static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t ldqz, const TT* RR, int64_t ldrr, const float* a_att,
-                               const int32_t* rowptr, const int32_t* col, const int32_t* etype, const jmac_item_t* items,
-                               const jmac_split_t* splits, const int32_t* counts, int64_t n_items_max, int64_t n_splits_max,
-                               int64_t n_parts_max, int64_t N, int64_t d, float slope, int32_t loop_rel, int64_t self_off, float out_scale,
-                               float* out, int64_t ldo, float* seg_max, float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
-    if (N < 0 || n_items_max < 0 || n_splits_max < 0) return JMAC_EINVAL;
+                               const int32_t* col, const int32_t* etype, const jmac_view_t* v, int64_t N, int64_t d, float slope,
+                               int32_t loop_rel, int64_t self_off, float out_scale, float* out, int64_t ldo, float* seg_max,
+                               float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    if (N < 0 || !v || v->n_items_max < 0 || v->n_splits_max < 0) return JMAC_EINVAL;
     if (N == 0) return JMAC_OK;
-    if (!P || !QZ || !RR || !a_att || !rowptr || !items || !counts || !out || !seg_max || !seg_den) return JMAC_EINVAL;
+    if (!P || !QZ || !RR || !a_att || !v->ptr || !v->items || !v->counts || !out || !seg_max || !seg_den) return JMAC_EINVAL;
     if (int rc = check_dims(d, ldp, ldqz, ldrr)) return rc;
     if (ldo % 4) return JMAC_EDIM;
     if (N >= INT32_MAX) return JMAC_ERANGE;
+    const int64_t n_items_max = v->n_items_max, n_splits_max = v->n_splits_max;
+    int64_t n_parts_max = v->n_parts_max, n_empty = v->n_empty, n_coop = v->n_coop;
+    if (n_empty < 0 || n_coop < 0 || n_coop * kWavesPerBlock + n_empty > n_items_max || n_coop > n_splits_max) return JMAC_EINVAL;
     FwdArgs a;
     a.P = P; a.QZ = QZ; a.RR = RR; a.a_att = a_att;
     a.ldp = ldp; a.ldqz = ldqz; a.ldrr = ldrr; a.ldo = ldo;
-    a.rowptr = rowptr; a.col = col; a.etype = etype;
-    a.items = items; a.splits = splits; a.counts = counts;
+    a.rowptr = v->ptr; a.col = col; a.etype = etype;
+    a.items = v->items; a.splits = v->splits; a.counts = v->counts;
+    a.item_edges = reinterpret_cast<const int4*>(v->item_edges);
     if (loop_rel >= 0 && self_off < 0) return JMAC_EINVAL;
     a.N = (int32_t)N; a.D4 = (int32_t)(d / 4); a.loop_rel = loop_rel; a.self_off = loop_rel >= 0 ? self_off : 0;
     a.n_items_max = (int32_t)(n_items_max > 0 ? n_items_max : 1);
+    a.n_coop = (int32_t)n_coop;
     a.slope = slope; a.out_scale = out_scale;
     a.out = out; a.seg_max = seg_max; a.seg_den = seg_den;
     // ws layout: [part_ml: 2 floats per slot][part_acc: d floats per slot]
@@ -828,9 +958,19 @@ static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t l
     a.part_acc = ws ? (float*)((char*)ws + align_up((size_t)n_parts_max * 8)) : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const int nch = (int)((2 * (d / 4) + 63) / 64);
-    const unsigned grid = fwd_grid(n_items_max);
+    // work units: cooperative segments (a block each) + items (a wave each) + packs of kEmptyPack empty segments
+    // (a wave each).  One-wave-per-unit grids cover max(blocks for the cooperative segments, blocks for the rest):
+    // block b first does cooperative segment b, then its items.
+    const int64_t n_wave_units = n_items_max - n_coop * kWavesPerBlock - n_empty + (n_empty + kEmptyPack - 1) / kEmptyPack;
+    int64_t need = (n_wave_units + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (need < n_coop) need = n_coop;
+    if (need < 1) need = 1;
+    static const int grid_env = env_int("JMAC_GRID", 0);               // tuning knob (debug)
+    unsigned grid;
+    if (grid_env > 0) grid = (unsigned)(need < grid_env ? need : grid_env);
+    else grid = (unsigned)(need <= 2 * kPersistBlocks ? need : kPersistBlocks);
     // small graphs (one wave per item) are bound by round trips, not by gathers in flight: the 2-edge group
-    // has fewer VGPRs, i.e. one more wave per SIMD (DBP-5L ja: 20.4 us against 22.6 us)
+    // is the faster form there (DBP-5L ja: 20.4 us against 22.6 us)
     static const int fwd_u_env = env_int("JMAC_FWD_U", 0);         // tuning knob (debug)
     const int fwd_u = fwd_u_env ? fwd_u_env : (n_items_max <= 8 * kPersistBlocks ? 2 : 4);
     const bool slope01 = slope >= 0.f && slope <= 1.f;
@@ -839,8 +979,8 @@ static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t l
     } else {
         JMAC_DISPATCH_D(a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 4, D4T, TT>), dim3(grid), dim3(kBlock), 0, st, a));
     }
-    if (n_splits_max > 0) {
-        const unsigned g2 = split_grid(n_splits_max);
+    if (n_splits_max - n_coop > 0) {
+        const unsigned g2 = split_grid(n_splits_max - n_coop);
         JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_fwd_combine_kernel<NCH, TT>), dim3(g2), dim3(kBlock), 0, st, a));
     }
     return (int)hipGetLastError();
@@ -854,25 +994,21 @@ size_t jmac_rel_attn_fwd_workspace_bytes(int64_t n_parts_max, int64_t d) {
 }
 
 int jmac_rel_attn_aggregate_fwd_f32(const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR,
-                                    int64_t ldrr, const float* a_att, const int32_t* rowptr, const int32_t* col,
-                                    const int32_t* etype, const jmac_item_t* items, const jmac_split_t* splits,
-                                    const int32_t* counts, int64_t n_items_max, int64_t n_splits_max,
-                                    int64_t n_parts_max, int64_t N, int64_t d, float slope, int32_t loop_rel, int64_t self_off, float out_scale, float* out, int64_t ldo,
-                                    float* seg_max, float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
-    return launch_rel_attn_fwd<float>(P, ldp, QZ, ldqz, RR, ldrr, a_att, rowptr, col, etype, items, splits, counts, n_items_max,
-                                      n_splits_max, n_parts_max, N, d, slope, loop_rel, self_off, out_scale, out, ldo, seg_max, seg_den, ws,
-                                      ws_bytes, stream);
+                                    int64_t ldrr, const float* a_att, const int32_t* col, const int32_t* etype,
+                                    const jmac_view_t* by_dst, int64_t N, int64_t d, float slope, int32_t loop_rel,
+                                    int64_t self_off, float out_scale, float* out, int64_t ldo, float* seg_max, float* seg_den,
+                                    void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    return launch_rel_attn_fwd<float>(P, ldp, QZ, ldqz, RR, ldrr, a_att, col, etype, by_dst, N, d, slope, loop_rel, self_off,
+                                      out_scale, out, ldo, seg_max, seg_den, ws, ws_bytes, stream);
 }
 
 int jmac_rel_attn_aggregate_fwd_bf16(const uint16_t* P, int64_t ldp, const uint16_t* QZ, int64_t ldqz, const uint16_t* RR,
-                                     int64_t ldrr, const float* a_att, const int32_t* rowptr, const int32_t* col,
-                                     const int32_t* etype, const jmac_item_t* items, const jmac_split_t* splits,
-                                     const int32_t* counts, int64_t n_items_max, int64_t n_splits_max,
-                                     int64_t n_parts_max, int64_t N, int64_t d, float slope, int32_t loop_rel, int64_t self_off, float out_scale, float* out, int64_t ldo,
-                                     float* seg_max, float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
-    return launch_rel_attn_fwd<bf16_t>(P, ldp, QZ, ldqz, RR, ldrr, a_att, rowptr, col, etype, items, splits, counts, n_items_max,
-                                       n_splits_max, n_parts_max, N, d, slope, loop_rel, self_off, out_scale, out, ldo, seg_max, seg_den, ws,
-                                       ws_bytes, stream);
+                                     int64_t ldrr, const float* a_att, const int32_t* col, const int32_t* etype,
+                                     const jmac_view_t* by_dst, int64_t N, int64_t d, float slope, int32_t loop_rel,
+                                     int64_t self_off, float out_scale, float* out, int64_t ldo, float* seg_max, float* seg_den,
+                                     void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    return launch_rel_attn_fwd<bf16_t>(P, ldp, QZ, ldqz, RR, ldrr, a_att, col, etype, by_dst, N, d, slope, loop_rel, self_off,
+                                       out_scale, out, ldo, seg_max, seg_den, ws, ws_bytes, stream);
 }
 
 // ---- backward workspace carving (shared by the size query and the launcher) ----

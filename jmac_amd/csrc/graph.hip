@@ -69,58 +69,116 @@ __global__ void csr_gather_kernel(const int64_t* __restrict__ edge_index, const 
     }
 }
 
-// per segment: number of items, number of partial slots, split flag
-__global__ void seg_counts_kernel(const int32_t* __restrict__ ptr, int64_t S, int32_t chunk,
-                                  int32_t* __restrict__ nitem, int32_t* __restrict__ npart,
+// Segment classes of a schedule:
+//   empty   no entries
+//   plain   1 .. chunk entries, one item, finalised by its wave
+//   coop    coop_min < len <= coop_max (small graphs only; coop_max = 0 disables): exactly kCoop = 4 items of
+//           ceil(len / 4) entries, the four waves of ONE workgroup; the forward kernel merges their partial softmax
+//           states through LDS (no combine launch)
+//   split   len > chunk: ceil(len / chunk) items of <= chunk entries, merged by the combine pass
+// Item order:  [coop: 4 per segment][split items][plain segments, in segment order][empty segments, in order].
+// coop first: block b of a one-wave-per-item launch owns coop segment b (its four item slots are block aligned), and
+// the longest rows of the graph start first.  Split items next (longest-first balancing under the round-robin
+// item->wave map).  Empty segments (DBP-5L train graphs: 54 % of the destinations) last: the forward kernel hands
+// several of them to one wave -- they need no gather, only the self term.
+constexpr int kCoop = 4;
+
+__device__ __forceinline__ int seg_class(int32_t len, int32_t chunk, int32_t coop_min, int32_t coop_max) {
+    if (len == 0) return 0;                                        // empty
+    if (coop_max > 0 && len > coop_min && len <= coop_max) return 2;   // coop
+    return len <= chunk ? 1 : 3;                                   // plain : split
+}
+
+__global__ void seg_counts_kernel(const int32_t* __restrict__ ptr, int64_t S, int32_t chunk, int32_t coop_min, int32_t coop_max,
+                                  int32_t* __restrict__ nempty, int32_t* __restrict__ ncoop, int32_t* __restrict__ npart,
                                   int32_t* __restrict__ nsplit) {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s < S) {
-        int32_t len = ptr[s + 1] - ptr[s];
-        int32_t nch = len <= chunk ? 1 : (len + chunk - 1) / chunk;
-        nitem[s] = nch;
-        npart[s] = nch > 1 ? nch : 0;
-        nsplit[s] = nch > 1 ? 1 : 0;
+        const int32_t len = ptr[s + 1] - ptr[s];
+        const int c = seg_class(len, chunk, coop_min, coop_max);
+        nempty[s] = c == 0;
+        ncoop[s] = c == 2;
+        npart[s] = c == 3 ? (len + chunk - 1) / chunk : 0;          // partial slots of the (non-coop) split segments
+        nsplit[s] = c == 3;
     }
 }
 
-// Items of split segments (the long ones, up to `chunk` entries each) come FIRST in the schedule, the
-// unsplit segments follow in segment order: with the kernels' round-robin item->wave map every wave then
-// starts with its share of the long items and short segments fill in behind them (longest-first balancing).
-__global__ void items_fill_kernel(const int32_t* __restrict__ ptr, int64_t S, int32_t chunk,
+__global__ void items_fill_kernel(const int32_t* __restrict__ ptr, int64_t S, int32_t chunk, int32_t coop_min, int32_t coop_max,
+                                  const int32_t* __restrict__ empty_off, const int32_t* __restrict__ coop_off,
                                   const int32_t* __restrict__ part_off, const int32_t* __restrict__ split_off,
                                   jmac_item_t* __restrict__ items, jmac_split_t* __restrict__ splits,
                                   int32_t* __restrict__ counts) {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
-    // totals from the last segment (every thread reads the same three words)
+    // totals from the last segment (every thread reads the same words)
     const int32_t last_len = ptr[S] - ptr[S - 1];
-    const int32_t last_nch = last_len <= chunk ? 1 : (last_len + chunk - 1) / chunk;
-    const int32_t n_parts = part_off[S - 1] + (last_nch > 1 ? last_nch : 0);
-    const int32_t n_splits = split_off[S - 1] + (last_nch > 1 ? 1 : 0);
-    int32_t beg = ptr[s], end = ptr[s + 1];
-    int32_t len = end - beg;
-    int32_t nch = len <= chunk ? 1 : (len + chunk - 1) / chunk;
-    if (nch == 1) {
-        items[n_parts + (int32_t)s - split_off[s]] = jmac_item_t{(int32_t)s, beg, end, -1};
-    } else {
-        int32_t po = part_off[s];
-        for (int32_t c = 0; c < nch; ++c) {
-            int32_t b = beg + c * chunk;
-            int32_t e = b + chunk < end ? b + chunk : end;
-            items[po + c] = jmac_item_t{(int32_t)s, b, e, po + c};
+    const int lc = seg_class(last_len, chunk, coop_min, coop_max);
+    const int32_t n_empty = empty_off[S - 1] + (lc == 0);
+    const int32_t n_coop = coop_off[S - 1] + (lc == 2);
+    const int32_t n_parts_nc = part_off[S - 1] + (lc == 3 ? (last_len + chunk - 1) / chunk : 0);
+    const int32_t n_splits_nc = split_off[S - 1] + (lc == 3);
+    const int32_t n_parts = kCoop * n_coop + n_parts_nc;
+    const int32_t n_plain = (int32_t)S - n_coop - n_splits_nc - n_empty;
+    const int32_t beg = ptr[s], end = ptr[s + 1];
+    const int32_t len = end - beg;
+    const int c = seg_class(len, chunk, coop_min, coop_max);
+    if (c == 0) {
+        items[n_parts + n_plain + empty_off[s]] = jmac_item_t{(int32_t)s, beg, end, -1};
+    } else if (c == 1) {
+        items[n_parts + (int32_t)s - coop_off[s] - split_off[s] - empty_off[s]] = jmac_item_t{(int32_t)s, beg, end, -1};
+    } else if (c == 2) {
+        const int32_t po = kCoop * coop_off[s];
+        const int32_t q = (len + kCoop - 1) / kCoop;
+        for (int32_t w = 0; w < kCoop; ++w) {
+            const int32_t b = beg + w * q < end ? beg + w * q : end;
+            const int32_t e = b + q < end ? b + q : end;
+            items[po + w] = jmac_item_t{(int32_t)s, b, e, po + w};
         }
-        splits[split_off[s]] = jmac_split_t{(int32_t)s, po, nch, 0};
+        splits[coop_off[s]] = jmac_split_t{(int32_t)s, po, kCoop, 1};
+    } else {
+        const int32_t nch = (len + chunk - 1) / chunk;
+        const int32_t po = kCoop * n_coop + part_off[s];
+        for (int32_t k = 0; k < nch; ++k) {
+            const int32_t b = beg + k * chunk;
+            const int32_t e = b + chunk < end ? b + chunk : end;
+            items[po + k] = jmac_item_t{(int32_t)s, b, e, po + k};
+        }
+        splits[n_coop + split_off[s]] = jmac_split_t{(int32_t)s, po, nch, 0};
     }
     if (s == S - 1) {
-        counts[0] = n_parts + (int32_t)S - n_splits;
-        counts[1] = n_splits;
+        counts[0] = n_parts + n_plain + n_empty;
+        counts[1] = n_coop + n_splits_nc;
         counts[2] = n_parts;
-        counts[3] = 0;
+        counts[3] = n_empty;
+        counts[4] = n_coop;
+        counts[5] = counts[6] = counts[7] = 0;
+    }
+}
+
+// edges[it] = {col[beg], etype[beg], col[beg+1], etype[beg+1]} of item it (-1 where the item has fewer entries): the first
+// two entries of an item inline with its header, so that a wave that owns ONE short item (small graphs: one wave per item)
+// starts its row gathers one dependent memory round trip earlier (header -> gathers instead of header -> col/type -> gathers)
+__global__ void item_edges_kernel(const jmac_item_t* __restrict__ items, const int32_t* __restrict__ counts,
+                                  const int32_t* __restrict__ col, const int32_t* __restrict__ etype,
+                                  int4* __restrict__ edges) {
+    const int n_items = counts[0];
+    for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < n_items; it += gridDim.x * blockDim.x) {
+        const jmac_item_t x = items[it];
+        int4 e = make_int4(-1, -1, -1, -1);
+        if (x.end > x.beg) {
+            e.x = col[x.beg];
+            e.y = etype[x.beg];
+        }
+        if (x.end > x.beg + 1) {
+            e.z = col[x.beg + 1];
+            e.w = etype[x.beg + 1];
+        }
+        edges[it] = e;
     }
 }
 
 __global__ void zero_counts_kernel(int32_t* counts) {
-    if (threadIdx.x < 4) counts[threadIdx.x] = 0;
+    if (threadIdx.x < 8) counts[threadIdx.x] = 0;
 }
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -163,7 +221,7 @@ size_t jmac_graph_workspace_bytes(int64_t E, int64_t S) {
     if (E < 0) E = 0;
     if (S < 0) S = 0;
     size_t a = 3 * align_up((size_t)E * 4) + sort_temp_bytes(E);
-    size_t b = 6 * align_up((size_t)(S + 1) * 4) + scan_temp_bytes(S + 1);
+    size_t b = 8 * align_up((size_t)(S + 1) * 4) + scan_temp_bytes(S + 1);   // 4 flag arrays + 4 scans
     return (a > b ? a : b) + 1024;
 }
 
@@ -232,50 +290,67 @@ int jmac_group_build(const int32_t* keys, int64_t E, int64_t S, int32_t* ptr, in
     return (int)hipGetLastError();
 }
 
-int64_t jmac_items_max(int64_t S, int64_t E, int32_t chunk) {
+// coop_min > 0: cooperative splits are enabled for segments longer than coop_min (each adds kCoop - 1 items, one split
+// entry and kCoop partial slots; there are at most E / (coop_min + 1) of them)
+int64_t jmac_items_max(int64_t S, int64_t E, int32_t chunk, int32_t coop_min) {
     if (chunk < 1) chunk = 1;
-    return S + E / chunk + 1;
+    return S + E / chunk + 1 + (coop_min > 0 ? (kCoop - 1) * (E / (coop_min + 1)) : 0);
 }
-int64_t jmac_splits_max(int64_t E, int32_t chunk) {
+int64_t jmac_splits_max(int64_t E, int32_t chunk, int32_t coop_min) {
     if (chunk < 1) chunk = 1;
-    return E / chunk + 1;
+    return E / chunk + 1 + (coop_min > 0 ? E / (coop_min + 1) : 0);
 }
-int64_t jmac_parts_max(int64_t E, int32_t chunk) {
+int64_t jmac_parts_max(int64_t E, int32_t chunk, int32_t coop_min) {
     if (chunk < 1) chunk = 1;
-    return 2 * (E / chunk) + 2;
+    return 2 * (E / chunk) + 2 + (coop_min > 0 ? kCoop * (E / (coop_min + 1)) : 0);
 }
 
-int jmac_items_build(const int32_t* ptr, int64_t S, int32_t chunk, jmac_item_t* items, jmac_split_t* splits,
-                     int32_t* counts, void* ws, size_t ws_bytes, jmac_stream_t stream) {
-    if (S < 0 || chunk < 1 || !counts || (S > 0 && (!ptr || !items || !splits))) return JMAC_EINVAL;
+int jmac_items_build(const int32_t* ptr, int64_t S, int32_t chunk, int32_t coop_min, int32_t coop_max, jmac_item_t* items,
+                     jmac_split_t* splits, int32_t* counts, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    if (S < 0 || chunk < 1 || coop_min < 0 || coop_max < 0 || !counts || (S > 0 && (!ptr || !items || !splits))) return JMAC_EINVAL;
+    if (coop_max > 0 && (coop_min < 1 || coop_max <= coop_min)) return JMAC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (S == 0) {
         hipLaunchKernelGGL(zero_counts_kernel, dim3(1), dim3(64), 0, st, counts);
         return (int)hipGetLastError();
     }
     size_t arr = align_up((size_t)S * 4);
-    if (!ws || ws_bytes < 6 * arr) return JMAC_EWORKSPACE;
+    if (!ws || ws_bytes < 8 * arr) return JMAC_EWORKSPACE;
     char* w = (char*)ws;
-    int32_t* nitem = (int32_t*)w;
-    int32_t* npart = (int32_t*)(w + arr);
-    int32_t* nsplit = (int32_t*)(w + 2 * arr);
-    int32_t* item_off = (int32_t*)(w + 3 * arr);
-    int32_t* part_off = (int32_t*)(w + 4 * arr);
-    int32_t* split_off = (int32_t*)(w + 5 * arr);
-    void* tmp = w + 6 * arr;
-    size_t tmp_bytes = ws_bytes - 6 * arr;
+    int32_t* flag[4];
+    int32_t* off[4];
+    for (int i = 0; i < 4; ++i) {
+        flag[i] = (int32_t*)(w + i * arr);           // empty, coop, parts (non-coop), split (non-coop)
+        off[i] = (int32_t*)(w + (4 + i) * arr);
+    }
+    void* tmp = w + 8 * arr;
+    size_t tmp_bytes = ws_bytes - 8 * arr;
     const int T = 256;
     unsigned nb = (unsigned)((S + T - 1) / T);
-    hipLaunchKernelGGL(seg_counts_kernel, dim3(nb), dim3(T), 0, st, ptr, S, chunk, nitem, npart, nsplit);
+    hipLaunchKernelGGL(seg_counts_kernel, dim3(nb), dim3(T), 0, st, ptr, S, chunk, coop_min, coop_max, flag[0], flag[1], flag[2],
+                       flag[3]);
     size_t need = 0;
-    hipError_t e = rocprim::exclusive_scan(nullptr, need, nitem, item_off, 0, (size_t)S, rocprim::plus<int32_t>(), st);
+    hipError_t e = rocprim::exclusive_scan(nullptr, need, flag[0], off[0], 0, (size_t)S, rocprim::plus<int32_t>(), st);
     if (e != hipSuccess) return (int)e;
     if (need > tmp_bytes) return JMAC_EWORKSPACE;
-    e = rocprim::exclusive_scan(tmp, need, npart, part_off, 0, (size_t)S, rocprim::plus<int32_t>(), st);
-    if (e != hipSuccess) return (int)e;
-    e = rocprim::exclusive_scan(tmp, need, nsplit, split_off, 0, (size_t)S, rocprim::plus<int32_t>(), st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(items_fill_kernel, dim3(nb), dim3(T), 0, st, ptr, S, chunk, part_off, split_off, items, splits, counts);
+    for (int i = 0; i < 4; ++i) {
+        e = rocprim::exclusive_scan(tmp, need, flag[i], off[i], 0, (size_t)S, rocprim::plus<int32_t>(), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(items_fill_kernel, dim3(nb), dim3(T), 0, st, ptr, S, chunk, coop_min, coop_max, off[0], off[1], off[2], off[3],
+                       items, splits, counts);
+    return (int)hipGetLastError();
+}
+
+int jmac_item_edges_build(const jmac_item_t* items, const int32_t* counts, int64_t n_items_max, const int32_t* col,
+                          const int32_t* etype, int32_t* item_edges, jmac_stream_t stream) {
+    if (n_items_max < 0 || !counts || (n_items_max > 0 && (!items || !col || !etype || !item_edges))) return JMAC_EINVAL;
+    if (n_items_max == 0) return JMAC_OK;
+    const int T = 256;
+    int64_t nb = (n_items_max + T - 1) / T;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(item_edges_kernel, dim3((unsigned)nb), dim3(T), 0, (hipStream_t)stream, items, counts, col, etype,
+                       reinterpret_cast<int4*>(item_edges));
     return (int)hipGetLastError();
 }
 

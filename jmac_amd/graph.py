@@ -17,6 +17,9 @@ from . import _lib
 from ._lib import View, check, check_index_range, lib, ptr, require_device, stream
 
 DEFAULT_CHUNK = None          # None -> auto_chunk()
+# schedules of up to this many items carry the first two entries of each item inline (the forward kernel gives every
+# item its own wave there -- aggregate.hip fwd_grid -- and is bound by dependent round trips, not by bandwidth)
+INLINE_EDGES_MAX_ITEMS = 16384
 
 
 def auto_chunk(n_entries: int) -> int:
@@ -30,33 +33,56 @@ def auto_chunk(n_entries: int) -> int:
     return int(min(512, max(32, p)))
 
 
+# cooperative splits (forward kernel, small graphs): rows longer than COOP_MIN and up to COOP_MAX entries are processed by
+# the four waves of one workgroup and merged in LDS.  Measured on the DBP-5L ja shape: the kernel's duration was set by
+# its longest row (28 entries = 14 dependent gather rounds in one wave); capping the rows at 8 entries took 19.4 -> 15.8 us.
+COOP_MIN, COOP_MAX = 8, 256
+
+
 class _Schedule:
     """items / splits / counts for one grouping of the CSR slots (jmac_items_build)."""
 
-    def __init__(self, seg_ptr: torch.Tensor, n_seg: int, n_entries: int, chunk: int, order: Optional[torch.Tensor]):
+    def __init__(self, seg_ptr: torch.Tensor, n_seg: int, n_entries: int, chunk: int, order: Optional[torch.Tensor],
+                 coop: bool = False):
         L = lib()
         dev = seg_ptr.device
         self.ptr = seg_ptr
         self.order = order
-        self.n_items_max = int(L.jmac_items_max(n_seg, n_entries, chunk))
-        self.n_splits_max = int(L.jmac_splits_max(n_entries, chunk))
-        self.n_parts_max = int(L.jmac_parts_max(n_entries, chunk))
+        cmin, cmax = (COOP_MIN, COOP_MAX) if coop else (0, 0)
+        self.n_items_max = int(L.jmac_items_max(n_seg, n_entries, chunk, cmin))
+        self.n_splits_max = int(L.jmac_splits_max(n_entries, chunk, cmin))
+        self.n_parts_max = int(L.jmac_parts_max(n_entries, chunk, cmin))
         self.items = torch.empty((self.n_items_max, 4), dtype=torch.int32, device=dev)
         self.splits = torch.empty((self.n_splits_max, 4), dtype=torch.int32, device=dev)
-        self.counts = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.counts = torch.zeros(8, dtype=torch.int32, device=dev)
         ws_bytes = int(L.jmac_graph_workspace_bytes(n_entries, n_seg))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        check(L.jmac_items_build(ptr(seg_ptr), n_seg, chunk, ptr(self.items), ptr(self.splits), ptr(self.counts),
+        check(L.jmac_items_build(ptr(seg_ptr), n_seg, chunk, cmin, cmax, ptr(self.items), ptr(self.splits), ptr(self.counts),
                                  ptr(ws), ws_bytes, stream()), "jmac_items_build")
         # one host read at build time (never on the hot path): exact launch bounds, and the combine
         # kernels are skipped altogether when no segment was split
-        n_items, n_splits, n_parts, _ = self.counts.tolist()
+        n_items, n_splits, n_parts, n_empty, n_coop = self.counts.tolist()[:5]
         self.n_items_max, self.n_splits_max, self.n_parts_max = int(n_items), int(n_splits), int(n_parts)
-        self._view = View(ptr(self.ptr), ptr(self.order), ptr(self.items), ptr(self.splits), ptr(self.counts),
-                          self.n_items_max, self.n_splits_max, self.n_parts_max)
+        self.n_empty = int(n_empty)            # empty segments = the last n_empty items of the schedule
+        self.n_coop = int(n_coop)              # cooperative segments = the first 4 * n_coop items / first n_coop splits
+        self.item_edges = None
+        self._view = None
 
     def view(self) -> View:
+        if self._view is None:
+            self._view = View(ptr(self.ptr), ptr(self.order), ptr(self.items), ptr(self.splits), ptr(self.counts),
+                              self.n_items_max, self.n_splits_max, self.n_parts_max, ptr(self.item_edges), self.n_empty,
+                              self.n_coop)
         return self._view
+
+    def build_item_edges(self, col: torch.Tensor, etype: torch.Tensor) -> None:
+        """{col, type} of the first two entries of every item, inline with the schedule (forward kernel on small
+        graphs: one dependent round trip fewer per wave)."""
+        if self.item_edges is None and self.n_items_max > 0:
+            self.item_edges = torch.empty((self.n_items_max, 4), dtype=torch.int32, device=col.device)
+            check(lib().jmac_item_edges_build(ptr(self.items), ptr(self.counts), self.n_items_max, ptr(col), ptr(etype),
+                                              ptr(self.item_edges), stream()), "jmac_item_edges_build")
+            self._view = None
 
 
 class RelGraph:
@@ -98,7 +124,11 @@ class RelGraph:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         check(L.jmac_csr_build(ptr(ei), ptr(et), E, N, ptr(self.rowptr), ptr(self.col), ptr(self.etype), ptr(self.perm),
                                ptr(ws), ws_bytes, stream()), "jmac_csr_build")
-        self.by_dst = _Schedule(self.rowptr, N, E, chunk, None)
+        # small graphs: one wave per item, long rows shared by a workgroup, first entries inline with the item headers
+        small = E > 0 and N + E // max(chunk, 1) + 1 <= INLINE_EDGES_MAX_ITEMS
+        self.by_dst = _Schedule(self.rowptr, N, E, chunk, None, coop=small)
+        if small:
+            self.by_dst.build_item_edges(self.col, self.etype)
         self._ei = ei
         self._bwd_ready = False
         self.dst_of_slot = None

@@ -74,8 +74,7 @@ class _RelAttnAggregate(torch.autograd.Function):
         fwd = L.jmac_rel_attn_aggregate_fwd_bf16 if bf16 else L.jmac_rel_attn_aggregate_fwd_f32
         check(fwd(
             ptr(PQZ), d3, PQZ.data_ptr() + d * esz, d3, ptr(RR), RR.shape[1], ptr(a),
-            ptr(graph.rowptr), ptr(graph.col), ptr(graph.etype), ptr(s.items), ptr(s.splits), ptr(s.counts),
-            s.n_items_max, s.n_splits_max, s.n_parts_max, N, d, float(slope), int(loop_rel), 0, float(out_scale),
+            ptr(graph.col), ptr(graph.etype), C.byref(s.view()), N, d, float(slope), int(loop_rel), 0, float(out_scale),
             ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(ws), ws_bytes, stream()),
             "jmac_rel_attn_aggregate_fwd_%s" % ("bf16" if bf16 else "f32"))
         if ev0 is not None:
@@ -155,8 +154,7 @@ class _RelAttnAggregateSplit(torch.autograd.Function):
         ev0 = _ev() if PROFILE is not None else None
         check(L.jmac_rel_attn_aggregate_fwd_f32(
             ptr(P), d, ptr(QZ), 2 * d, ptr(RR), RR.shape[1], ptr(a),
-            ptr(graph.rowptr), ptr(graph.col), ptr(graph.etype), ptr(s.items), ptr(s.splits), ptr(s.counts),
-            s.n_items_max, s.n_splits_max, s.n_parts_max, N, d, float(slope), int(loop_rel), int(self_off), float(out_scale),
+            ptr(graph.col), ptr(graph.etype), C.byref(s.view()), N, d, float(slope), int(loop_rel), int(self_off), float(out_scale),
             ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(ws), ws_bytes, stream()), "jmac_rel_attn_aggregate_fwd_f32")
         if ev0 is not None:
             PROFILE.append(("rel_attn_fwd", ev0, _ev()))

@@ -2,6 +2,7 @@
 Shapes: all rows empty, every row degree k, the ja profile.  Usage: lat_probe.py [d]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import ctypes as C
 import numpy as np, torch
 from jmac_amd import synth, ops
 from jmac_amd.graph import RelGraph
@@ -29,8 +30,7 @@ def run(name, ei, et, n, bwd=False):
         out = torch.empty((n, d), device=dev); smax = torch.empty(n, device=dev); sden = torch.empty(n, device=dev)
         wsb = int(L.jmac_rel_attn_fwd_workspace_bytes(sc.n_parts_max, d)); ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         st = stream()
-        args = (ptr(PQZ), 3 * d, PQZ.data_ptr() + d * 4, 3 * d, ptr(RR), 2 * d, ptr(a), ptr(g.rowptr), ptr(g.col), ptr(g.etype),
-                ptr(sc.items), ptr(sc.splits), ptr(sc.counts), sc.n_items_max, sc.n_splits_max, sc.n_parts_max, n, d, 0.05,
+        args = (ptr(PQZ), 3 * d, PQZ.data_ptr() + d * 4, 3 * d, ptr(RR), 2 * d, ptr(a), ptr(g.col), ptr(g.etype), C.byref(sc.view()), n, d, 0.05,
                 nrel - 1, 0, 0.5, ptr(out), d, ptr(smax), ptr(sden), ptr(ws), wsb, st)
         fn = lambda: L.jmac_rel_attn_aggregate_fwd_f32(*args)
         iters = 300

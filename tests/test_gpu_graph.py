@@ -15,7 +15,8 @@ def _csr_ref(ei, et, n):
     return np.cumsum(rowptr), ei[1][order], et[order], order
 
 
-@pytest.mark.parametrize("n,nr,e,chunk", [(50, 5, 400, 16), (1000, 40, 20000, 64), (7, 2, 0, 8), (3000, 961, 9000, 256)])
+@pytest.mark.parametrize("n,nr,e,chunk", [(50, 5, 400, 16), (1000, 40, 20000, 64), (7, 2, 0, 8), (3000, 961, 9000, 256),
+                                          (20000, 30, 60000, 32)])
 def test_csr_and_schedules(n, nr, e, chunk):
     from jmac_amd.graph import RelGraph
     rng = np.random.default_rng(n + e)
@@ -27,23 +28,43 @@ def test_csr_and_schedules(n, nr, e, chunk):
         assert (g.perm[:e].cpu().numpy() == perm).all()          # stable
         assert (g.col[:e].cpu().numpy() == col).all()
         assert (g.etype[:e].cpu().numpy() == typ).all()
-    # schedule: items tile every row exactly, chunks <= chunk, partial slots consecutive
-    cnt = g.by_dst.counts.cpu().numpy()
-    items = g.by_dst.items.cpu().numpy()[: cnt[0]]
-    splits = g.by_dst.splits.cpu().numpy()[: cnt[1]]
-    assert cnt[0] <= g.by_dst.n_items_max and cnt[1] <= g.by_dst.n_splits_max and cnt[2] <= g.by_dst.n_parts_max
+    # schedule: items tile every row exactly; plain rows <= chunk entries and finalised by their wave (pslot < 0), long rows
+    # split into <= chunk-entry items with consecutive partial slots; on small graphs rows of COOP_MIN < deg <= COOP_MAX
+    # entries are cooperative: exactly four items of ceil(deg / 4) entries at the HEAD of the list (block aligned), and
+    # the empty rows are the TAIL of the list
+    from jmac_amd import graph as jgraph
+    sch = g.by_dst
+    cnt = sch.counts.cpu().numpy()
+    items = sch.items.cpu().numpy()[: cnt[0]]
+    splits = sch.splits.cpu().numpy()[: cnt[1]]
+    assert cnt[0] == sch.n_items_max and cnt[1] == sch.n_splits_max and cnt[2] == sch.n_parts_max
+    assert cnt[3] == sch.n_empty and cnt[4] == sch.n_coop
+    small = e > 0 and n + e // chunk + 1 <= jgraph.INLINE_EDGES_MAX_ITEMS
+    degs = np.diff(rowptr)
+    is_coop = (degs > jgraph.COOP_MIN) & (degs <= jgraph.COOP_MAX) if small else np.zeros(n, bool)
+    assert sch.n_coop == int(is_coop.sum()) and sch.n_empty == int((degs == 0).sum())
     cover = np.zeros(max(e, 1), dtype=np.int64)
     seen_rows = np.zeros(n, dtype=np.int64)
-    for seg, b, en, ps in items:
-        assert rowptr[seg] <= b <= en <= rowptr[seg + 1] and en - b <= chunk
+    for pos, (seg, b, en, ps) in enumerate(items):
+        assert rowptr[seg] <= b <= en <= rowptr[seg + 1]
         cover[b:en] += 1
         seen_rows[seg] += 1
-        deg = rowptr[seg + 1] - rowptr[seg]
-        assert (ps < 0) == (deg <= chunk)
-    assert (cover[:e] == 1).all() and (seen_rows >= 1).all()
-    for seg, p0, nch, _ in splits:
+        deg = degs[seg]
+        if is_coop[seg]:
+            assert pos < 4 * sch.n_coop and ps == pos and en - b <= -(-deg // 4)
+        else:
+            assert pos >= 4 * sch.n_coop and en - b <= chunk and (ps < 0) == (deg <= chunk)
+        assert (deg == 0) == (pos >= cnt[0] - sch.n_empty)
+    assert (cover[:e] == 1).all() and (seen_rows >= 1).all() and (seen_rows[is_coop] == 4).all()
+    for k, (seg, p0, nch, flag) in enumerate(splits):
         mine = items[items[:, 0] == seg]
         assert len(mine) == nch and (np.sort(mine[:, 3]) == np.arange(p0, p0 + nch)).all()
+        assert (flag == 1) == bool(is_coop[seg]) == (k < sch.n_coop)
+    if sch.item_edges is not None:
+        ie = sch.item_edges.cpu().numpy()[: cnt[0]]
+        for (seg, b, en, ps), row in zip(items, ie):
+            want = [col[b] if en > b else -1, typ[b] if en > b else -1, col[b + 1] if en > b + 1 else -1, typ[b + 1] if en > b + 1 else -1]
+            assert list(row) == want
     # backward views
     g.ensure_backward_views()
     if e:
