@@ -63,11 +63,14 @@ int jmac_index_check(const void* idx, int32_t elem_bytes, int64_t n, int64_t lo,
                      jmac_stream_t stream);
 
 /* COO (edge_index [2,E] int64: row 0 = aggregation destination, row 1 = message source;
- * edge_type [E] int64) -> CSR by destination with a STABLE order inside each row.
+ * edge_type [E] int64) -> CSR by destination with a DETERMINISTIC order inside each row:
+ *   nrel > 0 (types in [0, nrel)): by relation type, then input order (edges of a row that share a relation are
+ *            neighbours: their [Rq|Rz] row is read once per group of gathers);
+ *   nrel = 0: input order.
  *   rowptr [N+1], col [E] (source of each CSR slot), etype [E], perm [E] (original edge id).
  * Precondition: destinations in [0,N) (check with jmac_index_check; sources / types are range-checked against the
  * tables by the caller the same way). */
-int jmac_csr_build(const int64_t* edge_index, const int64_t* edge_type, int64_t E, int64_t N,
+int jmac_csr_build(const int64_t* edge_index, const int64_t* edge_type, int64_t E, int64_t N, int64_t nrel,
                    int32_t* rowptr, int32_t* col, int32_t* etype, int32_t* perm,
                    void* ws, size_t ws_bytes, jmac_stream_t stream);
 

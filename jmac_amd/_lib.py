@@ -11,7 +11,7 @@ import re
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjmac_hip.so")
+LIB_PATH = os.environ.get("JMAC_LIB_PATH") or os.path.join(_HERE, "libjmac_hip.so")   # env: A/B builds of the kernels
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jmac_hip.h")
 
 _lib: Optional[C.CDLL] = None
@@ -36,7 +36,7 @@ _SIGS = {
     "jmac_version": (C.c_int, []),
     "jmac_graph_workspace_bytes": (sz, [i64, i64]),
     "jmac_index_check": (C.c_int, [vp, i32, i64, i64, i64, vp, vp]),
-    "jmac_csr_build": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
+    "jmac_csr_build": (C.c_int, [vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
     "jmac_group_build": (C.c_int, [vp, i64, i64, vp, vp, vp, sz, vp]),
     "jmac_items_max": (i64, [i64, i64, i32, i32]),
     "jmac_splits_max": (i64, [i64, i32, i32]),

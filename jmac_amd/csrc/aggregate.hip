@@ -103,8 +103,16 @@ __device__ __forceinline__ float4 sel4(bool c, float4 a) { return c ? a : f4zero
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+#ifndef JMAC_FWD_WPE
+#define JMAC_FWD_WPE 0
+#endif
+#if JMAC_FWD_WPE
+#define JMAC_FWD_ATTR __attribute__((amdgpu_waves_per_eu(JMAC_FWD_WPE, JMAC_FWD_WPE)))
+#else
+#define JMAC_FWD_ATTR
+#endif
 template <int NCH, int U, int D4T, typename TT>
-__global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
+__global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdArgs a) {
     typedef typename RawOf<TT>::type raw_t;
     // cooperative segments: the partial softmax states of the block's four waves meet here
     __shared__ float4 coop_acc[kWavesPerBlock][NCH][64];
@@ -210,16 +218,73 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_kernel(FwdArgs a) {
                 }
                 m = mn;
             };
-            int u0 = 0;
-            if (U >= 4)
-                for (; u0 + 4 <= nb; u0 += 4) group(std::integral_constant<int, 4>{}, u0);
-            if (u0 + 2 <= nb) {
-                group(std::integral_constant<int, 2>{}, u0);
-                u0 += 2;
-                if (U < 4)
-                    for (; u0 + 2 <= nb; u0 += 2) group(std::integral_constant<int, 2>{}, u0);
+            if constexpr (U >= 4) {
+                // Large graphs (HBM-bound): groups of two edges, SOFTWARE-PIPELINED -- the gathers of group g+1 are in
+                // flight while group g is reduced, so a wave always has rows outstanding (with "load 4, wait, compute 4"
+                // a wave's memory queue is empty for the whole compute phase).  Two register buffers, roles fixed per
+                // unrolled half; an odd tail edge is issued twice (clamped) and weighted zero.
+                raw_t qA[2][NCH], rA[2][NCH], qB[2][NCH], rB[2][NCH];
+                auto issue = [&](const int g, raw_t (&qr)[2][NCH], raw_t (&rr)[2][NCH]) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int le = min(2 * g + u, nb - 1);
+                        const int j = bcast_i(my_col, le);
+                        const int t = bcast_i(my_typ, le);
+                        const TT* qrow = tQZ + (int64_t)j * a.ldqz;
+                        const TT* rrow = tRR + (int64_t)t * a.ldrr;
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) {
+                            qr[u][k] = ldraw(qrow + L.coffc[k]);
+                            rr[u][k] = ldraw(rrow + L.coffc[k]);
+                        }
+                    }
+                };
+                auto consume = [&](const int g, const raw_t (&qr)[2][NCH], const raw_t (&rr)[2][NCH]) {
+                    float4 q[2][NCH];
+                    float sv[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        float part = 0.f;
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) {
+                            q[u][k] = sub4(cvt4(qr[u][k]), cvt4(rr[u][k]));
+                            if (!L.all_valid(k)) q[u][k] = sel4(L.valid[k], q[u][k]);
+                            if (L.any_h(k)) part += dot4(av[k], leaky4<D4T != 0>(add4(pv[k], q[u][k]), a.slope));
+                        }
+                        sv[u] = part;
+                    }
+                    wave_sum_n<2>(sv);
+                    if (2 * g + 1 >= nb) sv[1] = -INFINITY;            // odd tail: the duplicate gets weight exp(-inf) = 0
+                    const float mn = fmaxf(m, fmaxf(sv[0], sv[1]));
+                    const float sc = fast_exp(m - mn);
+                    const float w0 = fast_exp(sv[0] - mn), w1 = fast_exp(sv[1] - mn);
+                    l = l * sc + (w0 + w1);
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) {
+                        if (!L.any_v(k)) continue;
+                        acc[k] = fma4(q[1][k], w1, fma4(q[0][k], w0, mul4(acc[k], sc)));
+                    }
+                    m = mn;
+                };
+                const int ngr = (nb + 1) >> 1;
+                issue(0, qA, rA);
+                for (int g = 0; g < ngr; g += 2) {
+                    if (g + 1 < ngr) issue(g + 1, qB, rB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(g, qA, rA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g + 1 < ngr) {
+                        if (g + 2 < ngr) issue(g + 2, qA, rA);
+                        __builtin_amdgcn_sched_barrier(0);
+                        consume(g + 1, qB, rB);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
+                int u0 = 0;
+                for (; u0 + 2 <= nb; u0 += 2) group(std::integral_constant<int, 2>{}, u0);
+                if (u0 < nb) group(std::integral_constant<int, 1>{}, u0);
             }
-            if (u0 < nb) group(std::integral_constant<int, 1>{}, u0);
         }
     };
     // ---- out[i] = out_scale * ( sqrt(deg) / l * acc  +  Z[i] - Rz[loop] ),  softmax statistics for the backward ---------

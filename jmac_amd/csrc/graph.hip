@@ -25,6 +25,21 @@ __global__ void coo_keys_kernel(const int64_t* __restrict__ edge_index, int64_t 
     }
 }
 
+// keys[s] = (int32) src[perm[s]]   (second sort pass: the destination of every type-ordered edge)
+__global__ void gather_keys_kernel(const int64_t* __restrict__ src, const int32_t* __restrict__ perm, int64_t E,
+                                   int32_t* __restrict__ keys) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < E) keys[s] = (int32_t)src[perm[s]];
+}
+__global__ void type_keys_kernel(const int64_t* __restrict__ edge_type, int64_t E, int32_t* __restrict__ keys,
+                                 int32_t* __restrict__ iota) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) {
+        keys[e] = (int32_t)edge_type[e];
+        iota[e] = (int32_t)e;
+    }
+}
+
 // bad[0] += number of entries outside [lo, hi)  (the reference raises IndexError on such an id; the kernels trust them)
 template <typename IT>
 __global__ void index_check_kernel(const IT* __restrict__ idx, int64_t n, int64_t lo, int64_t hi, int32_t* __restrict__ bad) {
@@ -240,7 +255,7 @@ int jmac_index_check(const void* idx, int32_t elem_bytes, int64_t n, int64_t lo,
     return (int)hipGetLastError();
 }
 
-int jmac_csr_build(const int64_t* edge_index, const int64_t* edge_type, int64_t E, int64_t N, int32_t* rowptr,
+int jmac_csr_build(const int64_t* edge_index, const int64_t* edge_type, int64_t E, int64_t N, int64_t nrel, int32_t* rowptr,
                    int32_t* col, int32_t* etype, int32_t* perm, void* ws, size_t ws_bytes, jmac_stream_t stream) {
     if (E < 0 || N < 0 || !rowptr || (E > 0 && (!edge_index || !edge_type || !col || !etype || !perm))) return JMAC_EINVAL;
     if (E >= INT32_MAX || N >= INT32_MAX) return JMAC_ERANGE;
@@ -258,9 +273,23 @@ int jmac_csr_build(const int64_t* edge_index, const int64_t* edge_type, int64_t 
     int32_t* iota = (int32_t*)(w + 2 * arr);
     void* tmp = w + 3 * arr;
     unsigned nb = (unsigned)((E + T - 1) / T);
-    hipLaunchKernelGGL(coo_keys_kernel, dim3(nb), dim3(T), 0, st, edge_index, E, keys, iota);
-    int rc = sort_by_key(keys, keys_sorted, iota, perm, E, N, tmp, ws_bytes - 3 * arr, st);
-    if (rc) return rc;
+    int rc;
+    if (nrel > 0) {
+        // order inside a row: by relation type, then input order -- two stable passes (type, then destination).  Edges of
+        // one destination that share a relation become neighbours, so their [Rq|Rz] row is fetched once per group of
+        // gathers instead of once per edge (the repeats hit L1), and a hub's tail relations are touched in one burst.
+        hipLaunchKernelGGL(type_keys_kernel, dim3(nb), dim3(T), 0, st, edge_type, E, keys, iota);
+        rc = sort_by_key(keys, keys_sorted, iota, perm, E, nrel, tmp, ws_bytes - 3 * arr, st);        // perm = order by type
+        if (rc) return rc;
+        hipLaunchKernelGGL(gather_keys_kernel, dim3(nb), dim3(T), 0, st, edge_index, perm, E, keys);
+        rc = sort_by_key(keys, keys_sorted, perm, iota, E, N, tmp, ws_bytes - 3 * arr, st);           // iota = final order
+        if (rc) return rc;
+        if (hipMemcpyAsync(perm, iota, (size_t)E * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();
+    } else {
+        hipLaunchKernelGGL(coo_keys_kernel, dim3(nb), dim3(T), 0, st, edge_index, E, keys, iota);
+        rc = sort_by_key(keys, keys_sorted, iota, perm, E, N, tmp, ws_bytes - 3 * arr, st);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(ptr_from_sorted_kernel, dim3(nb), dim3(T), 0, st, keys_sorted, E, N, rowptr);
     hipLaunchKernelGGL(csr_gather_kernel, dim3(nb), dim3(T), 0, st, edge_index, edge_type, perm, E, col, etype);
     return (int)hipGetLastError();

@@ -5,7 +5,7 @@ import numpy as np, torch
 from jmac_amd import synth, ops
 from jmac_amd.graph import RelGraph
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
-chunk = int(sys.argv[2]) if len(sys.argv) > 2 else None
+chunk = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != 'auto' else None
 d = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 do_bwd = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 n, e, nr = int(1_000_000 * scale), int(20_000_000 * scale), 1000

@@ -30,7 +30,7 @@ def test_argument_validation_needs_no_device():
     assert L.jmac_l1_score_f32(None, 4, None, 4, -1, 3, 4, None, 4, 0, None) == -1          # negative size
     assert L.jmac_l1_score_f32(None, 4, None, 4, 2, 3, 4, None, 4, 0, None) == -1           # null pointers
     assert L.jmac_sim_matrix_f32(ctypes.c_void_p(16), 3, ctypes.c_void_p(16), 4, 2, 2, 4, ctypes.c_void_p(16), 2, None) == -2
-    assert L.jmac_csr_build(None, None, -5, 3, None, None, None, None, None, 0, None) == -1
+    assert L.jmac_csr_build(None, None, -5, 3, 2, None, None, None, None, None, 0, None) == -1
     assert b"workspace" in L.jmac_strerror(-3)
     assert L.jmac_items_max(10, 100, 8, 0) == 10 + 12 + 1
     assert L.jmac_items_max(10, 100, 8, 8) == 10 + 12 + 1 + 3 * 11           # cooperative splits: 3 extra items each

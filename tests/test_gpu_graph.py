@@ -9,7 +9,7 @@ from util import random_graph
 
 
 def _csr_ref(ei, et, n):
-    order = np.argsort(ei[0], kind="stable")
+    order = np.lexsort((np.arange(ei.shape[1]), et, ei[0]))          # by destination, then relation type, then input order
     rowptr = np.zeros(n + 1, dtype=np.int64)
     np.add.at(rowptr, ei[0] + 1, 1)
     return np.cumsum(rowptr), ei[1][order], et[order], order
@@ -25,7 +25,7 @@ def test_csr_and_schedules(n, nr, e, chunk):
     rowptr, col, typ, perm = _csr_ref(ei, et, n)
     assert (g.rowptr.cpu().numpy() == rowptr).all()
     if e:
-        assert (g.perm[:e].cpu().numpy() == perm).all()          # stable
+        assert (g.perm[:e].cpu().numpy() == perm).all()          # deterministic order
         assert (g.col[:e].cpu().numpy() == col).all()
         assert (g.etype[:e].cpu().numpy() == typ).all()
     # schedule: items tile every row exactly; plain rows <= chunk entries and finalised by their wave (pslot < 0), long rows
