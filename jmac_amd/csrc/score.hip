@@ -37,7 +37,7 @@ __device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((
 
 // TT = float or bf16_t (raw bits): bf16 operands are widened when they are staged into LDS, the |a-b| accumulation
 // is fp32 either way (the kernel is VALU-bound, so the narrower tables change the bytes, not the time)
-template <typename TT>
+template <typename TT, bool VEC>
 __global__ __launch_bounds__(kBlock) void l1_score_kernel(const TT* __restrict__ er, int64_t lder,
                                                           const TT* __restrict__ tab, int64_t ldt, int B, int N, int d,
                                                           float* __restrict__ out, int64_t ldout, int accumulate) {
@@ -55,10 +55,19 @@ __global__ __launch_bounds__(kBlock) void l1_score_kernel(const TT* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
+    // Every global load is UNCONDITIONAL at a clamped address: a load behind an exec-mask branch gets its s_waitcnt
+    // inside the branch (hipcc), i.e. the next slab's prefetch would be waited for before the current slab's arithmetic
+    // instead of after it.  Rows past the end re-read the last row (they only feed outputs that are never stored); k
+    // quads past d re-read the last quad and are zeroed when they are written to LDS.  (d % 4 != 0: scalar tail form.)
+    constexpr bool vec = VEC;                    // d % 4 == 0 (the launcher picks the instantiation)
     auto gload = [&](const TT* base, int64_t ld, int64_t row, int64_t nrows, int k0) -> float4 {
+        const int k = k0 + lk;
+        if constexpr (vec) {
+            const int64_t r = row < nrows ? row : nrows - 1;
+            return cvt4(ldraw(base + r * ld + (k < d ? k : d - 4)));
+        }
         float4 v = f4zero();
         if (row < nrows) {
-            const int k = k0 + lk;
             if (k + 3 < d) v = cvt4(ldraw(base + row * ld + k));
             else {
                 const TT* p = base + row * ld;
@@ -69,7 +78,8 @@ __global__ __launch_bounds__(kBlock) void l1_score_kernel(const TT* __restrict__
         }
         return v;
     };
-    auto sstore = [&](float (*S)[L1_LD], float4 v) {
+    auto sstore = [&](float (*S)[L1_LD], float4 v, int k0, bool row_ok) {
+        if (vec && !(row_ok && k0 + lk < d)) v = f4zero();          // the clamped loads' padding: |0 - 0| adds nothing
         S[lk + 0][lrow] = v.x;
         S[lk + 1][lrow] = v.y;
         S[lk + 2][lrow] = v.z;
@@ -77,8 +87,8 @@ __global__ __launch_bounds__(kBlock) void l1_score_kernel(const TT* __restrict__
     };
     const int nk = (d + L1_K - 1) / L1_K;
     float4 ra = gload(er, lder, arow, B, 0), rb = gload(tab, ldt, brow, N, 0);
-    sstore(As[0], ra);
-    sstore(Bs[0], rb);
+    sstore(As[0], ra, 0, arow < B);
+    sstore(Bs[0], rb, 0, brow < N);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
@@ -98,8 +108,8 @@ __global__ __launch_bounds__(kBlock) void l1_score_kernel(const TT* __restrict__
                 for (int j = 0; j < 4; ++j) acc[i][j] = add_absdiff(acc[i][j], av[i], bv[j]);
         }
         if (kt + 1 < nk) {
-            sstore(As[cur ^ 1], ra);
-            sstore(Bs[cur ^ 1], rb);
+            sstore(As[cur ^ 1], ra, (kt + 1) * L1_K, arow < B);
+            sstore(Bs[cur ^ 1], rb, (kt + 1) * L1_K, brow < N);
         }
         __syncthreads();
     }
@@ -823,8 +833,12 @@ int jmac_l1_score_f32(const float* er, int64_t lder, const float* table, int64_t
     if (lder % 4 || ldt % 4) return JMAC_EDIM;
     if (B >= INT32_MAX || N >= INT32_MAX) return JMAC_ERANGE;
     dim3 grid((unsigned)((N + L1_T - 1) / L1_T), (unsigned)((B + L1_T - 1) / L1_T));
-    hipLaunchKernelGGL(l1_score_kernel<float>, grid, dim3(kBlock), 0, (hipStream_t)stream, er, lder, table, ldt, (int)B, (int)N, (int)d,
-                       out, ldout, accumulate);
+    if (d % 4 == 0)
+        hipLaunchKernelGGL((l1_score_kernel<float, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, er, lder, table, ldt, (int)B,
+                           (int)N, (int)d, out, ldout, accumulate);
+    else
+        hipLaunchKernelGGL((l1_score_kernel<float, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, er, lder, table, ldt, (int)B,
+                           (int)N, (int)d, out, ldout, accumulate);
     return (int)hipGetLastError();
 }
 
@@ -836,8 +850,12 @@ int jmac_l1_score_bf16(const uint16_t* er, int64_t lder, const uint16_t* table, 
     if (lder % 4 || ldt % 4) return JMAC_EDIM;
     if (B >= INT32_MAX || N >= INT32_MAX) return JMAC_ERANGE;
     dim3 grid((unsigned)((N + L1_T - 1) / L1_T), (unsigned)((B + L1_T - 1) / L1_T));
-    hipLaunchKernelGGL(l1_score_kernel<bf16_t>, grid, dim3(kBlock), 0, (hipStream_t)stream, er, lder, table, ldt, (int)B, (int)N,
-                       (int)d, out, ldout, accumulate);
+    if (d % 4 == 0)
+        hipLaunchKernelGGL((l1_score_kernel<bf16_t, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, er, lder, table, ldt, (int)B,
+                           (int)N, (int)d, out, ldout, accumulate);
+    else
+        hipLaunchKernelGGL((l1_score_kernel<bf16_t, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, er, lder, table, ldt,
+                           (int)B, (int)N, (int)d, out, ldout, accumulate);
     return (int)hipGetLastError();
 }
 
