@@ -521,6 +521,211 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_combine_kernel(FwdArgs a)
     }
 }
 
+// ---- merge / reduction bodies: device functions over a (block id, block count) pair so that several of them can share
+// ---- one launch (the DBP-5L-scale backward is bound by launches, not by bytes) ------------------------------------------
+struct SumPartsTask {           // plain sum of the partial rows of split segments (width = 4*W4 floats)
+    const jmac_split_t* splits;
+    const int32_t* counts;
+    const float* part;
+    int W4;
+    float sign;
+    float* outp;
+    int64_t ldout;
+    const float* G;             // optional self term (pass B): out[seg][d:] += kappa * G[seg - self_off]
+    int64_t ldg;
+    int D4;
+    float kappa;
+    int add_self;
+    int64_t self_off, n_self;
+    int nblocks;                // blocks of the launch that work on this task (0 = task absent)
+};
+struct ReduceTask {             // out[c] = scale * sum_p partial[p*W + c]
+    const float* partial;
+    int nparts, W;
+    float scale;
+    float* outp;
+    int nblocks;
+};
+struct ColsumTask {             // per-block partial column sums of X [R, 4*W4] -> partial [nblocks, 4*W4]
+    const float* X;
+    int64_t ldx, R;
+    int W4;
+    float* partial;
+    int nblocks;
+};
+
+// one BLOCK per split segment: wave w sums partial rows w, w+4, w+8, ... (two rows in flight per lane), the four
+// wave sums are combined through LDS in wave order -> fixed summation order, and the hottest relation's thousands
+// of partial rows are no longer one wave's serial chain
+__device__ __forceinline__ void sum_parts_body(const SumPartsTask& t, int bid, int nb, float4 (*red)[64]) {
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n_splits = t.counts[1];
+    const int W4 = t.W4;
+    for (int sp = bid; sp < n_splits; sp += nb) {
+        const jmac_split_t s = t.splits[sp];
+        for (int c0 = 0; c0 < W4; c0 += 64) {
+            const int c4 = c0 + lane;
+            float4 a0 = f4zero(), a1 = f4zero(), a2 = f4zero(), a3 = f4zero();
+            if (c4 < W4) {
+                // four partial rows in flight per lane: a long list (the hottest relation of a DBP-5L graph: ~170 partial
+                // rows) is a chain of dependent round trips, not bandwidth
+                const float* base = t.part + ((int64_t)s.pslot0 * W4 + c4) * 4;
+                const int64_t rs = (int64_t)W4 * 4;
+                int c = wave;
+                for (; c + 3 * kWavesPerBlock < s.nchunks; c += 4 * kWavesPerBlock) {
+                    a0 = add4(a0, ld4(base + (int64_t)c * rs));
+                    a1 = add4(a1, ld4(base + (int64_t)(c + kWavesPerBlock) * rs));
+                    a2 = add4(a2, ld4(base + (int64_t)(c + 2 * kWavesPerBlock) * rs));
+                    a3 = add4(a3, ld4(base + (int64_t)(c + 3 * kWavesPerBlock) * rs));
+                }
+                for (; c < s.nchunks; c += kWavesPerBlock) a0 = add4(a0, ld4(base + (int64_t)c * rs));
+            }
+            a0 = add4(a0, a2);
+            a1 = add4(a1, a3);
+            red[wave][lane] = add4(a0, a1);
+            __syncthreads();
+            if (wave == 0 && c4 < W4) {
+                float4 acc = add4(add4(red[0][lane], red[1][lane]), add4(red[2][lane], red[3][lane]));
+                acc = mul4(acc, t.sign);
+                if (t.add_self && c4 >= t.D4 && s.seg >= t.self_off && s.seg - t.self_off < t.n_self)
+                    acc = fma4(ld4(t.G + ((int64_t)s.seg - t.self_off) * t.ldg + (c4 - t.D4) * 4), t.kappa, acc);
+                st4(t.outp + (int64_t)s.seg * t.ldout + c4 * 4, acc);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void sum_parts_kernel(SumPartsTask t) {
+    __shared__ float4 red[kWavesPerBlock][64];
+    sum_parts_body(t, blockIdx.x, gridDim.x, red);
+}
+
+// column sums of a [R, 4*W4] matrix in two deterministic steps: per-block partials (here), then a reduce task.
+// rpb = kBlock / W4 rows are in flight per block (thread = (row lane, float4 column)), 2 loads in flight per thread;
+// the row lanes are combined through LDS in a fixed order
+__device__ __forceinline__ void colsum_partial_body(const ColsumTask& t, int bid, int nb, float4* red) {
+    const int tid = threadIdx.x;
+    const int W4 = t.W4;
+    if (W4 > kBlock) {   // wide rows: one thread per float4 column, looped
+        for (int c4 = tid; c4 < W4; c4 += kBlock) {
+            float4 acc = f4zero();
+            for (int64_t r = bid; r < t.R; r += nb) acc = add4(acc, ld4(t.X + r * t.ldx + c4 * 4));
+            st4(t.partial + ((int64_t)bid * W4 + c4) * 4, acc);
+        }
+        return;
+    }
+    const int rpb = kBlock / W4;
+    const int rl = tid / W4, c4 = tid % W4;
+    float4 a0 = f4zero(), a1 = f4zero();
+    if (rl < rpb) {
+        const int64_t stride = (int64_t)nb * rpb;
+        int64_t r = (int64_t)bid * rpb + rl;
+        for (; r + stride < t.R; r += 2 * stride) {
+            a0 = add4(a0, ld4(t.X + r * t.ldx + c4 * 4));
+            a1 = add4(a1, ld4(t.X + (r + stride) * t.ldx + c4 * 4));
+        }
+        if (r < t.R) a0 = add4(a0, ld4(t.X + r * t.ldx + c4 * 4));
+    }
+    red[tid] = add4(a0, a1);
+    __syncthreads();
+    if (tid < W4) {
+        float4 acc = red[tid];
+        for (int q = 1; q < rpb; ++q) acc = add4(acc, red[q * W4 + tid]);
+        st4(t.partial + ((int64_t)bid * W4 + tid) * 4, acc);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void colsum_partial_kernel(ColsumTask t) {
+    __shared__ float4 red[kBlock];
+    colsum_partial_body(t, blockIdx.x, gridDim.x, red);
+}
+
+// out[c] = scale * sum_p partial[p][c]: 16 columns x 64 row lanes per 1024-thread block (a block's rows are read as 64-byte
+// segments; 16 columns per block instead of 64 puts 19 blocks instead of 5 on a 300-wide reduction: 6.6 -> ~4 us)
+constexpr int RR_COLS = 16, RR_LANES = 1024 / RR_COLS;
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ partial, int nparts, int W, float scale,
+                                                           float* __restrict__ outp) {
+    __shared__ float red[RR_LANES][RR_COLS];
+    const int cl = threadIdx.x % RR_COLS, rl = threadIdx.x / RR_COLS;
+    const int c = blockIdx.x * RR_COLS + cl;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < W) {
+        int p = rl;
+        for (; p + 3 * RR_LANES < nparts; p += 4 * RR_LANES) {
+            a0 += partial[(int64_t)p * W + c];
+            a1 += partial[(int64_t)(p + RR_LANES) * W + c];
+            a2 += partial[(int64_t)(p + 2 * RR_LANES) * W + c];
+            a3 += partial[(int64_t)(p + 3 * RR_LANES) * W + c];
+        }
+        for (; p < nparts; p += RR_LANES) a0 += partial[(int64_t)p * W + c];
+    }
+    red[rl][cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rl == 0 && c < W) {
+        float s = red[0][cl];
+#pragma unroll 8
+        for (int r = 1; r < RR_LANES; ++r) s += red[r][cl];
+        outp[c] = s * scale;
+    }
+}
+
+// the same reduction for a 256-thread block that shares a launch with other tasks: 8 columns x 32 row lanes
+constexpr int RT_COLS = 8, RT_LANES = kBlock / RT_COLS;
+__device__ __forceinline__ void reduce_rows_body(const ReduceTask& t, int bid, float (*red)[RT_COLS]) {
+    const int cl = threadIdx.x % RT_COLS, rl = threadIdx.x / RT_COLS;
+    const int c = bid * RT_COLS + cl;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < t.W) {
+        int p = rl;
+        for (; p + 3 * RT_LANES < t.nparts; p += 4 * RT_LANES) {
+            a0 += t.partial[(int64_t)p * t.W + c];
+            a1 += t.partial[(int64_t)(p + RT_LANES) * t.W + c];
+            a2 += t.partial[(int64_t)(p + 2 * RT_LANES) * t.W + c];
+            a3 += t.partial[(int64_t)(p + 3 * RT_LANES) * t.W + c];
+        }
+        for (; p < t.nparts; p += RT_LANES) a0 += t.partial[(int64_t)p * t.W + c];
+    }
+    red[rl][cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rl == 0 && c < t.W) {
+        float s = red[0][cl];
+#pragma unroll 8
+        for (int r = 1; r < RT_LANES; ++r) s += red[r][cl];
+        t.outp[c] = s * t.scale;
+    }
+}
+
+// Backward, last launch: every merge of the deterministic backward in ONE grid -- the partial rows of the split
+// destinations / sources / relations (dP, d[Q|Z], d[Rq|Rz]), the a_att gradient (per-block partial rows of pass A) and
+// the column sum of G (dRz[loop]).  Blocks are dealt to the tasks in order; every task loops over its own block range.
+struct FinalizeArgs {
+    SumPartsTask sp[3];
+    ReduceTask rd[2];
+};
+__global__ __launch_bounds__(kBlock) void bwd_finalize_kernel(FinalizeArgs f) {
+    __shared__ float4 red4[kWavesPerBlock][64];
+    __shared__ float redr[RT_LANES][RT_COLS];
+    int b = blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (b < f.sp[i].nblocks) {
+            sum_parts_body(f.sp[i], b, f.sp[i].nblocks, red4);
+            return;
+        }
+        b -= f.sp[i].nblocks;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (b < f.rd[i].nblocks) {
+            reduce_rows_body(f.rd[i], b, redr);
+            return;
+        }
+        b -= f.rd[i].nblocks;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
@@ -546,12 +751,17 @@ struct BwdArgs {
 
 // Pass A: by destination.  MODE 0: float atomics into dQZ / dRR.  MODE 1: per-edge records.
 template <int NCH, int U, int MODE, int D4T>
-__global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
+__global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a, int gridA, ColsumTask cs) {
     constexpr int NCH_H = (NCH + 1) / 2;
     __shared__ float4 red[kWavesPerBlock][NCH_H][64];
+    // the blocks behind the first gridA share the launch: column sum of G for the fused self loop (dRz[loop])
+    if ((int)blockIdx.x >= gridA) {
+        colsum_partial_body(cs, (int)blockIdx.x - gridA, cs.nblocks, &red[0][0][0]);
+        return;
+    }
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nwaves = gridDim.x * kWavesPerBlock;
+    const int nwaves = gridA * kWavesPerBlock;
     const int n_items = a.counts[0];
     Lanes<NCH, D4T> L;
     L.init(lane, a.D4);
@@ -718,12 +928,20 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a) {
 // Pass B (by source, sign=+1) and pass C (by relation, sign=-1): sum the per-edge records.
 //   row[h-half] = sign * sum_e ds_e * a (.) lrelu'(h_e)         (sign bits from pass A)
 //   row[v-half] = sign * sum_e w_e * g_{dst(e)}  (+ g_j for the fused self loop in pass B)
+// Both passes share ONE launch: blocks [0, grid_b) run pass B (arguments ab), the rest pass C (arguments ac).
 template <int NCH, int U, int D4T>
-__global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs a, float* __restrict__ outp, int64_t ldout) {
+__global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs ab, float* __restrict__ outb, int64_t ldoutb, int grid_b,
+                                                                     BwdArgs ac, float* __restrict__ outc, int64_t ldoutc) {
     constexpr int NCH_H = (NCH + 1) / 2;
+    const bool is_b = (int)blockIdx.x < grid_b;                       // block-uniform
+    const BwdArgs& a = is_b ? ab : ac;
+    float* const outp = is_b ? outb : outc;
+    const int64_t ldout = is_b ? ldoutb : ldoutc;
+    const int bid = is_b ? (int)blockIdx.x : (int)blockIdx.x - grid_b;
+    const int nblk = is_b ? grid_b : (int)gridDim.x - grid_b;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nwaves = gridDim.x * kWavesPerBlock;
+    const int nwaves = nblk * kWavesPerBlock;
     const int n_items = a.counts[0];
     Lanes<NCH, D4T> L;
     L.init(lane, a.D4);
@@ -736,7 +954,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs a, 
 #pragma unroll
     for (int k = 0; k < NCH; ++k) goff[k] = L.is_v(k) ? L.coff[k] - voff : 0;
 
-    for (int it = blockIdx.x * kWavesPerBlock + wave; it < n_items; it += nwaves) {
+    for (int it = bid * kWavesPerBlock + wave; it < n_items; it += nwaves) {
         const jmac_item_t item = a.items[it];
         const int seg = item.seg;
         float4 acc[NCH];
@@ -809,113 +1027,6 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs a, 
                 v = fma4(ld4(a.G + ((int64_t)seg - a.self_off) * a.ldg + (L.coff[k] - voff)), kappa, v);
             st4(row + L.coff[k], v);
         }
-    }
-}
-
-// plain sum of the partial rows of split segments (width = 4*W4 floats); optional self term (pass B)
-__global__ __launch_bounds__(kBlock) void sum_parts_kernel(const jmac_split_t* __restrict__ splits,
-                                                           const int32_t* __restrict__ counts,
-                                                           const float* __restrict__ part, int W4, float sign,
-                                                           float* __restrict__ outp, int64_t ldout,
-                                                           const float* __restrict__ G, int64_t ldg, int D4, float kappa,
-                                                           int add_self, int64_t self_off, int64_t n_self) {
-    // one BLOCK per split segment: wave w sums partial rows w, w+4, w+8, ... (two rows in flight per lane), the four
-    // wave sums are combined through LDS in wave order -> fixed summation order, and the hottest relation's thousands
-    // of partial rows are no longer one wave's serial chain
-    __shared__ float4 red[kWavesPerBlock][64];
-    const int lane = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int n_splits = counts[1];
-    for (int sp = blockIdx.x; sp < n_splits; sp += gridDim.x) {
-        const jmac_split_t s = splits[sp];
-        for (int c0 = 0; c0 < W4; c0 += 64) {
-            const int c4 = c0 + lane;
-            float4 a0 = f4zero(), a1 = f4zero();
-            if (c4 < W4) {
-                const float* base = part + ((int64_t)s.pslot0 * W4 + c4) * 4;
-                int c = wave;
-                for (; c + kWavesPerBlock < s.nchunks; c += 2 * kWavesPerBlock) {
-                    a0 = add4(a0, ld4(base + (int64_t)c * W4 * 4));
-                    a1 = add4(a1, ld4(base + (int64_t)(c + kWavesPerBlock) * W4 * 4));
-                }
-                if (c < s.nchunks) a0 = add4(a0, ld4(base + (int64_t)c * W4 * 4));
-            }
-            red[wave][lane] = add4(a0, a1);
-            __syncthreads();
-            if (wave == 0 && c4 < W4) {
-                float4 acc = add4(add4(red[0][lane], red[1][lane]), add4(red[2][lane], red[3][lane]));
-                acc = mul4(acc, sign);
-                if (add_self && c4 >= D4 && s.seg >= self_off && s.seg - self_off < n_self)
-                    acc = fma4(ld4(G + ((int64_t)s.seg - self_off) * ldg + (c4 - D4) * 4), kappa, acc);
-                st4(outp + (int64_t)s.seg * ldout + c4 * 4, acc);
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// column sums of a [R, 4*W4] matrix in two deterministic steps: per-block partials, then one block.
-__global__ __launch_bounds__(kBlock) void colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int64_t R,
-                                                                int W4, float* __restrict__ partial) {
-    // rpb = kBlock / W4 rows are in flight per block (thread = (row lane, float4 column)), 2 loads in flight per thread;
-    // the row lanes are combined through LDS in a fixed order
-    __shared__ float4 red[kBlock];
-    const int tid = threadIdx.x;
-    if (W4 > kBlock) {   // wide rows: one thread per float4 column, looped
-        for (int c4 = tid; c4 < W4; c4 += kBlock) {
-            float4 acc = f4zero();
-            for (int64_t r = blockIdx.x; r < R; r += gridDim.x) acc = add4(acc, ld4(X + r * ldx + c4 * 4));
-            st4(partial + ((int64_t)blockIdx.x * W4 + c4) * 4, acc);
-        }
-        return;
-    }
-    const int rpb = kBlock / W4;
-    const int rl = tid / W4, c4 = tid % W4;
-    float4 a0 = f4zero(), a1 = f4zero();
-    if (rl < rpb) {
-        const int64_t stride = (int64_t)gridDim.x * rpb;
-        int64_t r = (int64_t)blockIdx.x * rpb + rl;
-        for (; r + stride < R; r += 2 * stride) {
-            a0 = add4(a0, ld4(X + r * ldx + c4 * 4));
-            a1 = add4(a1, ld4(X + (r + stride) * ldx + c4 * 4));
-        }
-        if (r < R) a0 = add4(a0, ld4(X + r * ldx + c4 * 4));
-    }
-    red[tid] = add4(a0, a1);
-    __syncthreads();
-    if (tid < W4) {
-        float4 acc = red[tid];
-        for (int q = 1; q < rpb; ++q) acc = add4(acc, red[q * W4 + tid]);
-        st4(partial + ((int64_t)blockIdx.x * W4 + tid) * 4, acc);
-    }
-}
-
-// out[c] = scale * sum_p partial[p][c]: 16 columns x 64 row lanes per 1024-thread block (a block's rows are read as 64-byte
-// segments; 16 columns per block instead of 64 puts 19 blocks instead of 5 on a 300-wide reduction: 6.6 -> ~4 us)
-constexpr int RR_COLS = 16, RR_LANES = 1024 / RR_COLS;
-__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ partial, int nparts, int W, float scale,
-                                                           float* __restrict__ outp) {
-    __shared__ float red[RR_LANES][RR_COLS];
-    const int cl = threadIdx.x % RR_COLS, rl = threadIdx.x / RR_COLS;
-    const int c = blockIdx.x * RR_COLS + cl;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (c < W) {
-        int p = rl;
-        for (; p + 3 * RR_LANES < nparts; p += 4 * RR_LANES) {
-            a0 += partial[(int64_t)p * W + c];
-            a1 += partial[(int64_t)(p + RR_LANES) * W + c];
-            a2 += partial[(int64_t)(p + 2 * RR_LANES) * W + c];
-            a3 += partial[(int64_t)(p + 3 * RR_LANES) * W + c];
-        }
-        for (; p < nparts; p += RR_LANES) a0 += partial[(int64_t)p * W + c];
-    }
-    red[rl][cl] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (rl == 0 && c < W) {
-        float s = red[0][cl];
-#pragma unroll 8
-        for (int r = 1; r < RR_LANES; ++r) s += red[r][cl];
-        outp[c] = s * scale;
     }
 }
 
@@ -1144,53 +1255,68 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
     const int T = 256;
     const unsigned gridA = fwd_grid(by_dst->n_items_max);          // small graphs: one wave per item, like the forward
     const bool slope01 = slope >= 0.f && slope <= 1.f;
+    // column sum of G for the fused self loop (dRz[loop] -= kappa * sum_i G[i]): per-block partials by extra blocks of
+    // the pass-A launch, reduced in the last launch
+    float* colsum_part = (float*)(wsb + w.colsum_part);
+    ColsumTask cs{};
+    cs.X = G; cs.ldx = ldg; cs.R = N; cs.W4 = D4; cs.partial = colsum_part;
+    cs.nblocks = (loop_rel >= 0 && N > 0) ? (int)(N < 512 ? N : 512) : 0;
+    const unsigned gcs = (unsigned)cs.nblocks;
+    auto sum_task = [&](const jmac_view_t* v, const float* part, int W4, float* outp, int64_t ldout, int add_self) {
+        SumPartsTask t{};
+        t.splits = v->splits; t.counts = v->counts; t.part = part; t.W4 = W4; t.sign = 1.f; t.outp = outp; t.ldout = ldout;
+        t.G = G; t.ldg = ldg; t.D4 = D4; t.kappa = out_scale; t.add_self = add_self; t.self_off = self_off; t.n_self = N;
+        t.nblocks = v->n_splits_max > 0 ? (int)split_grid(v->n_splits_max) : 0;
+        return t;
+    };
+    auto reduce_task = [&](const float* partial, int nparts, float scale, float* outp) {
+        ReduceTask t{};
+        t.partial = partial; t.nparts = nparts; t.W = (int)d; t.scale = scale; t.outp = outp;
+        t.nblocks = nparts > 0 ? (int)((d + RT_COLS - 1) / RT_COLS) : 0;
+        return t;
+    };
     if (mode == 0) {
         // dQZ / dRR are accumulated with atomics: initialise them (dZ half of dQZ starts at the self term)
         hipLaunchKernelGGL(init_dqz_kernel, dim3((unsigned)((Nsrc * 2 * d + T - 1) / T)), dim3(T), 0, st, dQZ, lddqz, Nsrc, d, G, ldg,
                            out_scale, loop_rel >= 0 ? 1 : 0, self_off, N);
         hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((nrel * 2 * d + T - 1) / T)), dim3(T), 0, st, dRR, nrel, 2 * d, lddrr, 0.f);
-        JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 0, D4T>), dim3(gridA), dim3(kBlock), 0, st, a));
-    } else {
-        JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 1, D4T>), dim3(gridA), dim3(kBlock), 0, st, a));
+        JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 0, D4T>), dim3(gridA + gcs), dim3(kBlock), 0, st, a,
+                                                  (int)gridA, cs));
+        FinalizeArgs f{};
+        f.sp[0] = sum_task(by_dst, a.part, D4, dP, lddp, 0);
+        f.rd[0] = reduce_task(a.da_part, (int)gridA, 1.f, da);
+        // the fill wrote zeros into dRz[loop]: overwrite it
+        f.rd[1] = reduce_task(colsum_part, (int)gcs, -out_scale, dRR + (int64_t)(loop_rel >= 0 ? loop_rel : 0) * lddrr + d);
+        const int nb = f.sp[0].nblocks + f.rd[0].nblocks + f.rd[1].nblocks;
+        if (nb > 0) hipLaunchKernelGGL(bwd_finalize_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, f);
+        return (int)hipGetLastError();
     }
-    // a_att gradient: deterministic reduction of the per-block partial rows
-    launch_reduce_rows(a.da_part, (int)gridA, (int)d, 1.f, da, st);
-    if (by_dst->n_splits_max > 0)
-        hipLaunchKernelGGL(sum_parts_kernel, dim3(split_grid(by_dst->n_splits_max)), dim3(kBlock), 0, st, by_dst->splits,
-                           by_dst->counts, a.part, D4, 1.f, dP, lddp, nullptr, (int64_t)0, 0, 0.f, 0, (int64_t)0, (int64_t)0);
-
-    // column sum of G for the fused self loop:  dRz[loop] -= kappa * sum_i G[i]
-    float* colsum_part = (float*)(wsb + w.colsum_part);
-    unsigned gcs = 0;
-    if (loop_rel >= 0 && N > 0) {
-        gcs = (unsigned)(N < 512 ? N : 512);
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(gcs), dim3(kBlock), 0, st, G, ldg, N, D4, colsum_part);
-    }
-
-    if (mode != 0) {
-        BwdArgs b = a;
-        b.items = by_src->items; b.splits = by_src->splits; b.counts = by_src->counts; b.order = by_src->order;
-        b.part = (float*)(wsb + w.part_src);
-        b.sign = 1.f; b.add_self = loop_rel >= 0 ? 1 : 0;
-        JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_gather_kernel<NCH, 4, D4T>), dim3(persist_grid(by_src->n_items_max)),
-                                                  dim3(kBlock), 0, st, b, dQZ, lddqz));
-        if (by_src->n_splits_max > 0)
-            hipLaunchKernelGGL(sum_parts_kernel, dim3(split_grid(by_src->n_splits_max)), dim3(kBlock), 0, st, by_src->splits,
-                               by_src->counts, b.part, 2 * D4, 1.f, dQZ, lddqz, G, ldg, D4, out_scale, b.add_self, self_off, N);
-        BwdArgs c = a;
-        c.items = by_rel->items; c.splits = by_rel->splits; c.counts = by_rel->counts; c.order = by_rel->order;
-        c.part = (float*)(wsb + w.part_rel);
-        c.sign = -1.f; c.add_self = 0;
-        JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_gather_kernel<NCH, 4, D4T>), dim3(persist_grid(by_rel->n_items_max)),
-                                                  dim3(kBlock), 0, st, c, dRR, lddrr));
-        if (by_rel->n_splits_max > 0)
-            hipLaunchKernelGGL(sum_parts_kernel, dim3(split_grid(by_rel->n_splits_max)), dim3(kBlock), 0, st, by_rel->splits,
-                               by_rel->counts, c.part, 2 * D4, 1.f, dRR, lddrr, nullptr, (int64_t)0, 0, 0.f, 0, (int64_t)0, (int64_t)0);
-    }
-    if (loop_rel >= 0 && N > 0) {
-        // pass C wrote zeros (mode 1) / the fill wrote zeros (mode 0) into dRz[loop]: overwrite it
-        launch_reduce_rows(colsum_part, (int)gcs, (int)d, -out_scale, dRR + (int64_t)loop_rel * lddrr + d, st);
-    }
+    // ---- deterministic mode: three launches ----------------------------------------------------------------------------
+    // 1. pass A by destination (+ the column-sum partials of G)
+    JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 1, D4T>), dim3(gridA + gcs), dim3(kBlock), 0, st, a,
+                                              (int)gridA, cs));
+    // 2. pass B by source and pass C by relation, side by side
+    BwdArgs b = a;
+    b.items = by_src->items; b.splits = by_src->splits; b.counts = by_src->counts; b.order = by_src->order;
+    b.part = (float*)(wsb + w.part_src);
+    b.sign = 1.f; b.add_self = loop_rel >= 0 ? 1 : 0;
+    BwdArgs c = a;
+    c.items = by_rel->items; c.splits = by_rel->splits; c.counts = by_rel->counts; c.order = by_rel->order;
+    c.part = (float*)(wsb + w.part_rel);
+    c.sign = -1.f; c.add_self = 0;
+    const unsigned gB = persist_grid(by_src->n_items_max), gC = persist_grid(by_rel->n_items_max);
+    JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_gather_kernel<NCH, 4, D4T>), dim3(gB + gC), dim3(kBlock), 0, st, b, dQZ,
+                                              lddqz, (int)gB, c, dRR, lddrr));
+    // 3. every merge: partial rows of the split destinations / sources / relations, da, dRz[loop]
+    FinalizeArgs f{};
+    f.sp[0] = sum_task(by_dst, a.part, D4, dP, lddp, 0);
+    f.sp[1] = sum_task(by_src, b.part, 2 * D4, dQZ, lddqz, b.add_self);
+    f.sp[2] = sum_task(by_rel, c.part, 2 * D4, dRR, lddrr, 0);
+    f.rd[0] = reduce_task(a.da_part, (int)gridA, 1.f, da);
+    // pass C wrote zeros into dRz[loop] (the loop relation has no edges): overwrite it
+    f.rd[1] = reduce_task(colsum_part, (int)gcs, -out_scale, dRR + (int64_t)(loop_rel >= 0 ? loop_rel : 0) * lddrr + d);
+    const int nb = f.sp[0].nblocks + f.sp[1].nblocks + f.sp[2].nblocks + f.rd[0].nblocks + f.rd[1].nblocks;
+    if (nb > 0) hipLaunchKernelGGL(bwd_finalize_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, f);
     return (int)hipGetLastError();
 }
 

@@ -39,6 +39,7 @@ def auto_chunk(n_entries: int, cap: int = 512) -> int:
 # views: measured on config 4 (interleaved repetitions) the forward runs 11.46 / 11.11 / 11.04 / 11.44 ms at 512 / 256 /
 # 128 / 64 entries per item, while the backward's partial-row passes prefer 512 (20.6 ms against 23.3 ms at 128).
 DST_CHUNK_CAP = 256
+SMALL_BWD_CHUNK = 32
 
 
 # cooperative splits (forward kernel, small graphs): rows longer than COOP_MIN and up to COOP_MAX entries are processed by
@@ -156,6 +157,10 @@ class RelGraph:
         else:
             self.dst_of_slot = torch.zeros(1, dtype=torch.int32, device=dev)
 
+        # small graphs: shorter items (a 32-entry item is 8 dependent gather rounds in one wave; the merge pass keeps
+        # four partial rows in flight per lane, so the longer partial lists cost less than the rounds they save)
+        chunk_bwd = min(self.chunk, SMALL_BWD_CHUNK) if self.by_dst.item_edges is not None else self.chunk
+
         def group(keys: torch.Tensor, n_seg: int) -> _Schedule:
             seg_ptr = torch.empty(n_seg + 1, dtype=torch.int32, device=dev)
             order = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
@@ -163,7 +168,7 @@ class RelGraph:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             check(L.jmac_group_build(ptr(keys), E, n_seg, ptr(seg_ptr), ptr(order), ptr(ws), ws_bytes, stream()),
                   "jmac_group_build")
-            return _Schedule(seg_ptr, n_seg, E, self.chunk, order)
+            return _Schedule(seg_ptr, n_seg, E, chunk_bwd, order)
 
         self.by_src = group(self.col, self.num_src)
         self.by_rel = group(self.etype, self.num_rel)
