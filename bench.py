@@ -723,6 +723,8 @@ def main():
     def init_dist():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))      # JMAC_BENCH_FORCE_DIST on a bare command line
         if os.environ.get("JMAC_BENCH_SHARE_GPU"):         # RCCL refuses two ranks on one device: the debugging aid runs
             dist.init_process_group("gloo", rank=rank, world_size=world)   # the collectives through gloo (host staging)
             return

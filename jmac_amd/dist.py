@@ -135,15 +135,23 @@ class _AllGatherRows(torch.autograd.Function):
     ``defer``: start the collective and return at once -- RCCL runs it on its own stream; the caller enqueues independent
     work on the compute stream and calls ``pending_wait()`` before the first kernel that reads the gathered table."""
 
-    pending = None          # (work handle, profile start event, output) of a deferred all-gather
+    pending = None          # (work handle, profile start event, gathered buffer, fp32 output or None) of a deferred all-gather
 
     @staticmethod
-    def forward(ctx, x, group, defer=False):
+    def forward(ctx, x, group, defer=False, wire_dtype=None):
         ctx.group = group
         world = _world(group)
         if _skip(group):
+            if wire_dtype is not None and wire_dtype != x.dtype:
+                return x.to(wire_dtype).to(x.dtype)          # one rank: the same rounding as the wire would apply
             return x
         x = x.contiguous()
+        final = None
+        if wire_dtype is not None and wire_dtype != x.dtype:
+            # reduced-precision WIRE format: the table travels as bf16 (half the xGMI bytes) and is widened again on
+            # arrival; everything downstream (gathers, logits, sums) stays fp32 arithmetic on the rounded values
+            final = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            x = x.to(wire_dtype)
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         e0 = _cev(x)
         if x.is_cuda and dist.get_backend(group) == "gloo":           # tests only: stage through the host
@@ -152,38 +160,44 @@ class _AllGatherRows(torch.autograd.Function):
             out.copy_(h)
         elif defer:
             work = dist.all_gather_into_tensor(out, x, group=group, async_op=True)
-            _AllGatherRows.pending = (work, e0, out)
-            return out
+            _AllGatherRows.pending = (work, e0, out, final)
+            return final if final is not None else out
         else:
             dist.all_gather_into_tensor(out, x, group=group)
         _cdone("all_gather_qz", e0, out)
+        if final is not None:
+            final.copy_(out)
+            return final
         return out
 
     @staticmethod
     def pending_wait() -> None:
-        """Make the compute stream wait for the deferred all-gather (no host block under RCCL)."""
+        """Make the compute stream wait for the deferred all-gather (no host block under RCCL); a reduced-precision wire
+        buffer is widened into the fp32 table the caller already holds."""
         p, _AllGatherRows.pending = _AllGatherRows.pending, None
         if p is not None:
-            work, e0, out = p
+            work, e0, out, final = p
             work.wait()
             _cdone("all_gather_qz", e0, out)
+            if final is not None:
+                final.copy_(out)
 
     @staticmethod
     def backward(ctx, g):
         world = _world(ctx.group)
         if _skip(ctx.group):
-            return g, None, None
+            return g, None, None, None
         g = g.contiguous()
         n = g.shape[0] // world
         if dist.get_backend(ctx.group) == "gloo":          # gloo has no reduce_scatter: all-reduce + slice
             _all_reduce(g, ctx.group)
             r = dist.get_rank(ctx.group)
-            return g[r * n:(r + 1) * n].clone(), None, None
+            return g[r * n:(r + 1) * n].clone(), None, None, None
         out = torch.empty((n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
         e0 = _cev(g)
         dist.reduce_scatter_tensor(out, g, group=ctx.group)
         _cdone("reduce_scatter_dqz", e0, g)
-        return out, None, None
+        return out, None, None, None
 
 
 class _AllReduceSum(torch.autograd.Function):
@@ -205,8 +219,8 @@ class _AllReduceSum(torch.autograd.Function):
         return g, None
 
 
-def all_gather_rows(x: torch.Tensor, group=None, defer: bool = False) -> torch.Tensor:
-    return _AllGatherRows.apply(x, group, bool(defer))
+def all_gather_rows(x: torch.Tensor, group=None, defer: bool = False, wire_dtype=None) -> torch.Tensor:
+    return _AllGatherRows.apply(x, group, bool(defer), wire_dtype)
 
 
 def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
@@ -410,12 +424,19 @@ class ShardedRelationAwareLayer(nn.Module):
     tanh run on the fused phased kernels with the statistics combined across ranks (``sync_bn_tanh``).  With an injected
     ``local_aggregate`` (CPU test double) the torch formulation of the same steps is used."""
 
-    def __init__(self, layer: nn.Module, group=None, local_aggregate: Optional[Callable] = None, bn_kernels=None):
+    def __init__(self, layer: nn.Module, group=None, local_aggregate: Optional[Callable] = None, bn_kernels=None,
+                 wire_dtype=None):
         super().__init__()
         self.layer = layer                       # a jmac_amd.layer.RelationAwareLayer (holds the parameters)
         self.group = group
         self.local_aggregate = local_aggregate
         self.bn_kernels = bn_kernels
+        # None / torch.float32: the [Q|Z] table crosses xGMI in fp32 (default: results equal the one-GPU layer's).
+        # torch.bfloat16: it crosses as bf16 -- half the bytes of the exchange that bounds the 8-GPU step (16.8 GB
+        # received per GPU and layer at config 4 x 8) -- and is widened on arrival; the gathered Q / Z values then
+        # carry bf16 rounding (relative 2^-9 per element; measured on the layer output: tests/test_dist_gloo.py), the
+        # rank's own P, the relation tables, logits, softmax, sums and BN stay fp32.  The backward exchanges fp32.
+        self.wire_dtype = wire_dtype
 
     def forward(self, x_local: torch.Tensor, rel_emb: torch.Tensor, sg: ShardedGraph) -> torch.Tensor:
         L = self.layer
@@ -433,7 +454,7 @@ class ShardedRelationAwareLayer(nn.Module):
         Z_loc = QZ_loc[:, d:]
         if sg.n_local < sg.n_max:                                    # pad to the common slab height
             QZ_loc = F.pad(QZ_loc, (0, 0, 0, sg.n_max - sg.n_local))
-        QZ = all_gather_rows(QZ_loc.contiguous(), self.group, defer=True)   # [world*n_max, 2d], in flight
+        QZ = all_gather_rows(QZ_loc.contiguous(), self.group, defer=True, wire_dtype=self.wire_dtype)   # [world*n_max, 2d], in flight
         P = torch.mm(x_local, L.w_att[:d_in])
         rel = L.transform_relations(rel_emb)
         RR = L._rel_mm(rel, wqz)

@@ -82,7 +82,8 @@ def _worker(rank, world, port, ret):
         torch.manual_seed(11)
         base = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())
         lay = ShardedRelationAwareLayer(base, local_aggregate=_standin_aggregate,
-                                        bn_kernels=_StandinBN if os.environ.get("JMAC_TEST_FUSED_BN") else None).train()
+                                        bn_kernels=_StandinBN if os.environ.get("JMAC_TEST_FUSED_BN") else None,
+                                        wire_dtype=torch.bfloat16 if os.environ.get("JMAC_TEST_WIRE_BF16") else None).train()
         x = X[sg.lo:sg.hi].clone().requires_grad_(True)
         r = R.clone().requires_grad_(True)
         out = lay(x, r, sg)
@@ -149,3 +150,45 @@ def test_partition_rows_balances_edges():
     owner = (ei[1][(ei[0] >= 30)] >= 30).astype(int)
     src = ei[1][ei[0] >= 30]
     assert (sg.src_padded == owner * 70 + (src - b[owner])).all()
+
+
+@pytest.mark.timeout(300)
+def test_bf16_wire_format_rounds_only_the_gathered_table(monkeypatch):
+    """wire_dtype=bfloat16: the [Q|Z] table crosses the all-gather as bf16 and is widened on arrival.  The sharded
+    result must equal the single-process layer evaluated with Q and Z rounded to bf16 -- the ONLY change -- at fp32
+    tolerance (the rank's own P, the relation tables, logits, sums and BN stay fp32), and the distance to the fp32
+    layer is the stated price of the flag: ~2^-9 relative on the gathered rows, a few 1e-3 on the tanh-bounded output."""
+    world = 2
+    monkeypatch.setenv("JMAC_TEST_WIRE_BF16", "1")
+    monkeypatch.setenv("JMAC_TEST_FUSED_BN", "1")
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    ei, et, X, R, G, n, nr, d = _case()
+    from jmac_amd.layer import RelationAwareLayer
+    torch.manual_seed(11)
+    base = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())
+    p = {k: v.detach().clone() for k, v in base.named_parameters()}
+    eit, ett = torch.from_numpy(ei), torch.from_numpy(et)
+    with torch.no_grad():
+        # single-process restatement with the wire rounding applied to Q | Z and nothing else
+        rel = orc.transform_relations(p, R, 0.05, "leaky_relu")
+        wt, wb, wg = p["w_att"][:d], p["w_att"][d:], p["gcn_weight"]
+        P = X @ wt
+        QZ = torch.cat([X @ wb, X @ wg], 1).to(torch.bfloat16).float()
+        RR = torch.cat([rel @ wb, rel @ wg], 1)
+        dst, src = eit[0], eit[1]
+        diff = QZ[src] - RR[ett]
+        sc = torch.nn.functional.leaky_relu(P[dst] + diff[:, :d], 0.05) @ p["a_att"]
+        alpha = orc.scatter_softmax(sc, dst, n)
+        deg = orc.scatter_sum(torch.ones(dst.shape[0]), dst, n)
+        nb = orc.scatter_sum(alpha * diff[:, d:], dst, n) * deg.sqrt().view(-1, 1)
+        # self term: this test's torch stand-in adds the rank's OWN fp32 Z rows; the product's fused kernel reads them from
+        # the gathered table instead (jmac_amd/dist.py hip_local_layer), i.e. bf16-rounded like every other gathered row
+        pre = (nb + X @ wg - RR[-1, d:]) * 0.5
+        want = torch.tanh(torch.nn.functional.batch_norm(pre, None, None, p["bn.weight"], p["bn.bias"], True, 0.0, 1e-5))
+        fp32 = orc.layer_forward(p, X, R, eit, ett, 0.05, "sub", "leaky_relu", True, torch.zeros(d), torch.ones(d))
+    got = torch.cat([ret[r]["out"] for r in range(world)])
+    assert torch.allclose(got, want, atol=3e-5), float((got - want).abs().max())
+    err = float((got - fp32).abs().max())
+    assert 1e-5 < err < 3e-2, err                     # the flag is not free -- and not wild either
