@@ -92,9 +92,13 @@ class JMAC(nn.Module):
         comp_att = self.ent_init_att_completion[e0:e1]
         rel_comp = self.rel_init_att_completion[r0:r1]
         rel_align = self.rel_init_att_alignment[r0:r1]
-        name_att = torch.mm(self.ent_info_att[e0:e1].to(dev), self.name_linear)
         comp0 = self.completion_dropout(ops.row_normalize(comp_att))
-        align0 = torch.mm(torch.cat((comp0, name_att), dim=1), self.uni_linear1_1)
+        # :177 + :180  cat(comp0, info @ name_linear) @ W  ==  cat(comp0, info) @ [W_top ; name_linear @ W_bottom]:
+        # the [N,300]x[300,300] product of the constant name embeddings (and its [N,300]x[300,300] adjoint) becomes a
+        # [300,300]x[300,300] product of the two parameters -- same function, two N-row GEMMs fewer per step
+        d = self.entity_dim
+        w = torch.cat((self.uni_linear1_1[:d], torch.mm(self.name_linear, self.uni_linear1_1[d:])), dim=0)
+        align0 = torch.mm(torch.cat((comp0, self.ent_info_att[e0:e1].to(dev)), dim=1), w)
         a1 = self.conv1_alignment(align0, rel_align, edge_index, edge_type)
         align_layers, comp_layers, comp_rel_layers = [align0, a1], [comp_att], [rel_comp]
         if self.args.num_gcn_layer == 2:
