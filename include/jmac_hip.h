@@ -323,6 +323,15 @@ int jmac_gemm_f32(const float* A, int64_t lda, int32_t transA, const float* B, i
                   int32_t transB, int64_t M, int64_t N, int64_t K, float* C, int64_t ldc,
                   jmac_stream_t stream);
 
+/* fp32 GEMM on the bf16 matrix cores for the N-row dense products of the encoder and of the factorised layer
+ * (replaces torch.mm at src/jmac_model.py:177-203 and the hoisted X [Wt|Wb|Wg] projection / its adjoint):
+ *   C[M,N] = A[M,K] B[N,K]^T   ("NT": both operands k-contiguous; a weight W [K,N] is passed as its transpose),
+ * fp32 in, fp32 out.  Each operand element is split into three bf16 terms (24 mantissa bits) while it is staged and the
+ * six significant term pairs are accumulated in fp32: fp32-GEMM-level error at 6/16 of the fp32 MFMA's issue time.
+ * K % 4 == 0, lda / ldb % 4 == 0 (16-byte rows), any M, N. */
+int jmac_gemm_nt_x3_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N,
+                        int64_t K, float* C, int64_t ldc, jmac_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Loss gathers.  Indices are the reference's int64 tensors (batch_h /
  * batch_r / batch_t, links, neg_left ...), values in range; rows may have any d (16-byte aligned rows

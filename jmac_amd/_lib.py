@@ -81,6 +81,7 @@ _SIGS = {
     "jmac_col_softmax_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, f32, f32, vp, i64, vp, vp, sz, vp]),
     "jmac_csls_rank_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, vp]),
     "jmac_csls_apply_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, i64, vp]),
+    "jmac_gemm_nt_x3_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, vp]),
     "jmac_gemm_f32": (C.c_int, [vp, i64, i32, vp, i64, i32, i64, i64, i64, vp, i64, vp]),
     "jmac_triple_l1_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp]),
     "jmac_triple_l1_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp, i64, vp, i64, vp]),

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p /tmp/jv_$name
 for f in $R/jmac_amd/csrc/*.hip; do
   b=$(basename $f .hip)
-  if [ "$b" == "aggregate" ]; then
+  if [ "$b" == "${VARIANT_FILE:-aggregate}" ]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$R/include -I$R/jmac_amd/csrc "$@" -c $f -o /tmp/jv_$name/$b.o &
   else
     cp $R/build/$b.o /tmp/jv_$name/$b.o 2>/dev/null || /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$R/include -I$R/jmac_amd/csrc -c $f -o /tmp/jv_$name/$b.o &
