@@ -99,6 +99,8 @@ def parse():
     ap.add_argument("--bwd-mode", type=int, default=1)
     ap.add_argument("--synth-scale", type=float, default=1.0, help="scale of the config-4 side measurement")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the first pass")
+    ap.add_argument("--wire-bf16", action="store_true",
+                    help="sharded workload: the [Q|Z] all-gather travels as bf16 (not the reference's fp32 result: see DESIGN.md)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher self-test: every rank prints its RANK/WORLD_SIZE/LOCAL_RANK as one JSON line and exits "
                          "before touching the GPU")
@@ -661,7 +663,7 @@ def synth_measure(a, device, cpu=True):
            "fwd_ms": r["fwd_ms"], "fwd_edges_per_s": e / (r["fwd_ms"] * 1e-3),
            "fwd_GBps": fb / (r["fwd_ms"] * 1e-3) / 1e9, "fwd_frac_hbm": fb / (r["fwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "fwd_traffic_bytes": pmc_traffic("config4", "rel_attn_fwd_kernel") if (a.dim == 300 and a.synth_scale == 1.0) else None,
-           "fwd_traffic_source": "profiles/r1_pmc_config4.json (committed rocprofv3 --pmc passes; not collected by this run)",
+           "fwd_traffic_source": "profiles/r2_pmc_config4.json (committed rocprofv3 --pmc passes; not collected by this run)",
            "bwd_ms": r["bwd_ms"], "bwd_GBps": bb / (r["bwd_ms"] * 1e-3) / 1e9,
            "bwd_frac_hbm": bb / (r["bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bwd_bytes": "SURVEY 8d backward formula",
            "bwd_edges_per_s": e / (r["bwd_ms"] * 1e-3)}
@@ -675,10 +677,10 @@ def synth_measure(a, device, cpu=True):
 
 
 def pmc_traffic(key, kernel_prefix):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_<key>.json), or None.
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r2_pmc_<key>.json), or None.
     PMC collection needs rocprofv3 around the process, so bench.py reports the committed measurement."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_%s.json" % key)))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_%s.json" % key)))
         for k, v in d["kernels"].items():
             if k.startswith(kernel_prefix):
                 return v["traffic_bytes_corrected"]
@@ -780,7 +782,7 @@ def main():
     ms = el / a.steps * 1e3
     layer_calls = 3
     value = world * layer_calls * w.E * a.steps / el
-    roof_src = "profiles/r1_pmc_ja.json (committed rocprofv3 --pmc passes; not collected by this run)"
+    roof_src = "profiles/r2_pmc_ja.json (committed rocprofv3 --pmc passes; not collected by this run)"
     if dist_on:
         # N > 1: the headline is the path that actually shards -- BASELINE config 4 weak-scaled, destination-sharded, RCCL
         # all-gather / reduce-scatter per layer (north_star: "Partition ... across the 8 GPUs ... only when the graph

@@ -41,7 +41,8 @@ def run_sharded(a, rank, world, device):
     del ei, et
     torch.manual_seed(7)                                              # identical replicated parameters on every rank
     largs = types.SimpleNamespace(leaky_relu_w=0.05, comp_op="sub")
-    layers = [ShardedRelationAwareLayer(RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=largs).to(device))
+    wire = torch.bfloat16 if getattr(a, "wire_bf16", False) else None
+    layers = [ShardedRelationAwareLayer(RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=largs).to(device), wire_dtype=wire)
               for _ in range(2)]
     rel = torch.nn.Parameter(torch.randn(nr, d, device=device) * (2.0 / (nr + d)) ** 0.5)
     gen = torch.Generator(device=device).manual_seed(100 + rank)
@@ -114,6 +115,7 @@ def run_sharded(a, rank, world, device):
                                    "in-degree), d=%d; 2 stacked RelationAwareLayers fwd+bwd + grad all-reduce + Adam; "
                                    "destination-sharded, all-gather of [Q|Z] per layer" % (n_loc, e_loc, nr, d),
                        "global_entities": n_loc * world, "global_triples": e_total, "parallelism": "dst-shard x%d" % world,
+                       "wire": "bf16 [Q|Z] all-gather (flag)" if wire is not None else "fp32",
                        "edges_counted_per_step": 2 * e_total},
             "roofline": {"bound": "hbm", "kernel": "rel_attn_fwd_kernel (rank 0, local rows)", "achieved": fb / (fms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,

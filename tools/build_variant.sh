@@ -1,5 +1,5 @@
 #!/bin/bash
-# build an A/B variant of the library: scratch/build_variant.sh <name> <extra hipcc flags...>  -> /tmp/jmac_<name>.so
+# build an A/B variant of the library: tools/build_variant.sh <name> <extra hipcc flags...>  -> /tmp/jmac_<name>.so
 name=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p /tmp/jv_$name

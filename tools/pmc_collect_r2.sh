@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 PMC passes for the aggregation kernels, one counter group per pass (MI355X_MICROARCH.md: FETCH_SIZE and
 # WRITE_SIZE do not fit one pass; --pmc only with --kernel-trace-free runs).  usage (repo root, GPU box):
-#   bash scratch/pmc_collect_r2.sh <out_dir>
+#   bash tools/pmc_collect_r2.sh <out_dir>
 OUT=${1:-gpurun_out/pmc_r2}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/$OUT
@@ -12,8 +12,8 @@ run() {  # name counters... -- program args
 }
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | tr ' ' '+')
-  run c4_$tag "$c" python3 $R/scratch/agg_sweep.py 1.0 auto 300 1
-  DBG=samerel run c4samerel_$tag "$c" python3 $R/scratch/agg_sweep.py 1.0 auto 300 0
-  run ja_$tag "$c" python3 $R/scratch/ja_sweep.py ja
+  run c4_$tag "$c" python3 $R/tools/agg_sweep.py 1.0 auto 300 1
+  DBG=samerel run c4samerel_$tag "$c" python3 $R/tools/agg_sweep.py 1.0 auto 300 0
+  run ja_$tag "$c" python3 $R/tools/ja_sweep.py ja
 done
 ls $R/$OUT | head -40

@@ -1,4 +1,4 @@
-"""rocprofv3 --pmc CSVs of scratch/pmc_collect_r2.sh -> profiles/r2_pmc_agg.json: per kernel the mean FETCH_SIZE / WRITE_SIZE
+"""rocprofv3 --pmc CSVs of tools/pmc_collect_r2.sh -> profiles/r2_pmc_agg.json: per kernel the mean FETCH_SIZE / WRITE_SIZE
 (KB), the L2 hit rate TCC_HIT / (TCC_HIT + TCC_MISS), and the corrected fabric traffic.
 Correction (MI355X_MICROARCH.md, HBM): on gfx950 FETCH_SIZE tallies the 128-B requests of 16-B/lane reads at 64 B -> x2;
 WRITE_SIZE is exact for 16-B/lane stores.  The x2 is CALIBRATED here on this kernel's own access pattern: the samerel
