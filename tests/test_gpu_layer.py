@@ -92,21 +92,12 @@ def _kink_flips(lay, p64, X64, R64, ei, et, Xg, Rg):
     return int(((h32 > 0) != (h64 > 0)).sum())
 
 
-@pytest.mark.parametrize("n,nr,d,e,hub,chunk", [
-    (600, 25, 300, 5000, 700, 64),      # d=300 (BASELINE dim), a hub split into 11 chunks
-    (500, 17, 256, 4000, 300, 128),     # d=256 (reference default)
-    (300, 9, 128, 2500, None, 256),
-    (257, 6, 20, 1500, 200, 32),        # NCH=1, tiny d
-    (200, 8, 512, 900, None, 256),      # max d
-    (150, 5, 30, 700, 100, 16),         # d % 4 != 0 -> host pads to 32
-])
-@pytest.mark.parametrize("mode", [1, 0])
-def test_layer_matches_oracle_random(n, nr, d, e, hub, chunk, mode):
+def _check_random_layer(n, nr, d, e, hub, chunk, mode, seed, lay_seed, strict):
     """Oracle evaluated in float64: an fp32 CPU evaluation can land on the other side of a LeakyReLU kink
     (observed at d=512: fp32-CPU vs f64 differ by 2e-2 in grad w_att while HIP-fp32 vs f64 agree to 1e-6)."""
     from jmac_amd.layer import RelationAwareLayer
-    ei, et, X, R, G = _oracle_case(n, nr, d, e, seed=n + d, hub=hub)
-    torch.manual_seed(d)
+    ei, et, X, R, G = _oracle_case(n, nr, d, e, seed=seed, hub=hub)
+    torch.manual_seed(lay_seed)
     lay = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())
     with torch.no_grad():
         lay.bn.weight.uniform_(0.5, 1.5)
@@ -124,6 +115,8 @@ def test_layer_matches_oracle_random(n, nr, d, e, hub, chunk, mode):
     assert_close(out, ref, RTOL, 1e-6, "out")
     (out * G.cuda()).sum().backward()
     flips = _kink_flips(lay, {k: v.detach() for k, v in p.items()}, Xc.detach(), Rc.detach(), ei, et, Xg.detach(), Rg.detach())
+    if strict:
+        assert flips == 0, flips                                     # seed chosen flip-free (tools/flip_probe.py)
     assert flips <= 3, flips                                         # a handful at most out of e*d pre-activations
     grtol = RTOL if flips == 0 else 5e-2                             # see _kink_flips (one flip moved grad w_att by 1.4 %)
     assert_close(Xg.grad, Xc.grad, grtol, 1e-6, "grad_X")
@@ -132,6 +125,28 @@ def test_layer_matches_oracle_random(n, nr, d, e, hub, chunk, mode):
     for name, prm in lay.named_parameters():
         atol = 1e-4 * gscale + 1e-6 if name == "loop_rel" else 1e-6
         assert_close(prm.grad, p[name].grad, grtol, atol, "grad " + name)
+
+
+@pytest.mark.parametrize("n,nr,d,e,hub,chunk", [
+    (600, 25, 300, 5000, 700, 64),      # d=300 (BASELINE dim), a hub split into 11 chunks
+    (500, 17, 256, 4000, 300, 128),     # d=256 (reference default)
+    (300, 9, 128, 2500, None, 256),
+    (257, 6, 20, 1500, 200, 32),        # NCH=1, tiny d
+    (200, 8, 512, 900, None, 256),      # max d
+    (150, 5, 30, 700, 100, 16),         # d % 4 != 0 -> host pads to 32
+])
+@pytest.mark.parametrize("mode", [1, 0])
+def test_layer_matches_oracle_random(n, nr, d, e, hub, chunk, mode):
+    _check_random_layer(n, nr, d, e, hub, chunk, mode, seed=n + d, lay_seed=d, strict=False)
+
+
+@pytest.mark.parametrize("seed", [100, 101, 102])
+@pytest.mark.parametrize("n,nr,d,e,hub,chunk", [(600, 25, 300, 5000, 700, 64), (500, 17, 256, 4000, 300, 128)])
+def test_layer_gradients_at_1e4_on_flip_free_seeds(n, nr, d, e, hub, chunk, seed):
+    """The BASELINE dims (d=300, and the reference's default d=256) with NO tolerance escape: these seeds have no attention
+    pre-activation whose sign differs between the fp32 tables and the float64 oracle (tools/flip_probe.py scanned seeds
+    100-139: 0 flips for 100-119 at d=300, for 100-106 at d=256), so forward and every gradient must meet 1e-4 outright."""
+    _check_random_layer(n, nr, d, e, hub, chunk, 1, seed=seed, lay_seed=seed, strict=True)
 
 
 def test_deterministic_backward_is_bitwise_reproducible():
