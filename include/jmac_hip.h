@@ -100,8 +100,10 @@ int jmac_items_build(const int32_t* ptr, int64_t S, int32_t chunk, int32_t coop_
                      jmac_item_t* items, jmac_split_t* splits, int32_t* counts, void* ws, size_t ws_bytes,
                      jmac_stream_t stream);
 
-/* item_edges [n_items_max][4] int32 = {col[beg], etype[beg], col[beg+1], etype[beg+1]} per item of the by-destination
- * schedule (-1 where the item is shorter): optional input of the forward kernels (small graphs). */
+/* item_edges [n_items_max][4] int32 = {col[beg], etype[beg], col[beg+1], etype[beg+1]} per item (-1 where the item is
+ * shorter): the first two entries of an item inline with its header, optional input of the kernels on small graphs (one
+ * dependent round trip fewer per wavefront).  By-destination schedule: col / etype of the CSR (forward, backward pass A).
+ * By-source / by-relation schedules: pass `order` as col and the view's `entry_dst` as etype (backward passes B / C). */
 int jmac_item_edges_build(const jmac_item_t* items, const int32_t* counts, int64_t n_items_max,
                           const int32_t* col, const int32_t* etype, int32_t* item_edges,
                           jmac_stream_t stream);
@@ -120,6 +122,8 @@ typedef struct {
     int64_t n_items_max, n_splits_max, n_parts_max;
     const int32_t* item_edges;   /* jmac_item_edges_build's array for `items`, or NULL */
     int64_t n_empty, n_coop;
+    const int32_t* entry_dst;    /* by-source / by-relation views: destination node of every entry IN GROUPED ORDER
+                                  * (= dst_of_slot[order[x]]; saves the backward a dependent load), or NULL */
 } jmac_view_t;
 
 /* ---------------------------------------------------------------------------------------------

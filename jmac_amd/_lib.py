@@ -27,7 +27,7 @@ class View(C.Structure):
     """jmac_view_t"""
     _fields_ = [("ptr", vp), ("order", vp), ("items", vp), ("splits", vp), ("counts", vp),
                 ("n_items_max", i64), ("n_splits_max", i64), ("n_parts_max", i64),
-                ("item_edges", vp), ("n_empty", i64), ("n_coop", i64)]
+                ("item_edges", vp), ("n_empty", i64), ("n_coop", i64), ("entry_dst", vp)]
 
 
 # name -> (restype, argtypes); mirrors include/jmac_hip.h one to one

@@ -747,6 +747,11 @@ struct BwdArgs {
     unsigned char* bits;      // [E, 64] sign bits of h_e: lane's byte = nibble per h-role chunk
     float sign;               // pass B: +1, pass C: -1
     int32_t add_self;         // pass B: add g_j to the Z half
+    // small graphs (one wave per item, bound by dependent round trips): the first two entries of every item inline with its
+    // header -- pass A: {col, type} pairs, passes B / C: {CSR slot, destination} pairs -- or NULL
+    const int4* item_edges;
+    const int32_t* entry_dst; // passes B / C: destination of each entry in GROUPED order (= dst_of_slot[order[x]]), or NULL
+    int32_t n_items_max;      // bound of items[] (host value): headers are fetched before the device-side count arrives
 };
 
 // Pass A: by destination.  MODE 0: float atomics into dQZ / dRR.  MODE 1: per-edge records.
@@ -778,9 +783,39 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a, int
     const bool has_loop = a.loop_rel >= 0;
     const float* rloop = a.RR + (int64_t)(has_loop ? a.loop_rel : 0) * a.ldrr;
 
-    for (int it = blockIdx.x * kWavesPerBlock + wave; it < n_items; it += nwaves) {
-        const jmac_item_t item = a.items[it];
+    // the first header (and the item's first two entries) at a clamped index: they do not wait for the device-side count
+    const int it0 = blockIdx.x * kWavesPerBlock + wave;
+    jmac_item_t item = a.items[min(it0, a.n_items_max - 1)];
+    int4 e4 = make_int4(0, 0, 0, 0);
+    if (a.item_edges) e4 = a.item_edges[min(it0, a.n_items_max - 1)];
+    for (int it = it0; it < n_items; it += nwaves) {
+        if (it != it0) {
+            item = a.items[it];
+            if (a.item_edges) e4 = a.item_edges[it];
+        }
         const int i = item.seg;
+        // first batch of entries: requested BEFORE the destination's own rows, so that the first gathers follow the rows'
+        // round trip directly (items of up to two entries carry them inline: no request at all)
+        int fcol, ftyp;
+        {
+            const int nb0 = min(64, item.end - item.beg);
+            if (a.item_edges && nb0 <= 2) {
+                fcol = (lane == 0 || nb0 < 2) ? e4.x : e4.z;
+                ftyp = (lane == 0 || nb0 < 2) ? e4.y : e4.w;
+            } else {
+                const int idx = nb0 > 0 ? item.beg + min(lane, nb0 - 1) : 0;
+                fcol = a.col[idx];
+                ftyp = a.etype[idx];
+            }
+        }
+        if (item.beg == item.end && item.pslot < 0) {
+            // a destination without in-edges (more than half of a DBP-5L graph) contributes dP[i] = 0 and nothing else:
+            // none of its rows is read.  (An empty QUARTER of a cooperative segment owns a partial slot: general path.)
+#pragma unroll
+            for (int k = 0; k < NCH_H; ++k)
+                if (L.valid[k] && L.is_h[k]) st4(a.dP + (int64_t)i * a.lddp + L.coff[k], f4zero());
+            continue;
+        }
         float4 pv[NCH_H], gv[NCH], accP[NCH_H];
         float tpart = 0.f;
         const float* prow = a.P + (int64_t)i * a.ldp;
@@ -812,8 +847,11 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a, int
         for (int e0 = item.beg; e0 < item.end; e0 += 64) {
             const int nb = min(64, item.end - e0);
             const int le = min(lane, nb - 1);
-            const int my_col = a.col[e0 + le];
-            const int my_typ = a.etype[e0 + le];
+            int my_col = fcol, my_typ = ftyp;
+            if (e0 != item.beg) {
+                my_col = a.col[e0 + le];
+                my_typ = a.etype[e0 + le];
+            }
             float my_w = 0.f, my_ds = 0.f;
             auto group = [&](auto uu_c, const int u0) {
                 constexpr int UU = decltype(uu_c)::value;
@@ -942,7 +980,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs ab,
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = nblk * kWavesPerBlock;
-    const int n_items = a.counts[0];
+    const int n_items = min(a.counts[0], a.n_items_max);
     Lanes<NCH, D4T> L;
     L.init(lane, a.D4);
     const int voff = 4 * L.D4();
@@ -954,8 +992,15 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs ab,
 #pragma unroll
     for (int k = 0; k < NCH; ++k) goff[k] = L.is_v(k) ? L.coff[k] - voff : 0;
 
-    for (int it = bid * kWavesPerBlock + wave; it < n_items; it += nwaves) {
-        const jmac_item_t item = a.items[it];
+    const int it0 = bid * kWavesPerBlock + wave;
+    jmac_item_t item = a.items[max(min(it0, a.n_items_max - 1), 0)];     // clamped: does not wait for the device-side count
+    int4 e4 = make_int4(0, 0, 0, 0);
+    if (a.item_edges) e4 = a.item_edges[max(min(it0, a.n_items_max - 1), 0)];
+    for (int it = it0; it < n_items; it += nwaves) {
+        if (it != it0) {
+            item = a.items[it];
+            if (a.item_edges) e4 = a.item_edges[it];
+        }
         const int seg = item.seg;
         float4 acc[NCH];
 #pragma unroll
@@ -963,8 +1008,14 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs ab,
         for (int x0 = item.beg; x0 < item.end; x0 += 64) {
             const int nb = min(64, item.end - x0);
             const int le = min(lane, nb - 1);
-            const int my_slot = a.order[x0 + le];
-            const int my_dst = a.dst_of_slot[my_slot];
+            int my_slot, my_dst;
+            if (a.item_edges && x0 == item.beg && nb <= 2) {        // both entries arrived with the header
+                my_slot = (lane == 0 || nb < 2) ? e4.x : e4.z;
+                my_dst = (lane == 0 || nb < 2) ? e4.y : e4.w;
+            } else {
+                my_slot = a.order[x0 + le];
+                my_dst = a.entry_dst ? a.entry_dst[x0 + le] : a.dst_of_slot[my_slot];
+            }
             const float2 my_wd = a.wds[my_slot];
             auto group = [&](auto uu_c, const int u0) {
                 constexpr int UU = decltype(uu_c)::value;
@@ -1251,6 +1302,9 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
     a.wds = (float2*)(wsb + w.wds);
     a.bits = (unsigned char*)(wsb + w.bits);
     a.sign = 1.f; a.add_self = 0;
+    a.item_edges = reinterpret_cast<const int4*>(by_dst->item_edges);
+    a.entry_dst = nullptr;
+    a.n_items_max = (int32_t)(by_dst->n_items_max > 0 ? by_dst->n_items_max : 1);
 
     const int T = 256;
     const unsigned gridA = fwd_grid(by_dst->n_items_max);          // small graphs: one wave per item, like the forward
@@ -1300,10 +1354,14 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
     b.items = by_src->items; b.splits = by_src->splits; b.counts = by_src->counts; b.order = by_src->order;
     b.part = (float*)(wsb + w.part_src);
     b.sign = 1.f; b.add_self = loop_rel >= 0 ? 1 : 0;
+    b.item_edges = reinterpret_cast<const int4*>(by_src->item_edges); b.entry_dst = by_src->entry_dst;
+    b.n_items_max = (int32_t)(by_src->n_items_max > 0 ? by_src->n_items_max : 1);
     BwdArgs c = a;
     c.items = by_rel->items; c.splits = by_rel->splits; c.counts = by_rel->counts; c.order = by_rel->order;
     c.part = (float*)(wsb + w.part_rel);
     c.sign = -1.f; c.add_self = 0;
+    c.item_edges = reinterpret_cast<const int4*>(by_rel->item_edges); c.entry_dst = by_rel->entry_dst;
+    c.n_items_max = (int32_t)(by_rel->n_items_max > 0 ? by_rel->n_items_max : 1);
     const unsigned gB = persist_grid(by_src->n_items_max), gC = persist_grid(by_rel->n_items_max);
     JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_gather_kernel<NCH, 4, D4T>), dim3(gB + gC), dim3(kBlock), 0, st, b, dQZ,
                                               lddqz, (int)gB, c, dRR, lddrr));

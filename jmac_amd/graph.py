@@ -75,18 +75,19 @@ class _Schedule:
         self.n_empty = int(n_empty)            # empty segments = the last n_empty items of the schedule
         self.n_coop = int(n_coop)              # cooperative segments = the first 4 * n_coop items / first n_coop splits
         self.item_edges = None
+        self.entry_dst = None                  # by-source / by-relation views: destination of every entry, grouped order
         self._view = None
 
     def view(self) -> View:
         if self._view is None:
             self._view = View(ptr(self.ptr), ptr(self.order), ptr(self.items), ptr(self.splits), ptr(self.counts),
                               self.n_items_max, self.n_splits_max, self.n_parts_max, ptr(self.item_edges), self.n_empty,
-                              self.n_coop)
+                              self.n_coop, ptr(self.entry_dst))
         return self._view
 
     def build_item_edges(self, col: torch.Tensor, etype: torch.Tensor) -> None:
-        """{col, type} of the first two entries of every item, inline with the schedule (forward kernel on small
-        graphs: one dependent round trip fewer per wave)."""
+        """{col, type} of the first two entries of every item, inline with the schedule (small graphs: one dependent
+        round trip fewer per wave).  By-source / by-relation schedules pass (order, entry_dst)."""
         if self.item_edges is None and self.n_items_max > 0:
             self.item_edges = torch.empty((self.n_items_max, 4), dtype=torch.int32, device=col.device)
             check(lib().jmac_item_edges_build(ptr(self.items), ptr(self.counts), self.n_items_max, ptr(col), ptr(etype),
@@ -159,7 +160,8 @@ class RelGraph:
 
         # small graphs: shorter items (a 32-entry item is 8 dependent gather rounds in one wave; the merge pass keeps
         # four partial rows in flight per lane, so the longer partial lists cost less than the rounds they save)
-        chunk_bwd = min(self.chunk, SMALL_BWD_CHUNK) if self.by_dst.item_edges is not None else self.chunk
+        small = self.by_dst.item_edges is not None
+        chunk_bwd = min(self.chunk, SMALL_BWD_CHUNK) if small else self.chunk
 
         def group(keys: torch.Tensor, n_seg: int) -> _Schedule:
             seg_ptr = torch.empty(n_seg + 1, dtype=torch.int32, device=dev)
@@ -168,7 +170,13 @@ class RelGraph:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             check(L.jmac_group_build(ptr(keys), E, n_seg, ptr(seg_ptr), ptr(order), ptr(ws), ws_bytes, stream()),
                   "jmac_group_build")
-            return _Schedule(seg_ptr, n_seg, E, chunk_bwd, order)
+            sch = _Schedule(seg_ptr, n_seg, E, chunk_bwd, order)
+            # destination of every entry in grouped order: passes B / C read it beside `order` instead of behind it
+            sch.entry_dst = (self.dst_of_slot.index_select(0, order[:E].long()) if E > 0
+                             else torch.zeros(1, dtype=torch.int32, device=dev))
+            if small:
+                sch.build_item_edges(order, sch.entry_dst)
+            return sch
 
         self.by_src = group(self.col, self.num_src)
         self.by_rel = group(self.etype, self.num_rel)

@@ -76,6 +76,21 @@ def test_csr_and_schedules(n, nr, e, chunk):
         to = g.by_rel.order[:e].cpu().numpy()
         assert (to == np.argsort(typ, kind="stable")).all()
         assert (np.diff(g.by_rel.ptr.cpu().numpy()) == np.bincount(typ, minlength=nr + 1)).all()
+        # destination of every entry in grouped order, and (small graphs) the {slot, destination} pairs of the first two
+        # entries of every item inline with the schedule
+        dos = ei[0][perm]
+        for view, order in ((g.by_src, so), (g.by_rel, to)):
+            ed = view.entry_dst[:e].cpu().numpy()
+            assert (ed == dos[order]).all()
+            assert (view.item_edges is not None) == small
+            if small:
+                c2 = view.counts.cpu().numpy()
+                its = view.items.cpu().numpy()[: c2[0]]
+                ie = view.item_edges.cpu().numpy()[: c2[0]]
+                for (seg, b, en, ps), row in zip(its, ie):
+                    want = [order[b] if en > b else -1, ed[b] if en > b else -1,
+                            order[b + 1] if en > b + 1 else -1, ed[b + 1] if en > b + 1 else -1]
+                    assert list(row) == want
 
 
 def test_out_of_range_ids_raise_index_error():
