@@ -118,6 +118,14 @@ class RelationAwareLayer(nn.Module):
         rel = self.atv_mlp(rel) if self.rel_activation == "leaky_relu" else F.relu(rel)
         return self._rel_mm(rel, self.rel_transform_weight2)              # :42
 
+    def _padded_a(self):
+        d = self.out_channels
+        dp = (d + 3) // 4 * 4
+        a = self.a_att.reshape(-1)
+        if dp != d:
+            a = F.pad(a, (0, dp - d))
+        return a.float(), dp
+
     def _tables(self, ent_emb, rel):
         """P|Q|Z and Rq|Rz, zero-padded to a multiple of 4 columns for 16-byte rows."""
         d_in, d = self.in_channels, self.out_channels
@@ -147,12 +155,47 @@ class RelationAwareLayer(nn.Module):
                                          loop_rel=rel.size(0) - 1, out_scale=0.5, bwd_mode=self.bwd_mode)
             return pre if dp == self.out_channels else pre[:, : self.out_channels]
         if self.comp_op == "mult":
-            return self._pre_bn_unfactorised(ent_emb, rel, edge_index, edge_type)
+            return self._pre_bn_mult(ent_emb, rel, edge_index, edge_type)
         raise NotImplementedError(self.comp_op)
 
+    def _pre_bn_mult(self, x, rel, edge_index, edge_type):
+        """comp_op='mult' (src/jmac_model.py:61-64): the message (x_j * r_t) W does not factor into per-node and
+        per-relation tables, but it still factors into ONE [E+N, d] x [d, 2d] GEMM over per-edge rows: row e of the
+        table is (x_src(e) * r_type(e)) [Wb|Wg], rows E.. are the self loops (x_i * r_loop) [Wb|Wg].  The fused
+        aggregation kernel then runs on the graph whose "source" of slot e is row e of that table and whose only
+        relation is a zero row -- same kernel, same deterministic backward, no [E,d] scatter passes."""
+        n, E = x.size(0), int(edge_index.shape[1])
+        d_in, d = self.in_channels, self.out_channels
+        a, dp = self._padded_a()
+        graph = self._edge_row_graph(edge_index, edge_type, n)
+        wt, wb, wg = self.w_att[:d_in], self.w_att[d_in:], self.gcn_weight
+        if dp != d:
+            wt, wb, wg = (F.pad(w, (0, dp - d)) for w in (wt, wb, wg))
+        rows = torch.cat((x.index_select(0, edge_index[1]) * rel.index_select(0, edge_type), x * rel[-1:]), dim=0)
+        QZ = torch.mm(rows, torch.cat((wb, wg), dim=1))                  # [E + N, 2dp]
+        P = torch.mm(x, wt)                                              # [N, dp]
+        zero_rel = torch.zeros((1, 2 * dp), dtype=torch.float32, device=x.device)
+        pre = ops.rel_attn_aggregate_split(P, QZ, zero_rel, a, graph, self.atv_mlp.negative_slope, out_scale=0.5,
+                                           loop_rel=0, self_off=E)
+        return pre if dp == d else pre[:, :d]
+
+    def _edge_row_graph(self, edge_index, edge_type, n):
+        """CSR of (destination <- edge id): cached per COO tensor like graph_cache does for the node graph."""
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(n), str(edge_index.device))
+        hit = getattr(self, "_erg", None)
+        if hit is None or hit[0] != key:
+            E = int(edge_index.shape[1])
+            ei = torch.stack((edge_index[0].to(torch.int64), torch.arange(E, dtype=torch.int64, device=edge_index.device)))
+            et = torch.zeros(E, dtype=torch.int64, device=edge_index.device)
+            from .graph import RelGraph
+            hit = (key, RelGraph(ei, et, n, 1, self.chunk, num_src=E + n), edge_index)   # edge_index kept alive: no aliasing
+            self._erg = hit
+        return hit[1]
+
     def _pre_bn_unfactorised(self, x, rel, edge_index, edge_type):
-        """comp_op='mult' does not factor ((x_j * r) W): per-edge torch GEMMs + this library's
-        torch_scatter-compatible kernels (jmac_scatter_*), i.e. the reference formulation on HIP."""
+        """comp_op='mult' in the reference's own formulation -- per-edge torch GEMMs + this library's
+        torch_scatter-compatible kernels (jmac_scatter_*): an independent second implementation of _pre_bn_mult
+        (tests), and what boundary B2 (the torch_scatter trio) looks like in use."""
         n = x.size(0)
         slope = self.atv_mlp.negative_slope
 

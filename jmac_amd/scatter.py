@@ -22,7 +22,10 @@ def _prep(src: torch.Tensor, index: torch.Tensor, dim: int):
     E = src.shape[0]
     if index.numel() != E:
         raise ValueError("index must have one entry per row of src")
-    return src.contiguous().reshape(E, -1), index
+    width = 1
+    for k in src.shape[1:]:
+        width *= int(k)
+    return src.contiguous().reshape(E, width), index                  # (E = 0: "-1" would be ambiguous)
 
 
 class _ScatterSum(torch.autograd.Function):

@@ -181,19 +181,39 @@ def test_edge_permutation_invariance_and_chunking():
     assert_close(outs[2], outs[0], 1e-5, 1e-7)
 
 
-def test_comp_op_mult_runs_on_scatter_kernels():
+@pytest.mark.parametrize("n,nr,d,e,hub", [(120, 5, 16, 500, None), (300, 7, 30, 2500, 900), (64, 3, 8, 0, None)])
+def test_comp_op_mult(n, nr, d, e, hub):
+    """comp_op='mult' (src/jmac_model.py:61-64): the fused kernel on per-edge rows (layer._pre_bn_mult) against the oracle,
+    forward and every gradient; and against the second implementation on the torch_scatter-compatible kernels."""
     from jmac_amd.layer import RelationAwareLayer
-    ei, et, X, R, G = _oracle_case(120, 5, 16, 500, seed=3)
+    ei, et, X, R, G = _oracle_case(n, nr, d, e, seed=3, hub=hub)
     torch.manual_seed(2)
-    lay = RelationAwareLayer(16, 16, rel_dim=16, act=torch.tanh, args=make_args(comp_op="mult"))
-    p = {k: v.detach().clone().requires_grad_(True) for k, v in lay.named_parameters()}
-    Xc = X.clone().requires_grad_(True)
-    ref = orc.layer_forward(p, Xc, R, ei, et, 0.05, "mult", "leaky_relu", True)
-    (ref * G).sum().backward()
+    lay = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args(comp_op="mult"))
+    p = {k: v.detach().clone().double().requires_grad_(True) for k, v in lay.named_parameters()}
+    Xc, Rc = X.double().requires_grad_(True), R.double().requires_grad_(True)
+    ref = orc.layer_forward(p, Xc, Rc, ei, et, 0.05, "mult", "leaky_relu", True)
+    (ref * G.double()).sum().backward()
     lay = lay.cuda()
-    Xg = X.cuda().requires_grad_(True)
-    out = lay(Xg, R.cuda(), ei.cuda(), et.cuda())
+    Xg, Rg = X.cuda().requires_grad_(True), R.cuda().requires_grad_(True)
+    out = lay(Xg, Rg, ei.cuda(), et.cuda())
     assert_close(out, ref, RTOL, 1e-6)
     (out * G.cuda()).sum().backward()
-    assert_close(Xg.grad, Xc.grad, RTOL, 1e-6)
-    assert_close(lay.w_att.grad, p["w_att"].grad, RTOL, 1e-6)
+    flips = 0
+    with torch.no_grad():                                            # LeakyReLU kinks (see _kink_flips)
+        if e:
+            rel = lay.transform_relations(Rg)
+            h32 = torch.mm(torch.cat((Xg[ei[0].cuda()], Xg[ei[1].cuda()] * rel[et.cuda()]), dim=1), lay.w_att).cpu()
+            rel64 = orc.transform_relations(p, Rc, 0.05, "leaky_relu")
+            h64 = torch.cat((Xc[ei[0]], Xc[ei[1]] * rel64[et]), dim=1) @ p["w_att"]
+            flips = int(((h32 > 0) != (h64 > 0)).sum())
+    gtol = RTOL if flips == 0 else 5e-2
+    assert flips <= 3
+    assert_close(Xg.grad, Xc.grad, gtol, 1e-6, "grad_X")
+    assert_close(Rg.grad, Rc.grad, gtol, 1e-6, "grad_R")
+    for k, v in lay.named_parameters():
+        if p[k].grad is not None and v.grad is not None:
+            assert_close(v.grad, p[k].grad, gtol, 1e-6, "grad_" + k)
+    with torch.no_grad():
+        rel = lay.transform_relations(Rg)
+        alt = lay._pre_bn_unfactorised(Xg, rel, ei.cuda(), et.cuda())
+        assert_close(lay._pre_bn_mult(Xg, rel, ei.cuda(), et.cuda()), alt, RTOL, 1e-6, "fused vs scatter form")
