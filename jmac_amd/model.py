@@ -40,6 +40,14 @@ def _link_columns(links, device, n1, n2):
     return _idx(a[:, 0], device, n1), _idx(a[:, 1], device, n2)
 
 
+def _rows(table, lo, hi):
+    """table[lo:hi] (src/jmac_model.py:173-176) -- the table itself when the range is all of it: the backward of a slice is
+    a zero-fill of the whole table plus a copy, per step and per table, for nothing when a model holds one KG."""
+    if lo == 0 and hi == table.shape[0]:
+        return table
+    return table[lo:hi]
+
+
 class JMAC(nn.Module):
     def __init__(self, args, entity_name_emb, num_relations, num_entities):
         super().__init__()
@@ -89,16 +97,16 @@ class JMAC(nn.Module):
         e0, e1 = ent_bases
         r0, r1 = rel_bases
         dev = self.ent_init_att_completion.device
-        comp_att = self.ent_init_att_completion[e0:e1]
-        rel_comp = self.rel_init_att_completion[r0:r1]
-        rel_align = self.rel_init_att_alignment[r0:r1]
+        comp_att = _rows(self.ent_init_att_completion, e0, e1)
+        rel_comp = _rows(self.rel_init_att_completion, r0, r1)
+        rel_align = _rows(self.rel_init_att_alignment, r0, r1)
         comp0 = self.completion_dropout(ops.row_normalize(comp_att))
         # :177 + :180  cat(comp0, info @ name_linear) @ W  ==  cat(comp0, info) @ [W_top ; name_linear @ W_bottom]:
         # the [N,300]x[300,300] product of the constant name embeddings (and its [N,300]x[300,300] adjoint) becomes a
         # [300,300]x[300,300] product of the two parameters -- same function, two N-row GEMMs fewer per step
         d = self.entity_dim
         w = torch.cat((self.uni_linear1_1[:d], torch.mm(self.name_linear, self.uni_linear1_1[d:])), dim=0)
-        align0 = torch.mm(torch.cat((comp0, self.ent_info_att[e0:e1].to(dev)), dim=1), w)
+        align0 = torch.mm(torch.cat((comp0, _rows(self.ent_info_att, e0, e1).to(dev)), dim=1), w)
         a1 = self.conv1_alignment(align0, rel_align, edge_index, edge_type)
         align_layers, comp_layers, comp_rel_layers = [align0, a1], [comp_att], [rel_comp]
         if self.args.num_gcn_layer == 2:
@@ -118,8 +126,8 @@ class JMAC(nn.Module):
         """src/jmac_model.py:207-220."""
         e0, e1 = ent_bases
         r0, r1 = rel_bases
-        comp_att = self.ent_init_att_completion[e0:e1]
-        rel_comp = self.rel_init_att_completion[r0:r1]
+        comp_att = _rows(self.ent_init_att_completion, e0, e1)
+        rel_comp = _rows(self.rel_init_att_completion, r0, r1)
         comp_layers, comp_rel_layers = [comp_att], [rel_comp]
         if self.args.num_gcn_layer == 2:
             comp_layers.append(self.conv1_completion(comp_att, rel_comp, edge_index, edge_type))

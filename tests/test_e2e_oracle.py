@@ -52,5 +52,7 @@ def test_oracle_replays_reference_training_run():
         loss.backward()
         opt.step()
         losses.append(float(loss.detach()))
+    # (ranks at the checkpoint are usually ALL identical to the reference's; the undecided handful -- gold tail within 1e-4
+    # of a competitor -- may move with the summation order the CPU's thread count picks, so only check_outcome's criterion
+    # is asserted)
     check_outcome(g, losses, ranks_ckpt, val_ranks(), "oracle")
-    assert (ranks_ckpt == g["ranks_ckpt"]).all()        # same arithmetic as the reference on the same CPU: exact at 30 steps
