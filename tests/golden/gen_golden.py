@@ -151,6 +151,23 @@ def run_layer_case(layer_cls, make_layer, name, n, nr, d, ei, et, seed, x_scale=
     return arrays
 
 
+def gen_jafull():
+    """The reference's layer on the WHOLE real DBP-5L ja graph in its bidirectional loader form (src/utils.py:127-149): N = 11 805,
+    E = 35 958, in-degree up to 1 221 (hub rows: split and cooperative segments on the device), 4 332 isolated nodes.  d = 8
+    keeps the fixture small; the arithmetic per edge is the same at every d."""
+    from src.jmac_model import RelationAwareLayer
+    args = types.SimpleNamespace(leaky_relu_w=0.05, comp_op="sub")
+    mk = lambda d: RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=args)
+    n = sum(1 for _ in open(os.path.join(REF, "datasetdbp5l/entity/ja.tsv")))
+    ei, et = ja_slice(n, bidirectional=True)
+    assert n == 11805 and ei.shape[1] == 35958
+    arr = run_layer_case(RelationAwareLayer, mk, "ja_full", n, 961, 8, ei, et, 8)
+    arr["edge_index"], arr["edge_type"] = ei.astype(np.int32), et.astype(np.int32)
+    deg = np.bincount(ei[0], minlength=n)
+    print("  max in-degree %d, isolated %d" % (deg.max(), int((deg == 0).sum())))
+    _save("layer_ja_full", **arr)
+
+
 def gen_root():
     from src.jmac_model import RelationAwareLayer, JMAC
     from src.knowledgegraph import KnowledgeGraph
@@ -588,6 +605,62 @@ def gen_dataset():
     _save("dbp5l_mini", **out)
 
 
+def array_digest(a):
+    """Order-sensitive 64-bit digest of an integer array (plain numpy arithmetic; the tests recompute it)."""
+    v = np.ascontiguousarray(a).astype(np.uint64).reshape(-1)
+    w = (np.arange(1, v.size + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)
+    return np.uint64((v * w).sum(dtype=np.uint64) ^ np.uint64(v.size))
+
+
+def gen_realpair():
+    """BASELINE config 1 / SURVEY 8(d) "Config 1": the REAL DBP-5L el (supporter) and ja (target) KGs with their seed pairs,
+    re-serialised in the dataset's own on-disk format under tests/golden/dbp5l_ja_el/ (triples and seed pairs verbatim; entity
+    and relation NAME files replaced by placeholders of the same line counts -- the loaders only count their lines).  The
+    REFERENCE's loader reads that directory; its arrays are pinned by shape and digest (dbp5l_ja_el.npz)."""
+    from src.data_loader import ParseData
+    src, root = os.path.join(REF, "datasetdbp5l"), os.path.join(HERE, "dbp5l_ja_el")
+    for sub in ("entity", "kg", "seed_train_pairs", "seed_test_pairs"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    nrel = sum(1 for _ in open(os.path.join(src, "relations.txt")))
+    with open(os.path.join(root, "relations.txt"), "w") as f:
+        f.write("".join("r%d\n" % i for i in range(nrel)))
+    for lang in ("el", "ja"):
+        n = sum(1 for _ in open(os.path.join(src, "entity", lang + ".tsv")))
+        with open(os.path.join(root, "entity", lang + ".tsv"), "w") as f:
+            f.write("".join("%s%d\n" % (lang, i) for i in range(n)))
+        for part in ("train", "val", "test"):
+            tr = np.loadtxt(os.path.join(src, "kg", "%s-%s.tsv" % (lang, part)), dtype=np.int64, delimiter="\t").reshape(-1, 3)
+            np.savetxt(os.path.join(root, "kg", "%s-%s.tsv" % (lang, part)), tr, fmt="%d", delimiter="\t")
+    for sub in ("seed_train_pairs", "seed_test_pairs"):
+        pr = np.loadtxt(os.path.join(src, sub, "el-ja.tsv"), dtype=np.float64, delimiter="\t").reshape(-1, 2)
+        np.savetxt(os.path.join(root, sub, "el-ja.tsv"), pr, fmt="%.1f", delimiter="\t")
+    lg = logging.getLogger("golden"); lg.setLevel(logging.ERROR)
+    pd_ = ParseData(types.SimpleNamespace(data_path=root, target_language="ja", device="cpu"), lg)
+    kgs, s_train, s_test = pd_.create_KG_objects_and_alignment()
+    out = {"kg_names": np.array(pd_.kg_names), "num_entities": np.int64(pd_.num_entities)}
+    for lang, kg in kgs.items():
+        ei, et = kg.edge_index.cpu().numpy() if hasattr(kg.edge_index, "cpu") else np.asarray(kg.edge_index), \
+            kg.edge_type.cpu().numpy() if hasattr(kg.edge_type, "cpu") else np.asarray(kg.edge_type)
+        out[lang + ".meta"] = np.array([kg.num_entity, kg.num_relation, int(kg.is_supporter_kg), kg.entity_id_base,
+                                        kg.relation_id_base, kg.upper_entity_base, kg.upper_relation_base], dtype=np.int64)
+        out[lang + ".shapes"] = np.array([len(kg.train_data), len(kg.val_data), len(kg.test_data), ei.shape[1]], dtype=np.int64)
+        out[lang + ".digests"] = np.array([array_digest(kg.train_data), array_digest(kg.val_data), array_digest(kg.test_data),
+                                           array_digest(ei), array_digest(et)], dtype=np.uint64)
+        deg_in = np.bincount(ei[0], minlength=kg.num_entity)
+        out[lang + ".degree"] = np.array([deg_in.max(), int((deg_in == 0).sum())], dtype=np.int64)
+        if not kg.is_supporter_kg:
+            tt = kg.true_tail if hasattr(kg, "true_tail") else {}
+            out[lang + ".true_tail"] = np.array([len(tt), sum(len(v) for v in tt.values())], dtype=np.int64)
+    for tag, sd in (("seeds_train", s_train), ("seeds_test", s_test)):
+        (k, v), = sd.items()
+        out[tag + ".pair"] = np.array(list(k))
+        out[tag] = np.asarray(v.cpu().numpy() if hasattr(v, "cpu") else v, dtype=np.int64)
+    _save("dbp5l_ja_el", **out)
+    for k in sorted(out):
+        if k.endswith("shapes") or k.endswith("meta") or k.endswith("degree"):
+            print("  ", k, out[k])
+
+
 def gen_dbpv1_model():
     """Model-level fixture of the DBPv1 variant (row a17): JMAC_DBPv1/models/jmac_model.py:116-277 JMAC_MODEL on one
     merged graph with inverse edges (jmac_trainer.py:93-96): forward_base, get_emb, completion_loss (rows L2-normalised
@@ -698,13 +771,13 @@ def gen_dbpv1():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variant", default="all", choices=["all", "root", "dbpv1", "aligneval", "entr", "dataset", "e2e"])
+    ap.add_argument("--variant", default="all", choices=["all", "root", "jafull", "dbpv1", "aligneval", "entr", "dataset", "realpair", "e2e"])
     a = ap.parse_args()
     if a.variant == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for v in ("root", "dbpv1", "aligneval", "entr", "dataset", "e2e"):
+        for v in ("root", "jafull", "dbpv1", "aligneval", "entr", "dataset", "realpair", "e2e"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--variant", v], env=env)
     else:
         _paths(a.variant)
-        {"root": gen_root, "dbpv1": gen_dbpv1, "aligneval": gen_aligneval, "entr": gen_entr, "dataset": gen_dataset,
+        {"root": gen_root, "jafull": gen_jafull, "dbpv1": gen_dbpv1, "aligneval": gen_aligneval, "entr": gen_entr, "dataset": gen_dataset, "realpair": gen_realpair,
          "e2e": gen_e2e}[a.variant]()

@@ -1,0 +1,46 @@
+"""BASELINE config 1's data: the real DBP-5L el / ja KGs and their seed pairs (tests/golden/dbp5l_ja_el/, the dataset's own
+on-disk format) read by jmac_amd.data.load_dbp5l must give the arrays the REFERENCE's loader built from the same files
+(src/data_loader.py:158-221, src/utils.py:112-149, src/knowledgegraph.py:18-19,45-46; pinned in dbp5l_ja_el.npz), and the
+shapes SURVEY.md section 8(d) tabulates."""
+import os
+
+import numpy as np
+
+from conftest import load_golden
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dbp5l_ja_el")
+
+
+def array_digest(a):
+    """Same arithmetic as tests/golden/gen_golden.py:array_digest."""
+    v = np.ascontiguousarray(a).astype(np.uint64).reshape(-1)
+    w = (np.arange(1, v.size + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)
+    return np.uint64((v * w).sum(dtype=np.uint64) ^ np.uint64(v.size))
+
+
+def test_real_ja_el_dataset_matches_reference_loader():
+    from jmac_amd import data
+    g = load_golden("dbp5l_ja_el")
+    kgs, s_train, s_test, n_ent = data.load_dbp5l(ROOT, "ja")
+    assert list(kgs) == list(g["kg_names"]) == ["el", "ja"] and n_ent == int(g["num_entities"]) == 17036
+    for lang, kg in kgs.items():
+        meta = [kg.num_entity, kg.num_relation, int(kg.is_supporter_kg), kg.entity_id_base, kg.relation_id_base,
+                kg.upper_entity_base, kg.upper_relation_base]
+        assert meta == g[lang + ".meta"].tolist()
+        assert [len(kg.train_data), len(kg.val_data), len(kg.test_data), kg.edge_index.shape[1]] == g[lang + ".shapes"].tolist()
+        dig = [array_digest(kg.train_data), array_digest(kg.val_data), array_digest(kg.test_data), array_digest(kg.edge_index),
+               array_digest(kg.edge_type)]
+        assert [int(x) for x in dig] == [int(x) for x in g[lang + ".digests"]], lang
+        deg = np.bincount(kg.edge_index[0], minlength=kg.num_entity)
+        assert [int(deg.max()), int((deg == 0).sum())] == g[lang + ".degree"].tolist()
+    # ja N = 11 805, train 17 979, val 8 633, test 2 162, bidirectional E = 35 958, max degree 1 221,
+    # 4 332 isolated nodes; el (supporter: train + val) 12 822 triples, 25 644 bidirectional edges, max degree 673
+    ja, el = kgs["ja"], kgs["el"]
+    assert (ja.num_entity, len(ja.train_data), len(ja.val_data), len(ja.test_data), ja.edge_index.shape[1]) == (11805, 17979, 8633, 2162, 35958)
+    assert (el.num_entity, len(el.train_data), el.edge_index.shape[1]) == (5231, 12822, 25644)
+    tt = ja.true_tail
+    assert [len(tt), sum(len(v) for v in tt.values())] == g["ja.true_tail"].tolist()
+    for tag, sd in (("seeds_train", s_train), ("seeds_test", s_test)):
+        (k, v), = sd.items()
+        assert list(k) == list(g[tag + ".pair"]) == ["el", "ja"]
+        assert (np.asarray(v) == g[tag]).all() and len(v) == 1112

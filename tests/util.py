@@ -7,7 +7,8 @@ import torch
 
 from conftest import load_golden  # noqa: F401
 
-LAYER_CASES = ["layer_tiny", "layer_rand200", "layer_d300", "layer_ja_train", "layer_ja_bidir", "layer_noedge"]
+LAYER_CASES = ["layer_tiny", "layer_rand200", "layer_d300", "layer_ja_train", "layer_ja_bidir", "layer_noedge",
+               "layer_ja_full"]       # the whole real DBP-5L ja graph (bidirectional loader form), d = 8
 
 
 def layer_params(g, device="cpu"):
