@@ -24,7 +24,7 @@ for key in ("c4", "c4samerel", "ja"):
     m = load(os.path.join(d, key + "_TCC_HIT_sum+TCC_MISS_sum", "p_counter_collection.csv"), "TCC_MISS_sum")
     ks = {}
     for name in f:
-        if not any(k in name for k in ("rel_attn", "sum_parts")):
+        if not any(k in name for k in ("rel_attn", "sum_parts", "bwd_finalize")):
             continue
         mean = lambda v: sum(v) / len(v) if v else 0.0
         fm, wm, hm, mm = mean(f[name]), mean(w.get(name, [])), mean(h.get(name, [])), mean(m.get(name, []))
