@@ -500,17 +500,27 @@ def scoring_bench(w, iters=10, cpu=True):
     fptr, fidx = torch.from_numpy(fptr_h).to(w.ei.device), torch.from_numpy(fidx_h).to(w.ei.device)
     with torch.no_grad():
         cached = m.forward_base(w.ei, w.et, [0, w.N], [0, w.nr])
-        def once():
-            dist = scoring.linkpred_dist(cached[1], cached[2], hb, rb)
+        hb_d, rb_d = torch.from_numpy(hb).to(w.ei.device), torch.from_numpy(rb).to(w.ei.device)
+
+        def materialised():      # the reference's two steps: forward_linkpred's [B, N] matrix, then the ranking loop
+            dist = scoring.linkpred_dist(cached[1], cached[2], hb_d, rb_d)
             return scoring.filtered_rank(dist, gold, fptr, fidx)
-        for _ in range(2):
-            once()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            once()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / iters
+
+        def fused():             # the same ranks without the matrix (jmac_linkpred_rank_f32)
+            return scoring.linkpred_ranks(cached[1], cached[2], hb_d, rb_d, gold, fptr, fidx)
+
+        def wall(fn):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / iters
+        dt_mat, dt = wall(materialised), wall(fused)
+        r_mat, r_fus = materialised().cpu().numpy(), fused().cpu().numpy()
+        ranks_differ = int((r_mat != r_fus).sum())
         # the L1 kernel alone: HIP events around back-to-back launches on the launch stream, preallocated output
         er = (cached[1][1][torch.from_numpy(hb).to(w.ei.device)] + cached[2][1][torch.from_numpy(rb).to(w.ei.device)]).contiguous()
         tab = cached[1][1].contiguous()
@@ -531,6 +541,10 @@ def scoring_bench(w, iters=10, cpu=True):
     # against the fp32 vector peak.
     elems_layer = float(B) * w.N * w.d
     res = {"scored_triples_per_s": B / dt, "pair_scores_per_s": B * w.N * 2 / dt, "ms_per_batch": dt * 1e3,
+           "path": "fused: query rows + gold distances + filter correction, then L1 tiles with a compare-and-count epilogue; the "
+                   "[B, N] matrix is never written",
+           "materialised_ms_per_batch": dt_mat * 1e3, "materialised_scored_triples_per_s": B / dt_mat,
+           "ranks_differing_from_materialised_path": ranks_differ,
            "B": B, "N": w.N, "layers": 2,
            "l1_kernel_ms": k_ms, "l1_kernel": "l1_score_kernel<float>, one layer (B x N x d), back-to-back launches",
            "valu_issue_frac": (2.0 * elems_layer / (k_ms * 1e-3)) / VALU_ISSUE_PEAK, "valu_issue_peak_lane_insts_per_s": VALU_ISSUE_PEAK,

@@ -245,6 +245,28 @@ int jmac_l1_score_bf16(const uint16_t* er, int64_t lder, const uint16_t* table, 
                        int64_t N, int64_t d, float* out, int64_t ldout, int32_t accumulate,
                        jmac_stream_t stream);
 
+/* Fused link prediction (replaces: forward_linkpred's layer loop src/jmac_model.py:302-313 TOGETHER WITH the ranking loop of
+ * src/validate.py:50-64, for callers that want the ranks and not the [B,N] matrix -- CompletionEvaluator.test):
+ *     dist[b,n] = sum over layers l of || (ent_l[h[b]] +/- rel_l[r[b]]) - table_l[n] ||_1      (pred_head != 0: minus)
+ *     rank[b]   = 1 + #{n in [0,N): dist[b,n] before dist[b,gold[b]]} - #{filtered n != gold[b]: dist[b,n] before ...}
+ * with "before" = smaller, or equal and lower index, exactly as jmac_filtered_rank_f32.  The distance is ONE running fp32 sum
+ * over (layer, k) -- the materialised path rounds once more per layer (out += layer), so the two agree to fp32 rounding and
+ * give the same rank wherever the gold is not tied with a neighbour at that level.  ent / rel: fp32 tables the query rows are
+ * gathered from; table: the N candidate rows, fp32 (== ent) for _f32, raw bf16 for _bf16 (the query rows are then rounded to
+ * bf16 as well: BASELINE config 3).  n_layers <= 4.  The [B,N] matrix is never written. */
+typedef struct {
+    const float* ent;  int64_t ld_ent;      /* [*, d] */
+    const float* rel;  int64_t ld_rel;      /* [*, d] */
+    const void* table; int64_t ld_table;    /* [N, d] fp32 or bf16 */
+} jmac_link_layer_t;
+size_t jmac_linkpred_rank_workspace_bytes(int64_t B, int64_t d, int32_t n_layers);
+int jmac_linkpred_rank_f32(const jmac_link_layer_t* layers, int32_t n_layers, const int32_t* h, const int32_t* r,
+                           int32_t pred_head, const int32_t* gold, const int32_t* filt_ptr, const int32_t* filt_idx,
+                           int64_t B, int64_t N, int64_t d, int32_t* rank, void* ws, size_t ws_bytes, jmac_stream_t stream);
+int jmac_linkpred_rank_bf16(const jmac_link_layer_t* layers, int32_t n_layers, const int32_t* h, const int32_t* r,
+                            int32_t pred_head, const int32_t* gold, const int32_t* filt_ptr, const int32_t* filt_idx,
+                            int64_t B, int64_t N, int64_t d, int32_t* rank, void* ws, size_t ws_bytes, jmac_stream_t stream);
+
 /* rank[b] = 1 + #{n : score[b,n] < score[b,gold] or (== and n < gold[b])}, where entries listed in
  * the filter CSR (filt_ptr [B+1], filt_idx) other than the gold are skipped.  descending == 0: `score` is a
  * DISTANCE (the reference's predictions = -dist, sorted descending); descending != 0: `score` is a SIMILARITY

@@ -30,6 +30,11 @@ class View(C.Structure):
                 ("item_edges", vp), ("n_empty", i64), ("n_coop", i64), ("entry_dst", vp)]
 
 
+class LinkLayer(C.Structure):
+    """jmac_link_layer_t"""
+    _fields_ = [("ent", vp), ("ld_ent", i64), ("rel", vp), ("ld_rel", i64), ("table", vp), ("ld_table", i64)]
+
+
 # name -> (restype, argtypes); mirrors include/jmac_hip.h one to one
 _SIGS = {
     "jmac_strerror": (C.c_char_p, [C.c_int]),
@@ -67,6 +72,9 @@ _SIGS = {
     "jmac_l1_score_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, vp]),
     "jmac_l1_score_bf16": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, vp]),
     "jmac_filtered_rank_f32": (C.c_int, [vp, i64, vp, vp, vp, i64, i64, i32, vp, vp]),
+    "jmac_linkpred_rank_workspace_bytes": (sz, [i64, i64, i32]),
+    "jmac_linkpred_rank_f32": (C.c_int, [vp, i32, vp, vp, i32, vp, vp, vp, i64, i64, i64, vp, vp, sz, vp]),
+    "jmac_linkpred_rank_bf16": (C.c_int, [vp, i32, vp, vp, i32, vp, vp, vp, i64, i64, i64, vp, vp, sz, vp]),
     "jmac_sim_matrix_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, vp]),
     "jmac_sim_topk_workspace_bytes": (sz, [i64, i64]),
     "jmac_sim_topk_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, i32, vp, vp, vp, sz, vp]),

@@ -169,6 +169,218 @@ __global__ __launch_bounds__(kBlock) void filtered_rank_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// fused link prediction: ranks of the gold tails WITHOUT the [B, N] distance matrix
+//   dist[b, n] = sum over layers l, then k, of |(E_l[h_b] +/- R_l[r_b])[k] - T_l[n, k]|   (ONE running fp32 sum, in that order)
+//   rank[b]    = 1 + #{n : dist[b, n] before dist[b, gold_b]} - #{filtered n != gold : ... before ...}
+// "before" = smaller, or equal with the lower index (jmac_filtered_rank_f32).  Two launches: the prep kernel builds the
+// query rows, the gold distances and the filter correction; the tile kernel is the L1 score kernel with a layer loop around
+// its slab loop and a compare-and-count epilogue (integer atomics: order-independent) instead of the [B, N] store.
+// ------------------------------------------------------------------------------------------------
+constexpr int LR_MAX_LAYERS = 4;
+struct LinkRankArgs {
+    const float* ent[LR_MAX_LAYERS];      // [*, d] fp32 entity tables the query rows are gathered from
+    const float* rel[LR_MAX_LAYERS];      // [*, d] fp32 relation tables
+    const void* tab[LR_MAX_LAYERS];       // [N, d] candidate tables of element type TT (== ent for fp32)
+    int64_t ld_ent[LR_MAX_LAYERS], ld_rel[LR_MAX_LAYERS], ld_tab[LR_MAX_LAYERS];
+    int32_t nl, B, N, d, dq;              // dq = d rounded up to 4: row stride of the query workspace
+    int32_t rows;                         // candidate rows the prep kernel stages per pass (LDS budget)
+    float sign;                           // +1: E[h] + R[r] (tail prediction), -1: E[h] - R[r]
+    const int32_t *h, *r, *gold, *filt_ptr, *filt_idx;
+    void* er;                             // workspace [nl][B][dq] of TT
+    float* gs;                            // workspace [B]
+    int32_t* rank;                        // [B]: the counters themselves
+};
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);     // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = f32_to_bf16_rne(v); }
+
+// one block per query: (1) its rows er_l = E_l[h] +/- R_l[r] (rounded to TT) -> workspace and LDS; (2) the listed candidates
+// (the gold first, then the filter entries), LR_ROWS at a time: their table rows are staged into LDS with coalesced loads, then
+// one lane per candidate runs the SAME sequential sum the tile kernel runs (bit-identical distances: exact ties resolve by
+// index as in the materialised path); (3) rank[b] starts at 1 - #{filtered entries before the gold}
+constexpr int LR_ROWS = 16;                        // at most; fewer when nl * d is large (60 KB of LDS)
+template <typename TT>
+__global__ __launch_bounds__(kBlock) void link_rank_prep_kernel(LinkRankArgs a) {
+    extern __shared__ float lr_sh[];                // [nl*dq] query rows (widened) + [LR_ROWS][nl*dq + 1] candidate rows
+    __shared__ float gs_sh;
+    __shared__ int cand[LR_ROWS];
+    __shared__ int red[kBlock / 64];
+    const int b = blockIdx.x, d = a.d, dq = a.dq, W = a.nl * dq, WS = W + 1;
+    float* const erow = lr_sh;
+    float* const crow = lr_sh + W;
+    const int hb = a.h[b], rb = a.r[b], g = a.gold[b];
+    TT* const er = static_cast<TT*>(a.er);
+    for (int l = 0; l < a.nl; ++l)
+        for (int k = threadIdx.x; k < dq; k += kBlock) {
+            float v = 0.f;
+            if (k < d) v = a.ent[l][(int64_t)hb * a.ld_ent[l] + k] + a.sign * a.rel[l][(int64_t)rb * a.ld_rel[l] + k];
+            TT* dst = er + ((int64_t)l * a.B + b) * dq + k;
+            st1(dst, v);
+            erow[l * dq + k] = ld1(dst);            // what the tile kernel will read back (bf16: rounded)
+        }
+    const int f0 = a.filt_ptr ? a.filt_ptr[b] : 0, f1 = a.filt_ptr ? a.filt_ptr[b + 1] : 0;
+    const int n_list = 1 + (f1 - f0);               // entry 0 = the gold
+    float gs = 0.f;
+    int cnt = 0;
+    for (int c0 = 0; c0 < n_list; c0 += a.rows) {
+        const int nc = min(a.rows, n_list - c0);
+        __syncthreads();                            // previous chunk consumed; erow complete
+        if (threadIdx.x < nc) {
+            const int c = c0 + threadIdx.x;
+            int n = c == 0 ? g : a.filt_idx[f0 + c - 1];
+            if (c > 0 && (n == g || n < 0 || n >= a.N)) n = -1;      // skipped entries (as jmac_filtered_rank_f32)
+            cand[threadIdx.x] = n;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nc * W; i += kBlock) {
+            const int rI = i / W, q = i - rI * W, l = q / dq, k = q - l * dq;
+            const int n = cand[rI];
+            float v = 0.f;
+            if (n >= 0 && k < d) v = ld1(static_cast<const TT*>(a.tab[l]) + (int64_t)n * a.ld_tab[l] + k);
+            crow[rI * WS + q] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < nc) {
+            const float* row = crow + threadIdx.x * WS;
+            float acc = 0.f;
+            for (int l = 0; l < a.nl; ++l) {
+                int k = 0;
+                for (; k + 4 <= d; k += 4) {
+                    const float e0 = erow[l * dq + k], e1 = erow[l * dq + k + 1], e2 = erow[l * dq + k + 2], e3 = erow[l * dq + k + 3];
+                    const float t0 = row[l * dq + k], t1 = row[l * dq + k + 1], t2 = row[l * dq + k + 2], t3 = row[l * dq + k + 3];
+                    acc = add_absdiff(acc, e0, t0);
+                    acc = add_absdiff(acc, e1, t1);
+                    acc = add_absdiff(acc, e2, t2);
+                    acc = add_absdiff(acc, e3, t3);
+                }
+                for (; k < d; ++k) acc = add_absdiff(acc, erow[l * dq + k], row[l * dq + k]);
+            }
+            if (c0 == 0 && threadIdx.x == 0) gs_sh = acc;
+            crow[threadIdx.x * WS] = acc;           // parked for the compare below (row data no longer needed)
+        }
+        __syncthreads();
+        gs = gs_sh;
+        if (threadIdx.x < nc && !(c0 == 0 && threadIdx.x == 0)) {
+            const int n = cand[threadIdx.x];
+            const float sc = crow[threadIdx.x * WS];
+            if (n >= 0) cnt += (sc < gs || (sc == gs && n < g)) ? 1 : 0;
+        }
+    }
+    cnt = wave_sum_i(cnt);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < kBlock / 64; ++w) t += red[w];
+        a.gs[b] = gs;
+        a.rank[b] = 1 - t;
+    }
+}
+
+// the L1 score tile kernel over the concatenated (layer, k) axis; epilogue: count the entries that rank before the gold
+template <typename TT, bool VEC>
+__global__ __launch_bounds__(kBlock) void link_rank_tile_kernel(LinkRankArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[2][L1_K][L1_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][L1_K][L1_LD];
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int B = a.B, N = a.N, d = a.d;
+    const int b0 = blockIdx.y * L1_T, n0 = blockIdx.x * L1_T;
+    const int lrow = tid >> 2, lk = (tid & 3) * 4;
+    const int64_t arow = b0 + lrow, brow = n0 + lrow;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    constexpr bool vec = VEC;
+    // unconditional clamped loads, zeroed when staged (see l1_score_kernel)
+    auto gload = [&](const TT* base, int64_t ld, int64_t row, int64_t nrows, int k0) -> float4 {
+        const int k = k0 + lk;
+        if constexpr (vec) {
+            const int64_t r = row < nrows ? row : nrows - 1;
+            return cvt4(ldraw(base + r * ld + (k < d ? k : d - 4)));
+        }
+        float4 v = f4zero();
+        if (row < nrows) {
+            const TT* p = base + row * ld;
+            if (k + 0 < d) v.x = ld1(p + k + 0);
+            if (k + 1 < d) v.y = ld1(p + k + 1);
+            if (k + 2 < d) v.z = ld1(p + k + 2);
+            if (k + 3 < d) v.w = ld1(p + k + 3);
+        }
+        return v;
+    };
+    auto sstore = [&](float (*S)[L1_LD], float4 v, int k0, bool row_ok) {
+        if (vec && !(row_ok && k0 + lk < d)) v = f4zero();
+        S[lk + 0][lrow] = v.x;
+        S[lk + 1][lrow] = v.y;
+        S[lk + 2][lrow] = v.z;
+        S[lk + 3][lrow] = v.w;
+    };
+    const int nk = (d + L1_K - 1) / L1_K, ns = a.nl * nk;      // slabs: layer-major, k inside
+    const TT* const er = static_cast<const TT*>(a.er);
+    auto slab = [&](int s, float4& ra, float4& rb) {
+        const int l = s / nk, k0 = (s - l * nk) * L1_K;
+        ra = gload(er + (int64_t)l * B * a.dq, a.dq, arow, B, k0);
+        rb = gload(static_cast<const TT*>(a.tab[l]), a.ld_tab[l], brow, N, k0);
+    };
+    float4 ra, rb;
+    slab(0, ra, rb);
+    sstore(As[0], ra, 0, arow < B);
+    sstore(Bs[0], rb, 0, brow < N);
+    __syncthreads();
+    for (int s = 0; s < ns; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < ns) slab(s + 1, ra, rb);
+#pragma unroll
+        for (int k = 0; k < L1_K; ++k) {
+            const float4 av4 = *reinterpret_cast<const float4*>(&As[cur][k][ty * 4]);
+            const float4 bv4 = *reinterpret_cast<const float4*>(&Bs[cur][k][tx * 4]);
+            const float av[4] = {av4.x, av4.y, av4.z, av4.w};
+            const float bv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = add_absdiff(acc[i][j], av[i], bv[j]);
+        }
+        if (s + 1 < ns) {
+            const int l1 = (s + 1) / nk, k1 = (s + 1 - l1 * nk) * L1_K;
+            sstore(As[cur ^ 1], ra, k1, arow < B);
+            sstore(Bs[cur ^ 1], rb, k1, brow < N);
+        }
+        __syncthreads();
+    }
+    // count: 4 rows x 4 columns per thread; the 16 threads of a row (tx = 0..15: consecutive lanes) are summed with DPP
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = b0 + ty * 4 + i;
+        const bool row_ok = b < B;
+        const float gs = row_ok ? a.gs[b] : 0.f;
+        const int g = row_ok ? a.gold[b] : 0;
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            const float sc = acc[i][j];
+            c += (row_ok && n < N && (sc < gs || (sc == gs && n < g))) ? 1 : 0;
+        }
+        c += __shfl_xor(c, 1);
+        c += __shfl_xor(c, 2);
+        c += __shfl_xor(c, 4);
+        c += __shfl_xor(c, 8);
+        if (tx == 0 && row_ok && c) atomicAdd(a.rank + b, c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // similarity GEMM  C = A * B^T  on the fp32-input MFMA (32x32x2), 128x128 tile per 4-wave block, K staged 16 deep
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -823,6 +1035,41 @@ int launch_topk(const float* S, int64_t lds, int64_t L, int64_t N, int32_t k, fl
 
 }  // namespace
 
+template <typename TT>
+static int launch_link_rank(const jmac_link_layer_t* layers, int32_t n_layers, const int32_t* h, const int32_t* r, int32_t pred_head,
+                            const int32_t* gold, const int32_t* filt_ptr, const int32_t* filt_idx, int64_t B, int64_t N, int64_t d,
+                            int32_t* rank, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (B < 0 || N <= 0 || d <= 0 || n_layers <= 0 || n_layers > LR_MAX_LAYERS) return JMAC_EINVAL;
+    if (B == 0) return JMAC_OK;
+    if (!layers || !h || !r || !gold || !rank || (filt_ptr && !filt_idx)) return JMAC_EINVAL;
+    if (B >= INT32_MAX || N >= INT32_MAX || d > 512) return JMAC_ERANGE;
+    if (!ws || ws_bytes < jmac_linkpred_rank_workspace_bytes(B, d, n_layers)) return JMAC_EWORKSPACE;
+    LinkRankArgs a{};
+    a.nl = n_layers; a.B = (int32_t)B; a.N = (int32_t)N; a.d = (int32_t)d; a.dq = (int32_t)((d + 3) / 4 * 4);
+    bool vec = d % 4 == 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!layers[l].ent || !layers[l].rel || !layers[l].table) return JMAC_EINVAL;
+        a.ent[l] = layers[l].ent; a.rel[l] = layers[l].rel; a.tab[l] = layers[l].table;
+        a.ld_ent[l] = layers[l].ld_ent; a.ld_rel[l] = layers[l].ld_rel; a.ld_tab[l] = layers[l].ld_table;
+        if (a.ld_tab[l] % 4) vec = false;
+    }
+    a.sign = pred_head ? -1.f : 1.f;
+    a.h = h; a.r = r; a.gold = gold; a.filt_ptr = filt_ptr; a.filt_idx = filt_idx;
+    a.gs = (float*)ws;
+    a.er = (char*)ws + align_up((size_t)B * 4);
+    a.rank = rank;
+    const int64_t W = (int64_t)n_layers * a.dq, words = 60 * 1024 / 4;
+    int64_t rows = (words - W) / (W + 1);
+    if (rows < 1) return JMAC_ERANGE;
+    a.rows = (int32_t)(rows < LR_ROWS ? rows : LR_ROWS);
+    const size_t shm = (size_t)(W + a.rows * (W + 1)) * sizeof(float);
+    hipLaunchKernelGGL((link_rank_prep_kernel<TT>), dim3((unsigned)B), dim3(kBlock), shm, st, a);
+    dim3 grid((unsigned)((N + L1_T - 1) / L1_T), (unsigned)((B + L1_T - 1) / L1_T));
+    if (vec) hipLaunchKernelGGL((link_rank_tile_kernel<TT, true>), grid, dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL((link_rank_tile_kernel<TT, false>), grid, dim3(kBlock), 0, st, a);
+    return (int)hipGetLastError();
+}
+
 extern "C" {
 
 int jmac_l1_score_f32(const float* er, int64_t lder, const float* table, int64_t ldt, int64_t B, int64_t N, int64_t d,
@@ -869,6 +1116,25 @@ int jmac_filtered_rank_f32(const float* score, int64_t lds, const int32_t* gold,
     hipLaunchKernelGGL(filtered_rank_kernel, dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, score, lds, gold, filt_ptr,
                        filt_idx, (int)N, descending ? 1 : 0, rank);
     return (int)hipGetLastError();
+}
+
+size_t jmac_linkpred_rank_workspace_bytes(int64_t B, int64_t d, int32_t n_layers) {
+    if (B < 0 || d <= 0 || n_layers <= 0) return 0;
+    return align_up((size_t)B * 4) + align_up((size_t)n_layers * (size_t)B * (size_t)((d + 3) / 4 * 4) * 4) + 256;
+}
+
+int jmac_linkpred_rank_f32(const jmac_link_layer_t* layers, int32_t n_layers, const int32_t* h, const int32_t* r,
+                           int32_t pred_head, const int32_t* gold, const int32_t* filt_ptr, const int32_t* filt_idx, int64_t B,
+                           int64_t N, int64_t d, int32_t* rank, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    return launch_link_rank<float>(layers, n_layers, h, r, pred_head, gold, filt_ptr, filt_idx, B, N, d, rank, ws, ws_bytes,
+                                   (hipStream_t)stream);
+}
+
+int jmac_linkpred_rank_bf16(const jmac_link_layer_t* layers, int32_t n_layers, const int32_t* h, const int32_t* r,
+                            int32_t pred_head, const int32_t* gold, const int32_t* filt_ptr, const int32_t* filt_idx, int64_t B,
+                            int64_t N, int64_t d, int32_t* rank, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    return launch_link_rank<bf16_t>(layers, n_layers, h, r, pred_head, gold, filt_ptr, filt_idx, B, N, d, rank, ws, ws_bytes,
+                                    (hipStream_t)stream);
 }
 
 int jmac_sim_matrix_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t d, float* C,

@@ -84,7 +84,7 @@ def train_alignment_component(model: JMAC, opt, ei1, et1, ei2, et2, feeddict):
 
 
 @torch.no_grad()
-def evaluate_completion(model: JMAC, kg: KnowledgeGraph, ei, et, args, split="val", filtered=True):
+def evaluate_completion(model: JMAC, kg: KnowledgeGraph, ei, et, args, split="val", filtered=True, fused=True):
     """CompletionEvaluator.test (src/validate.py:22-80) with the encoder run once instead of once per batch."""
     model.eval()
     data = {"val": kg.val_data, "test": kg.test_data, "train": kg.train_data}[split]
@@ -94,11 +94,14 @@ def evaluate_completion(model: JMAC, kg: KnowledgeGraph, ei, et, args, split="va
     for s in range(0, len(data), args.batch_size):
         b = data[s:s + args.batch_size]
         h, r, t = b[:, 0].tolist(), b[:, 1].tolist(), b[:, 2].tolist()
-        dist = model.forward_linkpred(h, r, ei, et, range(kg.num_entity), eb, rb, cached=cached)
         fp = fi = None
         if filtered:
-            fp, fi = scoring.build_filter_csr(h, r, kg.true_tail, dist.device)
-        ranks.append(scoring.filtered_rank(dist, torch.as_tensor(t, dtype=torch.int32, device=dist.device), fp, fi))
+            fp, fi = scoring.build_filter_csr(h, r, kg.true_tail, ei.device)
+        if fused:       # ranks without the [B, N] matrix
+            ranks.append(model.linkpred_ranks(h, r, t, ei, et, eb, rb, fp, fi, cached=cached))
+        else:           # the reference's two steps: forward_linkpred, then the ranking loop
+            dist = model.forward_linkpred(h, r, ei, et, range(kg.num_entity), eb, rb, cached=cached)
+            ranks.append(scoring.filtered_rank(dist, torch.as_tensor(t, dtype=torch.int32, device=dist.device), fp, fi))
     rk = torch.cat(ranks).double()
     model.train()
     return float((rk <= 1).double().mean()), float((rk <= 10).double().mean()), float((1.0 / rk).mean())

@@ -170,6 +170,19 @@ class JMAC(nn.Module):
         return scoring.linkpred_dist([comp_layers[l] for l in layers], [comp_rel_layers[l] for l in layers],
                                      e_index, r_index, pred_head, table_dtype=getattr(self, "table_dtype", torch.float32))
 
+    def linkpred_ranks(self, e_index, r_index, gold, edge_index, edge_type, ent_bases, rel_bases, filt_ptr=None,
+                       filt_idx=None, pred_head=False, cached=None):
+        """Filtered ranks of ``gold`` among ALL entities of the KG: forward_linkpred (:295-313) followed by the ranking loop
+        of CompletionEvaluator.test (src/validate.py:50-64) in one fused op that never writes the [B, N] distance matrix
+        (scoring.linkpred_ranks).  ``filt_ptr`` / ``filt_idx``: scoring.build_filter_csr of the batch, or None (raw)."""
+        if cached is None:
+            cached = self.forward_base(edge_index, edge_type, ent_bases, rel_bases)
+        _, comp_layers, comp_rel_layers = cached
+        layers = range(self.args.num_gcn_layer)
+        return scoring.linkpred_ranks([comp_layers[l] for l in layers], [comp_rel_layers[l] for l in layers], e_index, r_index,
+                                      gold, filt_ptr, filt_idx, pred_head,
+                                      table_dtype=getattr(self, "table_dtype", torch.float32))
+
     # ---- losses (src/jmac_model.py:237-292, :316-380): gathers + L1 / cosine fused in HIP (jmac_amd.losses),
     # the margin arithmetic on the resulting [T] / [L] vectors stays in torch ----------------------------
     @staticmethod

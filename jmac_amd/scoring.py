@@ -65,6 +65,48 @@ def linkpred_dist(comp_layers: Sequence[torch.Tensor], comp_rel_layers: Sequence
     return dist
 
 
+def linkpred_ranks(comp_layers: Sequence[torch.Tensor], comp_rel_layers: Sequence[torch.Tensor], e_index, r_index, gold,
+                   filt_ptr: Optional[torch.Tensor] = None, filt_idx: Optional[torch.Tensor] = None,
+                   pred_head: bool = False, table_dtype=torch.float32) -> torch.Tensor:
+    """Filtered ranks of the gold tails -- ``filtered_rank(linkpred_dist(...), gold, filt_ptr, filt_idx)`` without the
+    [B, N] distance matrix (forward_linkpred src/jmac_model.py:302-313 + the ranking loop of src/validate.py:50-64, i.e. what
+    CompletionEvaluator.test needs).  The distance of a candidate is one running fp32 sum over (layer, k) where the
+    materialised path rounds once more per layer: same rank unless the gold is tied with a neighbour at fp32 rounding."""
+    from ._lib import LinkLayer
+    require_device(*comp_layers, *comp_rel_layers)
+    nl = len(comp_layers)
+    if nl != len(comp_rel_layers) or not 1 <= nl <= 4:
+        raise ValueError("1..4 layers of (entity table, relation table)")
+    dev = comp_layers[0].device
+    N, d = comp_layers[0].shape
+    bf16 = table_dtype == torch.bfloat16
+    keep, arr = [], (LinkLayer * nl)()
+    for l, (ent, rel) in enumerate(zip(comp_layers, comp_rel_layers)):
+        if ent.shape != (N, d) or rel.shape[1] != d:
+            raise ValueError("layer tables disagree in shape")
+        ent, rel = ent.detach().float().contiguous(), rel.detach().float().contiguous()
+        tab = _rows16(ent.to(torch.bfloat16), True) if bf16 else ent
+        keep += [ent, rel, tab]
+        arr[l] = LinkLayer(ptr(ent), ent.stride(0), ptr(rel), rel.stride(0), ptr(tab), tab.stride(0))
+    check_index_range(e_index, N, "e_index")
+    check_index_range(r_index, comp_rel_layers[0].shape[0], "r_index")
+    check_index_range(gold, N, "gold")
+    h = torch.as_tensor(e_index, device=dev).to(torch.int32).contiguous()
+    r = torch.as_tensor(r_index, device=dev).to(torch.int32).contiguous()
+    g = torch.as_tensor(gold, device=dev).to(torch.int32).contiguous()
+    B = h.numel()
+    if r.numel() != B or g.numel() != B:
+        raise ValueError("e_index, r_index and gold must have one entry per query")
+    rank = torch.empty(B, dtype=torch.int32, device=dev)
+    L = lib()
+    ws_bytes = int(L.jmac_linkpred_rank_workspace_bytes(B, d, nl))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    fn, name = (L.jmac_linkpred_rank_bf16, "jmac_linkpred_rank_bf16") if bf16 else (L.jmac_linkpred_rank_f32, "jmac_linkpred_rank_f32")
+    check(fn(arr, nl, ptr(h), ptr(r), 1 if pred_head else 0, ptr(g), ptr(filt_ptr), ptr(filt_idx), B, N, d, ptr(rank), ptr(ws),
+             ws_bytes, stream()), name)
+    return rank
+
+
 def build_filter_csr(heads, rels, true_tail: Dict, device) -> Tuple[torch.Tensor, torch.Tensor]:
     """Pack er_vocab[(h, r)] lists (src/validate.py:53; knowledgegraph.py:62-86) as CSR over the batch."""
     ptr_l, idx = [0], []

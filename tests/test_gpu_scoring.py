@@ -249,3 +249,76 @@ def test_row_and_col_softmax_against_torch(n1, n2):
         assert_close(o, pc, 1e-5, 1e-9, "col softmax")
         assert_close(e, hc, 1e-4, 1e-6, "col entropy")
         assert scoring.col_softmax(s.cuda(), rmg, cmg, fill, 20.0, False, True)[0] is None
+
+
+def _undecided(dist, gold, rel=2e-6):
+    """Queries whose gold distance is within fp32 rounding of a neighbour's: the fused and the materialised paths may order
+    those differently (one more rounding per layer in the materialised sum)."""
+    d = dist.double().cpu().numpy()
+    gd = d[np.arange(len(gold)), gold][:, None]
+    gap = np.abs(d - gd)
+    gap[np.arange(len(gold)), gold] = np.inf
+    return gap.min(1) <= rel * np.abs(gd[:, 0])
+
+
+@pytest.mark.parametrize("B,N,d,nl,bf16,pred_head", [(37, 301, 48, 2, False, False), (130, 1000, 300, 2, False, False),
+                                                      (64, 517, 30, 1, False, True), (100, 777, 256, 2, True, False),
+                                                      (9, 70, 7, 3, False, False), (1000, 4000, 300, 2, False, False)])
+def test_fused_linkpred_ranks_equal_materialised_path(B, N, d, nl, bf16, pred_head):
+    """jmac_linkpred_rank_*: forward_linkpred + the filtered ranking loop without the [B, N] matrix (src/jmac_model.py:302-313,
+    src/validate.py:50-64) must give the ranks of linkpred_dist -> filtered_rank on the same inputs -- filtered and raw, one to
+    three layers, e - r, bf16 tables (config 3), rows that are no multiple of 16 bytes."""
+    from jmac_amd import scoring
+    rng = np.random.default_rng(B * N + d)
+    gen = torch.Generator().manual_seed(d + nl)
+    nrel = 11
+    comp = [torch.randn(N, d, generator=gen).cuda() for _ in range(nl)]
+    rel = [torch.randn(nrel, d, generator=gen).cuda() for _ in range(nl)]
+    h, r, gold = rng.integers(0, N, B), rng.integers(0, nrel, B), rng.integers(0, N, B)
+    ptr_l, idx = [0], []
+    for b in range(B):
+        f = rng.choice(N, rng.integers(0, 40), replace=False)
+        if b % 3 == 0:
+            f = np.unique(np.append(f, gold[b]))                      # the gold itself is listed, as in er_vocab
+        idx.extend(f.tolist())
+        ptr_l.append(len(idx))
+    fp = torch.tensor(ptr_l, dtype=torch.int32).cuda()
+    fi = torch.tensor(idx if idx else [0], dtype=torch.int32).cuda()
+    dt = torch.bfloat16 if bf16 else torch.float32
+    dist = scoring.linkpred_dist(comp, rel, h, r, pred_head=pred_head, table_dtype=dt)
+    und = _undecided(dist, gold)
+    assert und.mean() < 0.25          # random tables: candidates crowd around the gold (real embeddings separate far better)
+    for filt in (True, False):
+        want = scoring.filtered_rank(dist, gold, fp if filt else None, fi if filt else None).cpu().numpy()
+        got = scoring.linkpred_ranks(comp, rel, h, r, gold, fp if filt else None, fi if filt else None, pred_head=pred_head,
+                                     table_dtype=dt).cpu().numpy()
+        assert (got[~und] == want[~und]).all(), (int((got != want).sum()), np.abs(got - want).max())
+        assert np.abs(got - want).max() <= 2                           # a tie moves a rank by one place
+    # and the oracle's rank function on float64 distances of the same (rounded) tables
+    if not bf16:
+        sign = -1.0 if pred_head else 1.0
+        d64 = sum(torch.cdist((c[h].double() + sign * rl[r].double()), c.double(), p=1) for c, rl in zip(comp, rel)).cpu()
+        want64 = orc.filtered_ranks(d64, gold.tolist(), np.asarray(ptr_l, dtype=np.int32), np.asarray(idx if idx else [0], dtype=np.int32))
+        got = scoring.linkpred_ranks(comp, rel, h, r, gold, fp, fi, pred_head=pred_head).cpu().numpy()
+        und64 = _undecided(d64.float(), gold, rel=1e-5)
+        assert (got[~und64] == want64[~und64]).all()
+
+
+def test_fused_linkpred_ranks_match_reference_golden():
+    from jmac_amd import scoring
+    g = load_golden("model_small")
+    comp = [t(g["comp1_l0"], "cuda"), t(g["comp1_l1"], "cuda")]
+    rel = [t(g["rel1_l0"], "cuda"), t(g["rel1_l1"], "cuda")]
+    gold = g["lp_t"]
+    fp, fi = t(g["filt_ptr"], "cuda"), t(g["filt_idx"], "cuda")
+    d_ref = g["lp_dist"]
+    gd = d_ref[np.arange(len(gold)), gold][:, None]
+    gap = np.abs(d_ref - gd)
+    gap[np.arange(len(gold)), gold] = np.inf
+    safe = gap.min(1) > 1e-4 * np.abs(gd[:, 0])
+    for filt in (False, True):
+        got = scoring.linkpred_ranks(comp, rel, g["lp_h"].tolist(), g["lp_r"].tolist(), gold, fp if filt else None,
+                                     fi if filt else None).cpu().numpy()
+        ref = g["ranks_filt%d" % int(filt)]                          # the reference's CompletionEvaluator.test
+        assert safe.mean() > 0.5 and (got[safe] == ref[safe]).all()
+        assert np.allclose(orc.ranking_metrics(got), g["eval_filt%d" % int(filt)], atol=0.02)
