@@ -253,7 +253,8 @@ int jmac_l1_score_bf16(const uint16_t* er, int64_t lder, const uint16_t* table, 
  * over (layer, k) -- the materialised path rounds once more per layer (out += layer), so the two agree to fp32 rounding and
  * give the same rank wherever the gold is not tied with a neighbour at that level.  ent / rel: fp32 tables the query rows are
  * gathered from; table: the N candidate rows, fp32 (== ent) for _f32, raw bf16 for _bf16 (the query rows are then rounded to
- * bf16 as well: BASELINE config 3).  n_layers <= 4.  The [B,N] matrix is never written. */
+ * bf16 as well: BASELINE config 3).  n_layers <= 4, n_layers * d <= ~15 000 (the prep kernel stages candidate rows through
+ * 60 KB of LDS; JMAC_ERANGE beyond), d <= 512.  The [B,N] matrix is never written. */
 typedef struct {
     const float* ent;  int64_t ld_ent;      /* [*, d] */
     const float* rel;  int64_t ld_rel;      /* [*, d] */
