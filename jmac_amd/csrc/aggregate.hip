@@ -566,24 +566,25 @@ __device__ __forceinline__ void sum_parts_body(const SumPartsTask& t, int bid, i
         const jmac_split_t s = t.splits[sp];
         for (int c0 = 0; c0 < W4; c0 += 64) {
             const int c4 = c0 + lane;
-            float4 a0 = f4zero(), a1 = f4zero(), a2 = f4zero(), a3 = f4zero();
+            // SP_INFLIGHT partial rows in flight per lane: a long list (the hottest relation of a DBP-5L graph: ~170 partial
+            // rows) is a chain of dependent round trips, not bandwidth
+            constexpr int SP_INFLIGHT = 4;
+            float4 acc[SP_INFLIGHT];
+#pragma unroll
+            for (int q = 0; q < SP_INFLIGHT; ++q) acc[q] = f4zero();
             if (c4 < W4) {
-                // four partial rows in flight per lane: a long list (the hottest relation of a DBP-5L graph: ~170 partial
-                // rows) is a chain of dependent round trips, not bandwidth
                 const float* base = t.part + ((int64_t)s.pslot0 * W4 + c4) * 4;
                 const int64_t rs = (int64_t)W4 * 4;
                 int c = wave;
-                for (; c + 3 * kWavesPerBlock < s.nchunks; c += 4 * kWavesPerBlock) {
-                    a0 = add4(a0, ld4(base + (int64_t)c * rs));
-                    a1 = add4(a1, ld4(base + (int64_t)(c + kWavesPerBlock) * rs));
-                    a2 = add4(a2, ld4(base + (int64_t)(c + 2 * kWavesPerBlock) * rs));
-                    a3 = add4(a3, ld4(base + (int64_t)(c + 3 * kWavesPerBlock) * rs));
+                for (; c + (SP_INFLIGHT - 1) * kWavesPerBlock < s.nchunks; c += SP_INFLIGHT * kWavesPerBlock) {
+#pragma unroll
+                    for (int q = 0; q < SP_INFLIGHT; ++q) acc[q] = add4(acc[q], ld4(base + (int64_t)(c + q * kWavesPerBlock) * rs));
                 }
-                for (; c < s.nchunks; c += kWavesPerBlock) a0 = add4(a0, ld4(base + (int64_t)c * rs));
+                for (; c < s.nchunks; c += kWavesPerBlock) acc[0] = add4(acc[0], ld4(base + (int64_t)c * rs));
             }
-            a0 = add4(a0, a2);
-            a1 = add4(a1, a3);
-            red[wave][lane] = add4(a0, a1);
+#pragma unroll
+            for (int q = 1; q < SP_INFLIGHT; ++q) acc[0] = add4(acc[0], acc[q]);
+            red[wave][lane] = acc[0];
             __syncthreads();
             if (wave == 0 && c4 < W4) {
                 float4 acc = add4(add4(red[0][lane], red[1][lane]), add4(red[2][lane], red[3][lane]));
@@ -676,18 +677,24 @@ constexpr int RT_COLS = 8, RT_LANES = kBlock / RT_COLS;
 __device__ __forceinline__ void reduce_rows_body(const ReduceTask& t, int bid, float (*red)[RT_COLS]) {
     const int cl = threadIdx.x % RT_COLS, rl = threadIdx.x / RT_COLS;
     const int c = bid * RT_COLS + cl;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // RT_INFLIGHT partial rows in flight per thread: the a_att reduction of a DBP-5L graph sums ~3 000 partial rows, i.e. a
+    // chain of dependent round trips per thread, not bandwidth
+    constexpr int RT_INFLIGHT = 12;
+    float acc[RT_INFLIGHT];
+#pragma unroll
+    for (int q = 0; q < RT_INFLIGHT; ++q) acc[q] = 0.f;
     if (c < t.W) {
         int p = rl;
-        for (; p + 3 * RT_LANES < t.nparts; p += 4 * RT_LANES) {
-            a0 += t.partial[(int64_t)p * t.W + c];
-            a1 += t.partial[(int64_t)(p + RT_LANES) * t.W + c];
-            a2 += t.partial[(int64_t)(p + 2 * RT_LANES) * t.W + c];
-            a3 += t.partial[(int64_t)(p + 3 * RT_LANES) * t.W + c];
+        for (; p + (RT_INFLIGHT - 1) * RT_LANES < t.nparts; p += RT_INFLIGHT * RT_LANES) {
+#pragma unroll
+            for (int q = 0; q < RT_INFLIGHT; ++q) acc[q] += t.partial[(int64_t)(p + q * RT_LANES) * t.W + c];
         }
-        for (; p < t.nparts; p += RT_LANES) a0 += t.partial[(int64_t)p * t.W + c];
+        for (; p < t.nparts; p += RT_LANES) acc[0] += t.partial[(int64_t)p * t.W + c];
     }
-    red[rl][cl] = (a0 + a1) + (a2 + a3);
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < RT_INFLIGHT; ++q) tot += acc[q];
+    red[rl][cl] = tot;
     __syncthreads();
     if (rl == 0 && c < t.W) {
         float s = red[0][cl];
