@@ -616,27 +616,26 @@ def array_digest(a):
 
 
 def gen_realpair():
-    """BASELINE config 1 / SURVEY 8(d) "Config 1": the REAL DBP-5L el (supporter) and ja (target) KGs with their seed pairs,
-    re-serialised in the dataset's own on-disk format under tests/golden/dbp5l_ja_el/ (triples and seed pairs verbatim; entity
-    and relation NAME files replaced by placeholders of the same line counts -- the loaders only count their lines).  The
-    REFERENCE's loader reads that directory; its arrays are pinned by shape and digest (dbp5l_ja_el.npz)."""
+    """BASELINE config 1 / SURVEY 8(d) "Config 1": the REAL DBP-5L el (supporter) and ja (target) KGs with their seed pairs as
+    integer arrays (dbp5l_ja_el_data.npz: triples and seed pairs; entity / relation names are not kept -- the loaders only
+    count those lines).  tests/util.py:write_dbp5l_dir turns the arrays back into the dataset's on-disk format in a temporary
+    directory; the REFERENCE's loader reads that directory here and its arrays are pinned by shape and digest
+    (dbp5l_ja_el.npz)."""
     from src.data_loader import ParseData
-    src, root = os.path.join(REF, "datasetdbp5l"), os.path.join(HERE, "dbp5l_ja_el")
-    for sub in ("entity", "kg", "seed_train_pairs", "seed_test_pairs"):
-        os.makedirs(os.path.join(root, sub), exist_ok=True)
-    nrel = sum(1 for _ in open(os.path.join(src, "relations.txt")))
-    with open(os.path.join(root, "relations.txt"), "w") as f:
-        f.write("".join("r%d\n" % i for i in range(nrel)))
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from util import write_dbp5l_dir
+    src = os.path.join(REF, "datasetdbp5l")
+    data = {"langs": np.array(["el", "ja"]), "seed_pair": np.array(["el", "ja"]),
+            "n_relation_lines": np.int64(sum(1 for _ in open(os.path.join(src, "relations.txt"))))}
     for lang in ("el", "ja"):
-        n = sum(1 for _ in open(os.path.join(src, "entity", lang + ".tsv")))
-        with open(os.path.join(root, "entity", lang + ".tsv"), "w") as f:
-            f.write("".join("%s%d\n" % (lang, i) for i in range(n)))
+        data[lang + ".num_entity"] = np.int64(sum(1 for _ in open(os.path.join(src, "entity", lang + ".tsv"))))
         for part in ("train", "val", "test"):
-            tr = np.loadtxt(os.path.join(src, "kg", "%s-%s.tsv" % (lang, part)), dtype=np.int64, delimiter="\t").reshape(-1, 3)
-            np.savetxt(os.path.join(root, "kg", "%s-%s.tsv" % (lang, part)), tr, fmt="%d", delimiter="\t")
+            data["%s.%s" % (lang, part)] = np.loadtxt(os.path.join(src, "kg", "%s-%s.tsv" % (lang, part)), dtype=np.int64,
+                                                      delimiter="\t").reshape(-1, 3).astype(np.int32)
     for sub in ("seed_train_pairs", "seed_test_pairs"):
-        pr = np.loadtxt(os.path.join(src, sub, "el-ja.tsv"), dtype=np.float64, delimiter="\t").reshape(-1, 2)
-        np.savetxt(os.path.join(root, sub, "el-ja.tsv"), pr, fmt="%.1f", delimiter="\t")
+        data[sub] = np.loadtxt(os.path.join(src, sub, "el-ja.tsv"), dtype=np.float64, delimiter="\t").reshape(-1, 2).astype(np.int32)
+    _save("dbp5l_ja_el_data", **data)
+    root = write_dbp5l_dir(tempfile.mkdtemp(prefix="dbp5l_ja_el_"), data)
     lg = logging.getLogger("golden"); lg.setLevel(logging.ERROR)
     pd_ = ParseData(types.SimpleNamespace(data_path=root, target_language="ja", device="cpu"), lg)
     kgs, s_train, s_test = pd_.create_KG_objects_and_alignment()

@@ -1,14 +1,13 @@
-"""BASELINE config 1's data: the real DBP-5L el / ja KGs and their seed pairs (tests/golden/dbp5l_ja_el/, the dataset's own
-on-disk format) read by jmac_amd.data.load_dbp5l must give the arrays the REFERENCE's loader built from the same files
+"""BASELINE config 1's data: the real DBP-5L el / ja KGs and their seed pairs (tests/golden/dbp5l_ja_el_data.npz, written back
+into the dataset's own on-disk format by util.write_dbp5l_dir) read by jmac_amd.data.load_dbp5l must give the arrays the
+REFERENCE's loader built from the same files
 (src/data_loader.py:158-221, src/utils.py:112-149, src/knowledgegraph.py:18-19,45-46; pinned in dbp5l_ja_el.npz), and the
 shapes SURVEY.md section 8(d) tabulates."""
-import os
 
 import numpy as np
 
 from conftest import load_golden
-
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dbp5l_ja_el")
+from util import write_dbp5l_dir
 
 
 def array_digest(a):
@@ -18,10 +17,11 @@ def array_digest(a):
     return np.uint64((v * w).sum(dtype=np.uint64) ^ np.uint64(v.size))
 
 
-def test_real_ja_el_dataset_matches_reference_loader():
+def test_real_ja_el_dataset_matches_reference_loader(tmp_path):
     from jmac_amd import data
     g = load_golden("dbp5l_ja_el")
-    kgs, s_train, s_test, n_ent = data.load_dbp5l(ROOT, "ja")
+    root = write_dbp5l_dir(str(tmp_path / "dbp5l_ja_el"), load_golden("dbp5l_ja_el_data"))
+    kgs, s_train, s_test, n_ent = data.load_dbp5l(root, "ja")
     assert list(kgs) == list(g["kg_names"]) == ["el", "ja"] and n_ent == int(g["num_entities"]) == 17036
     for lang, kg in kgs.items():
         meta = [kg.num_entity, kg.num_relation, int(kg.is_supporter_kg), kg.entity_id_base, kg.relation_id_base,

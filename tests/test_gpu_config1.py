@@ -1,5 +1,5 @@
 """BASELINE config 1 on the device: the reference's own default run -- target_language=ja, d=256 (train.py:73), batch 1000,
-25 negatives, dropout 0.4, two GCN layers -- on the REAL DBP-5L el / ja KGs (tests/golden/dbp5l_ja_el/), driven like train.py
+25 negatives, dropout 0.4, two GCN layers -- on the REAL DBP-5L el / ja KGs (tests/golden/dbp5l_ja_el_data.npz), driven like train.py
 (get_emb -> EnTr -> completion batches -> alignment step, src of truth: jmac_amd/harness.py), one epoch and then a few more.
 
 What can be asserted without the reference's random streams (its DataLoader workers draw the negatives): the plumbing at
@@ -7,7 +7,6 @@ full size -- every kernel on the real graphs (hub rows of 1 221 / 673 edges, 4 3
 transfer, the filtered evaluator over 11 805 candidates -- finite losses that go down, and link-prediction quality on the
 VALIDATION triples that moves far from the untrained model's.  Numerical parity at this size is test_gpu_layer's
 `layer_ja_full` case (the reference's layer on this very graph) and tests/test_gpu_ja_oracle.py."""
-import os
 
 import numpy as np
 import pytest
@@ -15,14 +14,15 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dbp5l_ja_el")
 
-
-def test_config1_epochs_on_real_ja():
+def test_config1_epochs_on_real_ja(tmp_path):
+    from conftest import load_golden
+    from util import write_dbp5l_dir
     from jmac_amd import data, harness
     from jmac_amd.model import JMAC
     torch.manual_seed(0)
-    kgs, s_train, s_test, n_ent = data.load_dbp5l(ROOT, "ja")
+    root = write_dbp5l_dir(str(tmp_path / "dbp5l_ja_el"), load_golden("dbp5l_ja_el_data"))
+    kgs, s_train, s_test, n_ent = data.load_dbp5l(root, "ja")
     args = harness.make_args(dim=256, batch_size=1000, num_negative=25, dropout=0.4, lr=1e-3)
     name_emb = np.random.default_rng(0).standard_normal((n_ent, 300)).astype(np.float32)   # synthetic N(0,1) names
     n_rel_total = sum(kg.num_relation for kg in kgs.values())

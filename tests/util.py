@@ -55,3 +55,23 @@ def assert_close(got, ref, rtol, atol=1e-6, what=""):
     err = (got - ref).abs().max().item() if ref.numel() else 0.0
     bound = rtol * (ref.abs().max().item() if ref.numel() else 0.0) + atol
     assert err <= bound, "%s: max|err| %.3e > %.3e" % (what, err, bound)
+
+
+def write_dbp5l_dir(root, g):
+    """Write the arrays of tests/golden/dbp5l_ja_el_data.npz as a directory in the DBP-5L on-disk format (entity/<lang>.tsv,
+    kg/<lang>-{train,val,test}.tsv, seed_{train,test}_pairs/<l1>-<l2>.tsv with float-formatted ids, relations.txt).  Entity and
+    relation NAME files are placeholders of the right line counts: the loaders only count their lines."""
+    import os
+    for sub in ("entity", "kg", "seed_train_pairs", "seed_test_pairs"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    with open(os.path.join(root, "relations.txt"), "w") as f:
+        f.write("".join("r%d\n" % i for i in range(int(g["n_relation_lines"]))))
+    for lang in [str(x) for x in g["langs"]]:
+        with open(os.path.join(root, "entity", lang + ".tsv"), "w") as f:
+            f.write("".join("%s%d\n" % (lang, i) for i in range(int(g[lang + ".num_entity"]))))
+        for part in ("train", "val", "test"):
+            np.savetxt(os.path.join(root, "kg", "%s-%s.tsv" % (lang, part)), g["%s.%s" % (lang, part)], fmt="%d", delimiter="\t")
+    pair = "-".join(str(x) for x in g["seed_pair"])
+    for sub in ("seed_train_pairs", "seed_test_pairs"):
+        np.savetxt(os.path.join(root, sub, pair + ".tsv"), g[sub].astype(np.float64), fmt="%.1f", delimiter="\t")
+    return root
