@@ -481,14 +481,28 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_combine_kernel(FwdArgs a)
         float4 acc[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) acc[k] = f4zero();
-        for (int c = wave; c < s.nchunks; c += kWavesPerBlock) {
-            const int ps = s.pslot0 + c;
-            const float f = fast_exp(a.part_ml[2 * ps] - M);
-            lsum += a.part_ml[2 * ps + 1] * f;
+        // eight partial states in flight per wave (a hub of config 4 has ~1 000 of them: a chain of round trips otherwise);
+        // the tail re-reads the last chunk with factor 0, so that every load is unconditional
+        constexpr int CI = 8;
+        for (int c = wave; c < s.nchunks; c += CI * kWavesPerBlock) {
+            float2 ml[CI];
+            float4 row[CI][NCH];
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                const int o = L.is_v(k) ? L.coff[k] - voff : 0;
-                acc[k] = fma4(ld4(a.part_acc + (int64_t)ps * voff + o), f, acc[k]);
+            for (int q = 0; q < CI; ++q) {
+                const int ps = s.pslot0 + min(c + q * kWavesPerBlock, s.nchunks - 1);
+                ml[q] = *reinterpret_cast<const float2*>(a.part_ml + 2 * ps);
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int o = L.is_v(k) ? L.coff[k] - voff : 0;
+                    row[q][k] = ld4(a.part_acc + (int64_t)ps * voff + o);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CI; ++q) {
+                const float f = c + q * kWavesPerBlock < s.nchunks ? fast_exp(ml[q].x - M) : 0.f;
+                lsum += ml[q].y * f;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) acc[k] = fma4(row[q][k], f, acc[k]);
             }
         }
 #pragma unroll
