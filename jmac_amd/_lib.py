@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import re
+import weakref
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -124,6 +125,26 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_tlib: Optional[C.CDLL] = None
+
+
+def testing_lib() -> C.CDLL:
+    """libjmac_hip_testing.so: the same library with the ATOMIC aggregation backward compiled in (mode 0) -- an independent
+    second implementation for the parity tests.  Nothing on the product path calls this."""
+    global _tlib
+    if _tlib is None:
+        path = os.path.join(_HERE, "libjmac_hip_testing.so")
+        if not os.path.exists(path):
+            raise JmacError("jmac_amd: %s is missing (the atomic backward lives in the testing build only: "
+                            "`make -C jmac_amd/csrc`)" % path)
+        l = C.CDLL(path)
+        for name in ("jmac_rel_attn_aggregate_bwd_f32", "jmac_rel_attn_bwd_workspace_bytes", "jmac_strerror"):
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = _SIGS[name]
+        _tlib = l
+    return _tlib
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().jmac_strerror(rc)
@@ -150,8 +171,11 @@ _CHECKED_CAP = 64
 
 def check_index_range(idx, n: int, what: str = "index"):
     """Raise IndexError unless every entry of ``idx`` lies in [0, n).  Host data (lists, numpy, CPU tensors) is
-    checked on the host; a device tensor is checked once per (storage, version) by jmac_index_check -- one host read
-    the first time a tensor is seen, nothing afterwards, and nothing while a stream is being captured."""
+    checked on the host; a device tensor is checked once per (tensor object, version) by jmac_index_check -- one host read
+    the first time a tensor is seen, nothing afterwards, and nothing while a stream is being captured.  Hot loops should
+    pass tensors that were checked on the host and marked before the upload (``mark_index_range``): a fresh device tensor
+    per step costs one blocking read per step here.  A kernel outside torch that rewrites a validated tensor in place does
+    not bump ``_version``: re-validate such a tensor yourself (``jmac_index_check``)."""
     import numpy as np
     import torch
     n = int(n)
@@ -172,8 +196,11 @@ def check_index_range(idx, n: int, what: str = "index"):
     ok = getattr(idx, "_jmac_range_ok", None)             # set by a host-side check before the upload (mark_index_range)
     if ok is not None and ok <= n:
         return
-    key = (idx.data_ptr(), idx._version, idx.numel(), idx.dtype, n)
-    if key in _CHECKED:
+    # validated tensors are remembered by IDENTITY through a weak reference (no strong reference: a [2,E] COO of a dropped
+    # graph is not pinned by this cache), together with the version counter torch bumps on in-place writes
+    key = id(idx)
+    hit = _CHECKED.get(key)
+    if hit is not None and hit[0]() is idx and hit[1] == idx._version and hit[2] >= 0 and hit[2] <= n:
         return
     if torch.cuda.is_current_stream_capturing():
         return                                             # cannot read back inside a capture; eager warm-up has checked
@@ -183,9 +210,14 @@ def check_index_range(idx, n: int, what: str = "index"):
     nbad = int(bad.item())
     if nbad:
         raise IndexError("%s out of range: %d of %d entries outside [0, %d)" % (what, nbad, t.numel(), n))
+    for k in [k for k, v in _CHECKED.items() if v[0]() is None]:
+        del _CHECKED[k]                                    # tensors that have died since
     if len(_CHECKED) >= _CHECKED_CAP:
         _CHECKED.pop(next(iter(_CHECKED)))
-    _CHECKED[key] = idx            # keeps the tensor alive: a recycled data_ptr can never alias a validated entry
+    try:
+        _CHECKED[key] = (weakref.ref(idx), idx._version, n)
+    except TypeError:                                      # pragma: no cover  (not weak-referenceable: do not cache)
+        pass
 
 
 def mark_index_range(t, n: int):

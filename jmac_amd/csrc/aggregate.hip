@@ -1350,6 +1350,11 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
         t.nblocks = nparts > 0 ? (int)((d + RT_COLS - 1) / RT_COLS) : 0;
         return t;
     };
+#ifndef JMAC_TEST_ATOMIC_BWD
+    // the product library carries the deterministic backward only; the atomic variant (an independent second implementation
+    // for the parity tests) is compiled into libjmac_hip_testing.so (csrc/Makefile)
+    if (mode == 0) return JMAC_EINVAL;
+#else
     if (mode == 0) {
         // dQZ / dRR are accumulated with atomics: initialise them (dZ half of dQZ starts at the self term)
         hipLaunchKernelGGL(init_dqz_kernel, dim3((unsigned)((Nsrc * 2 * d + T - 1) / T)), dim3(T), 0, st, dQZ, lddqz, Nsrc, d, G, ldg,
@@ -1366,6 +1371,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
         if (nb > 0) hipLaunchKernelGGL(bwd_finalize_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, f);
         return (int)hipGetLastError();
     }
+#endif
     // ---- deterministic mode: three launches ----------------------------------------------------------------------------
     // 1. pass A by destination (+ the column-sum partials of G)
     JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 1, D4T>), dim3(gridA + gcs), dim3(kBlock), 0, st, a,

@@ -1011,10 +1011,12 @@ int launch_sim(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t
     if (d % 4) return JMAC_EDIM;
     // persistent: as many blocks as are resident at once (occupancy query: 3 per CU with 80 + 64 accumulation VGPRs and
     // 33 KB of LDS), rounded down to a multiple of 8 so that a block's tile ids stay on its XCD
-    static int resident = 0;
-    if (resident == 0) {
-        int dev = 0, cus = 256, occ = 3;
-        hipGetDevice(&dev);
+    static int resident_of[64] = {0};                                   // per device: CU counts may differ between devices
+    int dev = 0;
+    hipGetDevice(&dev);
+    int& resident = resident_of[dev >= 0 && dev < 64 ? dev : 0];
+    if (resident == 0 || dev >= 64) {
+        int cus = 256, occ = 3;
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(sim_gemm_kernel), kBlock, 0) != hipSuccess || occ < 1)
             occ = 3;
@@ -1051,7 +1053,8 @@ static int launch_link_rank(const jmac_link_layer_t* layers, int32_t n_layers, c
         if (!layers[l].ent || !layers[l].rel || !layers[l].table) return JMAC_EINVAL;
         a.ent[l] = layers[l].ent; a.rel[l] = layers[l].rel; a.tab[l] = layers[l].table;
         a.ld_ent[l] = layers[l].ld_ent; a.ld_rel[l] = layers[l].ld_rel; a.ld_tab[l] = layers[l].ld_table;
-        if (a.ld_tab[l] % 4) vec = false;
+        // the vector form issues 4-element loads (16 B fp32, 8 B bf16): leading dimension AND base pointer must allow it
+        if (a.ld_tab[l] % 4 || ((uintptr_t)a.tab[l] % (4 * sizeof(TT)))) vec = false;
     }
     a.sign = pred_head ? -1.f : 1.f;
     a.h = h; a.r = r; a.gold = gold; a.filt_ptr = filt_ptr; a.filt_idx = filt_idx;
@@ -1080,7 +1083,9 @@ int jmac_l1_score_f32(const float* er, int64_t lder, const float* table, int64_t
     if (lder % 4 || ldt % 4) return JMAC_EDIM;
     if (B >= INT32_MAX || N >= INT32_MAX) return JMAC_ERANGE;
     dim3 grid((unsigned)((N + L1_T - 1) / L1_T), (unsigned)((B + L1_T - 1) / L1_T));
-    if (d % 4 == 0)
+    // 4-element vector loads need 4-element-aligned base pointers too (a column-offset view is not): scalar form otherwise
+    const bool aligned = (((uintptr_t)er | (uintptr_t)table) % (4 * sizeof(float))) == 0;
+    if (d % 4 == 0 && aligned)
         hipLaunchKernelGGL((l1_score_kernel<float, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, er, lder, table, ldt, (int)B,
                            (int)N, (int)d, out, ldout, accumulate);
     else
@@ -1097,7 +1102,9 @@ int jmac_l1_score_bf16(const uint16_t* er, int64_t lder, const uint16_t* table, 
     if (lder % 4 || ldt % 4) return JMAC_EDIM;
     if (B >= INT32_MAX || N >= INT32_MAX) return JMAC_ERANGE;
     dim3 grid((unsigned)((N + L1_T - 1) / L1_T), (unsigned)((B + L1_T - 1) / L1_T));
-    if (d % 4 == 0)
+    // 4-element vector loads need 4-element-aligned base pointers too (a column-offset view is not): scalar form otherwise
+    const bool aligned = (((uintptr_t)er | (uintptr_t)table) % (4 * sizeof(uint16_t))) == 0;
+    if (d % 4 == 0 && aligned)
         hipLaunchKernelGGL((l1_score_kernel<bf16_t, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, er, lder, table, ldt, (int)B,
                            (int)N, (int)d, out, ldout, accumulate);
     else

@@ -180,7 +180,10 @@ class _AllGatherRows(torch.autograd.Function):
             work.wait()
             _cdone("all_gather_qz", e0, out)
             if final is not None:
-                final.copy_(out)
+                # outside forward() grad mode is on and ``final`` is the Function's OUTPUT: a recorded in-place copy would
+                # put a CopyBackwards node between the table and its consumers and hand backward() an all-zero gradient
+                with torch.no_grad():
+                    final.copy_(out)
 
     @staticmethod
     def backward(ctx, g):

@@ -10,10 +10,10 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import check, lib, ptr, require_device, stream
+from ._lib import check, lib, ptr, require_device, stream, testing_lib
 from .graph import RelGraph
 
-BWD_MODE_ATOMIC = 0
+BWD_MODE_ATOMIC = 0            # testing build only (libjmac_hip_testing.so): float atomics, a second implementation for the tests
 BWD_MODE_DETERMINISTIC = 1
 
 # bench.py sets this to a list to collect (name, start_event, end_event) around the aggregation launches;
@@ -90,13 +90,13 @@ class _RelAttnAggregate(torch.autograd.Function):
     def backward(ctx, G):
         PQZ, RR, a, out, seg_max, seg_den = ctx.saved_tensors
         graph: RelGraph = ctx.graph
-        L = lib()
+        mode = int(ctx.bwd_mode)
+        L = lib() if mode == BWD_MODE_DETERMINISTIC else testing_lib()      # mode 0 exists in the testing build only
         dev = PQZ.device
         N, d3 = PQZ.shape
         d = d3 // 3
         nrel = RR.shape[0]
         G = _f32c(G).contiguous()
-        mode = int(ctx.bwd_mode)
         if mode == BWD_MODE_DETERMINISTIC:
             graph.ensure_backward_views()
         dPQZ = torch.empty_like(PQZ)

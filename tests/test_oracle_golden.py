@@ -29,23 +29,25 @@ def test_layer_forward_backward_matches_reference(case):
     d = int(g["d"])
     rm, rv = torch.zeros(d), torch.ones(d)
     out = orc.layer_forward(p, X, R, ei, et, float(g["slope"]), "sub", rel_act, True, rm, rv)
-    assert rel_err(out, g["out_train"]) < 5e-6
-    assert rel_err(rm, g["running_mean_after"]) < 5e-6 and rel_err(rv, g["running_var_after"]) < 5e-6
+    # measured on one thread in the build container: every quantity below is BIT-IDENTICAL to the fixture (error 0.0) on all
+    # eight cases; 1e-6 / 1e-5 is head-room for a host whose BLAS splits its sums differently, not a measured error
+    assert rel_err(out, g["out_train"]) < 1e-6
+    assert rel_err(rm, g["running_mean_after"]) < 1e-6 and rel_err(rv, g["running_var_after"]) < 1e-6
     (out * t(g["G"])).sum().backward()
-    assert rel_err(X.grad, g["grad_X"]) < 2e-5
-    assert rel_err(R.grad, g["grad_R"]) < 2e-5
+    assert rel_err(X.grad, g["grad_X"]) < 1e-5
+    assert rel_err(R.grad, g["grad_R"]) < 1e-5
     for name, ref in layer_grads(g).items():
         got = p[name].grad if p[name].grad is not None else torch.zeros_like(p[name])
         # loop_rel's gradient is mathematically zero here: judge its noise against grad_R's scale
         atol = 1e-4 * float(np.abs(g["grad_R"]).max()) + 1e-6 if name == "loop_rel" else 1e-6
-        assert_close(got, ref, 2e-5, atol, name)
+        assert_close(got, ref, 1e-5, atol, name)
     # eval mode uses the running statistics left by the training step
     out_eval = orc.layer_forward({k: v.detach() for k, v in p.items()}, X.detach(), R.detach(), ei, et,
                                  float(g["slope"]), "sub", rel_act, False, rm, rv)
-    assert rel_err(out_eval, g["out_eval"]) < 5e-6
+    assert rel_err(out_eval, g["out_eval"]) < 1e-6
     nb, _, _ = orc.layer_pre_bn({k: v.detach() for k, v in p.items()}, X.detach(), R.detach(), ei, et,
                                 float(g["slope"]), "sub", rel_act)
-    assert rel_err(nb, g["nb"]) < 5e-6 or np.abs(g["nb"]).max() == 0
+    assert rel_err(nb, g["nb"]) < 1e-6 or np.abs(g["nb"]).max() == 0
 
 
 @pytest.mark.parametrize("case", LAYER_CASES + ["layer_dbpv1"])
