@@ -31,6 +31,7 @@ import ctypes as C
 import numpy as np
 import torch
 
+REAL_DATA = os.path.join(ROOT, "tests", "golden", "dbp5l_ja_el_data.npz")   # the real el / ja triples as integer arrays
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 
 
@@ -89,6 +90,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="dbp5l-ja", choices=["dbp5l-ja", "synth-1m"])
+    ap.add_argument("--data", default="real", choices=["real", "synthetic"],
+                    help="dbp5l-ja workload: the real DBP-5L ja KG (committed integer arrays) or the seeded synthetic graph of "
+                         "the same shape")
     ap.add_argument("--dim", type=int, default=300)
     ap.add_argument("--batch", type=int, default=1000)
     ap.add_argument("--negatives", type=int, default=25)
@@ -173,11 +177,22 @@ def make_args(dim, batch, negatives, device):
 class JaWorkload:
     """Synthetic KG of the DBP-5L ``ja`` shape + the training-step closure."""
 
-    def __init__(self, a, device, seed=1234, bidirectional=False):
+    def __init__(self, a, device, seed=1234, bidirectional=False, data="synthetic"):
         from jmac_amd import synth
         from jmac_amd.model import JMAC
         self.a = a
-        ei, et, n, nr = synth.dbp5l_like("ja", seed, bidirectional)
+        self.data = data
+        if data == "real":
+            # the REAL DBP-5L ja KG (train triples; train.py:130-132 graph, or the loader's bidirectional form with its
+            # 1 221-edge hub and 4 332 isolated entities) from the committed integer arrays; name embeddings and weights
+            # stay seeded random (the fastText vectors and checkpoints are not available offline)
+            from jmac_amd.data import edges_from_triples, load_dbp5l_arrays
+            z = load_dbp5l_arrays(REAL_DATA)
+            ei, et = edges_from_triples(z["ja.train"], bidirectional)
+            n, nr = int(z["ja.num_entity"]), int(z["n_relation_lines"]) + 1
+            self.real_triples = z["ja.train"].astype(np.int64)
+        else:
+            ei, et, n, nr = synth.dbp5l_like("ja", seed, bidirectional)
         self.N, self.E, self.nr, self.d = n, ei.shape[1], nr, a.dim
         rng = np.random.default_rng(seed + 1)
         torch.manual_seed(seed)
@@ -191,10 +206,15 @@ class JaWorkload:
         self.ei = torch.from_numpy(ei).to(device)
         self.et = torch.from_numpy(et).to(device)
         B, K = a.batch, a.negatives
-        trip = rng.integers(0, ei.shape[1], B)
-        self.h = torch.from_numpy(np.tile(ei[0][trip], K + 1)).to(device)
-        self.r = torch.from_numpy(np.tile(et[trip], K + 1)).to(device)
-        self.t = torch.from_numpy(np.concatenate([ei[1][trip], rng.integers(0, n, B * K)])).to(device)
+        if data == "real":                      # a batch of the KG's own training triples (train.py:338-352)
+            trip = rng.integers(0, len(self.real_triples), B)
+            bh, br, bt = (self.real_triples[trip, c] for c in range(3))
+        else:
+            trip = rng.integers(0, ei.shape[1], B)
+            bh, br, bt = ei[0][trip], et[trip], ei[1][trip]
+        self.h = torch.from_numpy(np.tile(bh, K + 1)).to(device)
+        self.r = torch.from_numpy(np.tile(br, K + 1)).to(device)
+        self.t = torch.from_numpy(np.concatenate([bt, rng.integers(0, n, B * K)])).to(device)
         self.pairs = torch.from_numpy(rng.integers(0, n, (2264, 2))).to(device)
         self.state_cpu = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
         self.name_emb = torch.from_numpy(name_emb)
@@ -212,11 +232,19 @@ class JaWorkload:
         return losses.pair_cosine_distance(e1, i1, e2, i2)
 
     def loss_fn(self, align_out, comp, rel, h, r, t, pairs, margin, l1=None, cos=None):
+        """completion loss of both layers (src/jmac_model.py:331-378) + an alignment-style cosine term (:271-273).  On the
+        device: the product's fused ops (triple L1 gathers, margin ranking loss, pair cosine); the oracle legs pass the
+        reference's torch expressions (l1 / cos given: the margin term is then the reference's expression as well)."""
+        on_device = l1 is None
         l1, cos = l1 or self.l1, cos or self.cos
         B = self.a.batch
         loss = 0
         for ent, rl in zip(comp, rel):                                   # src/jmac_model.py:331-378
             score = l1(ent, rl, h, r, t)
+            if on_device:
+                from jmac_amd import losses
+                loss = loss + losses.margin_loss(score, B, margin)
+                continue
             pos = score[:B].view(-1, B).permute(1, 0)
             neg = score[B:].view(-1, B).permute(1, 0)
             loss = loss + torch.max(pos - neg, -margin).mean() + margin
@@ -236,10 +264,23 @@ class JaWorkload:
         return loss
 
     # ---- the oracle on this very workload (checker only: parity assertion below, tests/test_gpu_ja_oracle.py) ------
-    def oracle_pass(self, dtype=torch.float32, kink_masks=None, backward=False):
+    def oracle_pass(self, dtype=torch.float32, kink_masks=None, backward=False, l1_sign_masks=None):
         """One pass of the same step through oracle/jmac_oracle.py (un-factorised reference formulation, PyTorch CPU,
-        dropout off) from the workload's INITIAL parameters: (loss, align_out, comp_layers, {param: grad})."""
+        dropout off) from the workload's INITIAL parameters: (loss, align_out, comp_layers, {param: grad}).
+        ``l1_sign_masks`` (tests only): per completion layer a bool [T, d] pattern -- |v| of the L1 triple score is evaluated as
+        ``where(mask, v, -v)``, i.e. on the other evaluation's side of the kink at v = 0 (same idea as ``kink_masks``);
+        the number of elements whose own sign differs is left in ``self.l1_flips``."""
         import oracle.jmac_oracle as orc
+        l1 = orc.triple_l1_score
+        if l1_sign_masks is not None:
+            todo = list(l1_sign_masks)
+            self.l1_flips = 0
+
+            def l1(ent, rl, h, r, t):
+                m = todo.pop(0)
+                v = (ent[h] + rl[r]) - ent[t]
+                self.l1_flips += int((((v > 0) != m) & (v != 0)).sum())
+                return torch.where(m, v, -v).sum(-1).flatten()
         skip = ("running", "num_batches", "margin_completion")
         st = {k: v.clone().to(dtype if v.dtype.is_floating_point else v.dtype) for k, v in self.state_cpu.items()}
         for k, v in st.items():
@@ -249,7 +290,7 @@ class JaWorkload:
         align_out, comp, rel = orc.forward_name(st, self.name_emb.to(dtype), self.ei.cpu(), self.et.cpu(), [0, self.N],
                                                 [0, self.nr], 2, 0.05, "sub", True, bn, kink_masks=kink_masks)
         loss = self.loss_fn(align_out, comp, rel, self.h.cpu(), self.r.cpu(), self.t.cpu(), self.pairs.cpu(),
-                            st["margin_completion"].detach(), orc.triple_l1_score, orc.pair_cosine_distance)
+                            st["margin_completion"].detach(), l1, orc.pair_cosine_distance)
         grads = {}
         if backward:
             loss.backward()
@@ -769,7 +810,9 @@ def main():
     # (weak scaling: the units all ranks processed / the slowest rank's time).  The destination-sharded RCCL
     # path is measured on config 4 and reported beside it ("sharded").
     tuned = (not a.no_gemm_tuning) and enable_gemm_tuning(rank)
-    w = JaWorkload(a, device, seed=1234 + rank)
+    if a.data == "real" and not os.path.exists(REAL_DATA):
+        raise SystemExit("bench.py: %s is missing (--data synthetic runs the seeded graph of the same shape)" % REAL_DATA)
+    w = JaWorkload(a, device, seed=1234 + rank, data=a.data)
     parity = None
     if rank == 0 and not a.no_parity_check:
         parity = w.check_against_oracle()
@@ -851,9 +894,13 @@ def main():
 
     line = {"metric": "gnn_layer_edges_per_s", "value": value, "unit": "edges/s", "n_gpus": 1, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "DBP-5L ja shape: N=%d E=%d nr=%d d=%d; forward_base (3 RelationAwareLayer calls, "
-                                   "num_gcn_layer=2) fwd+bwd + Adam, batch %dx(1+%d)" % (w.N, w.E, w.nr, w.d, a.batch, a.negatives),
+            "dtype": "f32",
+            "data": ("real DBP-5L ja graph + training triples (committed integer arrays); seeded random name embeddings, "
+                     "random-init weights, uniform negatives") if a.data == "real" else "synthetic",
+            "config": {"workload": "DBP-5L ja%s: N=%d E=%d nr=%d d=%d; forward_base (3 RelationAwareLayer calls, "
+                                   "num_gcn_layer=2) fwd+bwd + Adam, batch %dx(1+%d)"
+                                   % (" (real KG, train-mode graph)" if a.data == "real" else " shape", w.N, w.E, w.nr, w.d,
+                                      a.batch, a.negatives),
                        "exec": exec_mode, "bwd_mode": "deterministic" if a.bwd_mode else "atomic",
                        "library_gemm": "torch.mm (hipBLASLt/rocBLAS), TunableOp %s" % ("on" if tuned else "off"),
                        "edges_counted_per_step": layer_calls * w.E},

@@ -200,6 +200,21 @@ int jmac_bn_tanh_bwd_f32(const float* x, int64_t ldx, const float* y, int64_t ld
                          float* gx, int64_t ldgx, float* gweight, float* gbias, void* ws,
                          size_t ws_bytes, jmac_stream_t stream);
 
+/* The same with a second destination / a second gradient source: the layer's output is an operand of two concatenations in
+ * JMAC.forward_name (src/jmac_model.py:192 cat(comp_l1, align_l1) and :203 cat(align_layers)): the forward writes the rows
+ * into both cat buffers (y2 / ldy2, may be NULL), the backward sums the two incoming gradients (gy2 / ldgy2, may be NULL)
+ * while it reads them -- no cat copy, no gradient add. */
+int jmac_bn_tanh_fwd2_f32(const float* x, int64_t ldx, int64_t N, int64_t d, const float* weight,
+                          const float* bias, float* running_mean, float* running_var,
+                          int32_t training, float momentum, float eps, float* y, int64_t ldy,
+                          float* y2, int64_t ldy2, float* save_mean, float* save_invstd, void* ws,
+                          size_t ws_bytes, jmac_stream_t stream);
+int jmac_bn_tanh_bwd2_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy,
+                          int64_t ldgy, const float* gy2, int64_t ldgy2, int64_t N, int64_t d,
+                          const float* weight, const float* save_mean, const float* save_invstd,
+                          int32_t training, float* gx, int64_t ldgx, float* gweight, float* gbias,
+                          void* ws, size_t ws_bytes, jmac_stream_t stream);
+
 /* Phased forms of the same BatchNorm + tanh for batch statistics that span several ranks (destination-sharded
  * layer): the caller combines the per-rank moments / sums between the phases (torch.distributed over RCCL).
  *   forward : jmac_col_moments_f32 -> mean[d], m2[d] = sum (x - mean)^2 of THIS rank's N rows
@@ -230,6 +245,18 @@ int jmac_row_normalize_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d
 int jmac_row_normalize_bwd_f32(const float* y, int64_t ldy, const float* g, int64_t ldg, const float* inv,
                                int64_t N, int64_t d, float eps, float* gx, int64_t ldgx,
                                jmac_stream_t stream);
+
+/* completion_dropout(F.normalize(x)) in one pass each way (src/jmac_model.py:179,191).  mask [N,d] holds the caller's
+ * {0,1} Bernoulli draws (NULL: no dropout), scale = 1/(1-p); y may be a strided slice of a cat buffer.  The backward keeps
+ * only inv [N] from the forward and recomputes the normalised row from x:  gx (+)= d/dx of the forward applied to g
+ * (accumulate != 0 adds into gx).  d % 4 == 0, leading dimensions % 4 == 0, 16-byte aligned bases. */
+int jmac_row_normalize_drop_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, float eps,
+                                    const float* mask, int64_t ldm, float scale, float* y, int64_t ldy,
+                                    float* inv, jmac_stream_t stream);
+int jmac_row_normalize_drop_bwd_f32(const float* x, int64_t ldx, const float* inv, const float* mask,
+                                    int64_t ldm, float scale, const float* g, int64_t ldg, int64_t N,
+                                    int64_t d, float eps, float* gx, int64_t ldgx, int32_t accumulate,
+                                    jmac_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Completion scoring (replaces: torch.cdist(er, all_kg_emb, p=1), src/jmac_model.py:312; the
@@ -350,6 +377,34 @@ int jmac_gemm_f32(const float* A, int64_t lda, int32_t transA, const float* B, i
                   int32_t transB, int64_t M, int64_t N, int64_t K, float* C, int64_t ldc,
                   jmac_stream_t stream);
 
+/* Grouped form: up to JMAC_GEMM_MAX_TASKS independent small products in ONE launch (the relation side of a training step is
+ * ~40 such products, each launch-bound on its own: products of one dependency level go out together).  `tasks` is a HOST
+ * array; it is copied into the kernel arguments, so the call is safe under stream capture.  Per task:
+ *   C[M,N] (+)= epilogue( op(A) op(B) ),  op as in jmac_gemm_f32;
+ *   a_split > 0: the MEMORY rows >= a_split of A are read from A2 (row index - a_split) -- cat(rel_emb, loop_rel) of
+ *                src/jmac_model.py:39 without the copy; c_split > 0: output rows >= c_split are written to C2 (its adjoint);
+ *   act: JMAC_GEMM_ACT_LEAKY / _RELU apply the activation to the product (src/jmac_model.py:41; DBPv1 :51: ReLU);
+ *        JMAC_GEMM_DACT_LEAKY / _RELU multiply the product by act'(z) where act_src holds act(z) (same shape as C; the
+ *        sign of act(z) is the sign of z for slope > 0) -- the activation's backward fused into the product that
+ *        produces its incoming gradient;
+ *   accumulate != 0: C += (applied after the epilogue).
+ * Exact fp32 products (fp32-input MFMA), fixed summation order per element (bitwise reproducible). */
+#define JMAC_GEMM_MAX_TASKS 24
+#define JMAC_GEMM_ACT_NONE 0
+#define JMAC_GEMM_ACT_LEAKY 1
+#define JMAC_GEMM_ACT_RELU 2
+#define JMAC_GEMM_DACT_LEAKY 3
+#define JMAC_GEMM_DACT_RELU 4
+typedef struct {
+    const float* A;  const float* A2;  int64_t lda;  int64_t a_split;  int32_t transA;  int32_t transB;
+    const float* B;  int64_t ldb;
+    float* C;  float* C2;  int64_t ldc;  int64_t c_split;
+    int64_t M, N, K;
+    const float* act_src;  int64_t ld_act_src;
+    int32_t act;  int32_t accumulate;  float slope;  int32_t pad_;
+} jmac_gemm_task_t;
+int jmac_gemm_grouped_f32(const jmac_gemm_task_t* tasks, int32_t n_tasks, jmac_stream_t stream);
+
 /* fp32 GEMM on the bf16 matrix cores for the N-row dense products of the encoder and of the factorised layer
  * (replaces torch.mm at src/jmac_model.py:177-203 and the hoisted X [Wt|Wb|Wg] projection / its adjoint):
  *   C[M,N] = A[M,K] B[N,K]^T   ("NT": both operands k-contiguous; a weight W [K,N] is passed as its transpose),
@@ -394,6 +449,16 @@ int jmac_pair_cosine_bwd_f32(const float* e1, int64_t ld1, const float* e2, int6
                              const int64_t* i1, const int64_t* i2, int64_t L, int64_t d,
                              const float* gdist, float* de1, int64_t ldd1, float* de2, int64_t ldd2,
                              jmac_stream_t stream);
+
+/* Margin ranking loss of completion_loss (src/jmac_model.py:351-378) on the [B + B*K] score vector of one batch, with the
+ * reference's n-major consumption of the negative block kept (neg_{b,k} = score[B + k*B + b]):
+ *   loss[0] = mean_{b<B,k<K} max(score[b] - neg_{b,k}, -gamma[0]) + gamma[0]
+ * gamma: DEVICE pointer (the model's margin_completion parameter).  bwd: dscore [B + B*K] = gloss[0] * d loss / d score
+ * (a tie diff == -gamma receives half the gradient, as torch.max(a, b) gives it).  One launch each way, fixed summation order. */
+int jmac_margin_loss_fwd_f32(const float* score, int64_t B, int64_t K, const float* gamma, float* loss,
+                             jmac_stream_t stream);
+int jmac_margin_loss_bwd_f32(const float* score, int64_t B, int64_t K, const float* gamma,
+                             const float* gloss, float* dscore, jmac_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * torch_scatter-compatible primitives (replace the third-party calls at src/jmac_model.py:105 and

@@ -36,6 +36,14 @@ class LinkLayer(C.Structure):
     _fields_ = [("ent", vp), ("ld_ent", i64), ("rel", vp), ("ld_rel", i64), ("table", vp), ("ld_table", i64)]
 
 
+class GemmTask(C.Structure):
+    """jmac_gemm_task_t"""
+    _fields_ = [("A", vp), ("A2", vp), ("lda", i64), ("a_split", i64), ("transA", i32), ("transB", i32),
+                ("B", vp), ("ldb", i64), ("C", vp), ("C2", vp), ("ldc", i64), ("c_split", i64),
+                ("M", i64), ("N", i64), ("K", i64), ("act_src", vp), ("ld_act_src", i64),
+                ("act", i32), ("accumulate", i32), ("slope", f32), ("pad_", i32)]
+
+
 # name -> (restype, argtypes); mirrors include/jmac_hip.h one to one
 _SIGS = {
     "jmac_strerror": (C.c_char_p, [C.c_int]),
@@ -64,6 +72,13 @@ _SIGS = {
                                        vp, sz, vp]),
     "jmac_bn_tanh_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, vp, vp, vp, i32, vp, i64, vp, vp,
                                        vp, sz, vp]),
+    "jmac_bn_tanh_fwd2_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, i32, f32, f32, vp, i64, vp, i64, vp, vp,
+                                        vp, sz, vp]),
+    "jmac_bn_tanh_bwd2_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, vp, vp, vp, i32, vp, i64, vp, vp,
+                                        vp, sz, vp]),
+    "jmac_row_normalize_drop_fwd_f32": (C.c_int, [vp, i64, i64, i64, f32, vp, i64, f32, vp, i64, vp, vp]),
+    "jmac_row_normalize_drop_bwd_f32": (C.c_int, [vp, i64, vp, vp, i64, f32, vp, i64, i64, i64, f32, vp, i64, i32, vp]),
+    "jmac_gemm_grouped_f32": (C.c_int, [C.POINTER(GemmTask), i32, vp]),
     "jmac_col_moments_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, sz, vp]),
     "jmac_bn_tanh_apply_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, vp, i64, vp]),
     "jmac_bn_tanh_bwd_sums_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, vp, vp, vp, vp, sz, vp]),
@@ -96,6 +111,8 @@ _SIGS = {
     "jmac_triple_l1_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp, i64, vp, i64, vp]),
     "jmac_pair_cosine_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp]),
     "jmac_pair_cosine_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp]),
+    "jmac_margin_loss_fwd_f32": (C.c_int, [vp, i64, i64, vp, vp, vp]),
+    "jmac_margin_loss_bwd_f32": (C.c_int, [vp, i64, i64, vp, vp, vp, vp]),
     "jmac_scatter_sum_f32": (C.c_int, [vp, vp, i64, i64, i64, vp, vp]),
     "jmac_scatter_softmax_workspace_bytes": (sz, [i64, i64]),
     "jmac_scatter_softmax_f32": (C.c_int, [vp, vp, i64, i64, i64, vp, vp, sz, vp]),

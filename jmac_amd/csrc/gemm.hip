@@ -4,9 +4,9 @@
 // (src/jmac_model.py:40-42), the hoisted rel'' @ [Wb|Wg] of the factorised layer, and JMAC's relation MLPs
 // (src/jmac_model.py:195-196) -- [962,300] x [300,300..600] at DBP-5L size, 36 of them per training step with their
 // backward forms.  A library GEMM spends ~17 us on each (24 workgroups of a 256-CU chip); here one 8-wave block owns
-// a 32x32 output tile, the waves split K, every operand fragment goes from L2 straight to registers (the matrices
-// are ~1 MB: no LDS staging, no barrier inside the K loop) and the partial tiles are summed through LDS in wave
-// order (deterministic).  v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation.
+// a 32x32 output tile: both operand panels are staged through LDS in one coalesced round trip, the waves split K and the
+// partial tiles are summed through LDS in wave order (deterministic).  v_mfma_f32_32x32x2_f32: exact fp32 products,
+// fp32 accumulation.  Products that do not depend on each other share one launch (jmac_gemm_grouped_f32).
 //
 // C[M,N] = op(A) op(B), row-major, op = identity or transpose: the three forms autograd needs
 //   forward  C = A B           (NN)        dA = G B^T  (NT)        dB = A^T G  (TN)
@@ -18,105 +18,296 @@ namespace {
 
 constexpr int kWaves = 8;             // waves per 32x32 tile = K split factor
 constexpr int kBlock = 64 * kWaves;
-constexpr int kAhead = 4;             // K steps in flight per wave ahead of the MFMAs (8 measured no faster)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Fragment of one 8-deep K step for the 32x32x2 MFMA: lane (r = lane & 31, h = lane >> 5) holds the operand's
 // values for row/column r and k = k0 + 4h + s, s = 0..3; MFMA step s then contracts k = {k0 + s, k0 + 4 + s}.
 // KC = true: the operand is stored with k contiguous (row r is a memory row): one 16-byte load.
 // KC = false: stored with r contiguous (k selects the memory row): four 4-byte loads, each coalesced over r.
-template <bool KC, bool VEC>
-__device__ __forceinline__ float4 load_frag(const float* __restrict__ p, int64_t ld, int r, int R, int k, int K) {
-    const int rc = min(r, R - 1);                      // rows past the end feed outputs that are never stored
-    if (KC) {
-        const float* q = p + (int64_t)rc * ld;
-        if (VEC) {                                     // K % 4 == 0, rows 16-byte aligned
-            const float4 v = ld4(q + min(k, K - 4));
-            return k < K ? v : f4zero();
-        }
-        float4 v;
-        v.x = k + 0 < K ? q[k + 0] : 0.f;
-        v.y = k + 1 < K ? q[k + 1] : 0.f;
-        v.z = k + 2 < K ? q[k + 2] : 0.f;
-        v.w = k + 3 < K ? q[k + 3] : 0.f;
-        return v;
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// ---- grouped form: many independent small products in ONE launch ------------------------------------------------------
+// The relation side of a training step is ~40 products of ~10^3 rows (src/jmac_model.py:39-42 per layer, :195-196, the
+// hoisted R''[Wb|Wg], and their backward forms).  Each is far too small to fill the chip, so as separate launches they
+// cost a launch + a latency chain each (~9 us, whatever their size).  Products with no dependence on each other are
+// issued together: the task table travels in the kernel arguments (by value: safe under stream capture), a block finds its
+// task by a scan over the table's tile prefix, and each task carries its own operand forms and epilogue:
+//   act on the output (LeakyReLU / ReLU between the two relation transforms), multiplication by act'(saved output) (the
+//   backward of that activation, fused into the product that produces its input gradient), accumulation into C, an
+//   operand whose last rows live in a second buffer (cat(rel_emb, loop_rel), src/jmac_model.py:39, without the cat) and
+//   an output whose last rows go to a second buffer (its adjoint).
+struct GOperand {
+    const float* p;
+    const float* p2;       // memory rows >= split come from p2 (row index - split)
+    int64_t ld;
+    int32_t split;
+    __device__ __forceinline__ const float* row(int i) const {
+        return i < split ? p + (int64_t)i * ld : p2 + (int64_t)(i - split) * ld;
     }
-    float4 v;
-    v.x = k + 0 < K ? p[(int64_t)(k + 0) * ld + rc] : 0.f;
-    v.y = k + 1 < K ? p[(int64_t)(k + 1) * ld + rc] : 0.f;
-    v.z = k + 2 < K ? p[(int64_t)(k + 2) * ld + rc] : 0.f;
-    v.w = k + 3 < K ? p[(int64_t)(k + 3) * ld + rc] : 0.f;
-    return v;
+};
+struct GTask {
+    GOperand A, B;
+    float* C;
+    float* C2;             // output rows >= c_split go to C2
+    const float* mask;     // act' source (same shape as C)
+    int64_t ldc, ldmask;
+    int32_t M, N, K, c_split;
+    int32_t ta, tb, vec, act, accumulate;
+    float slope;
+    int32_t tiles_n, tile_begin;       // tile_begin: the task's tile count (grid.x bound)
+};
+constexpr int kMaxTasks = JMAC_GEMM_MAX_TASKS;
+struct GTable {
+    GTask t[kMaxTasks];
+};
+
+// ---- one 32x32 output tile per 8-wave block ------------------------------------------------------------------------------
+// Both operand panels of the tile (32 x Kc each, Kc <= kKc = 304) are staged through LDS with fully coalesced 16-byte
+// loads, all of them in flight together: ONE global round trip per K chunk (K <= 304 -- every forward product at d <= 304 --
+// is a single chunk).  The eight waves then split the chunk's 8-deep K steps, read their MFMA fragments from LDS and the
+// partial tiles are summed through LDS in wave order.  (The first form of this kernel loaded fragments straight from L2
+// into registers: 32 rows x 32 bytes per wave instruction, four dependent-latency rounds per wave: 12 us for one
+// 962x300x300 product, 41 us for a level of four.)
+//
+// Panel forms in LDS, chosen by how the operand is stored:
+//   KC ("k contiguous": A not transposed, B transposed)  lds[r * kLdk + k], r < 32: fragment = one ds_read_b128 of k0+4h..+3
+//       (kLdk = 308 = 4 * 77: rows 4*odd banks apart -> the 16-lane groups of a b128 read hit 64 distinct banks)
+//   RC ("r contiguous": A transposed, B not transposed)  lds[k * 32 + r]: fragment = four ds_read_b32, lanes r consecutive
+// Fragment of one 8-deep K step for the 32x32x2 MFMA: lane (r = lane & 31, h = lane >> 5) holds the operand's values for
+// row/column r and k = k0 + 4h + s, s = 0..3; MFMA step s contracts k = {k0 + s, k0 + 4 + s}.
+constexpr int kKc = 304;                       // K chunk (38 steps of 8)
+constexpr int kLdk = 308;                      // row pitch of a KC panel (floats)
+constexpr int kPanel = 32 * kLdk;              // floats per panel (KC form; the RC form needs kKc * 32 <= this)
+constexpr int kStage = (32 * (kKc / 4) + kBlock - 1) / kBlock;      // float4s per thread per panel = 5
+constexpr int kSteps = (kKc / 8 + kWaves - 1) / kWaves;             // K steps per wave per chunk = 5
+constexpr size_t kGroupedLds = (size_t)2 * kPanel * sizeof(float);  // 78 848 B: two blocks per CU
+
+// The task's pointers come out of the kernarg copy as GENERIC pointers: without the casts below every access is a flat_*
+// instruction (aperture check, both vmcnt and lgkmcnt) instead of global_*.
+typedef const float __attribute__((address_space(1))) * gcf_t;
+typedef float __attribute__((address_space(1))) * gf_t;
+typedef const jmac_f32x4 __attribute__((address_space(1))) * gcf4_t;
+__device__ __forceinline__ float gld(const float* p) { return *(gcf_t)p; }
+__device__ __forceinline__ float4 gld4(const float* p) {
+    const jmac_f32x4 v = *(gcf4_t)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gst(float* p, float v) { *(gf_t)p = v; }
+
+// global -> registers: kStage float4s of one panel (unconditional loads at clamped addresses; zeros past K / past the chunk)
+template <bool KC>
+__device__ __forceinline__ void panel_load(const GOperand& o, int r0, int R, int k0, int K, float4 (&v)[kStage]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < kStage; ++i) {
+        const int f = tid + i * kBlock;
+        if (KC) {                                              // f -> (row r, quad q): 76 quads per row
+            const int r = min(f / (kKc / 4), 31), q = f % (kKc / 4);
+            const int k = k0 + 4 * q;
+            v[i] = gld4(o.row(min(r0 + r, R - 1)) + max(min(k, K - 4), 0));
+            if (k >= K) v[i] = f4zero();
+        } else {                                               // f -> (k row kk, quad q of the 32 columns)
+            const int kk = min(f >> 3, kKc - 1), q = f & 7;
+            const int k = k0 + kk;
+            v[i] = gld4(o.row(min(k, K - 1)) + min(r0 + 4 * q, R - 4));
+            if (k >= K) v[i] = f4zero();
+        }
+    }
 }
 
-template <bool TA, bool TB, bool VEC>
-__global__ __launch_bounds__(kBlock) void small_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
-                                                            int64_t ldb, int M, int N, int K, float* __restrict__ C, int64_t ldc,
-                                                            int tiles_n) {
-    __shared__ float red[kWaves - 1][16][64];
+// operands that do not allow 16-byte loads (odd K, unaligned rows, a ragged last column tile of an RC panel): element by
+// element, straight into LDS, in a rolled loop (this path is about correctness for any shape, not speed)
+template <bool KC>
+__device__ __forceinline__ void panel_stage_scalar(const GOperand& o, int r0, int R, int k0, int K, float* __restrict__ lds) {
+#pragma unroll 1
+    for (int f = threadIdx.x; f < 32 * kKc; f += kBlock) {
+        const int r = KC ? f / kKc : f % 32, kk = KC ? f % kKc : f / 32;
+        const int k = k0 + kk, rr = min(r0 + r, R - 1), kc = min(k, K - 1);
+        const float x = KC ? gld(o.row(rr) + kc) : gld(o.row(kc) + rr);
+        lds[KC ? r * kLdk + kk : kk * 32 + r] = k < K ? x : 0.f;
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void panel_store(float* __restrict__ lds, const float4 (&v)[kStage]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < kStage; ++i) {
+        const int f = tid + i * kBlock;
+        if (KC) {
+            if (f < 32 * (kKc / 4)) st4(lds + (f / (kKc / 4)) * kLdk + 4 * (f % (kKc / 4)), v[i]);
+        } else {
+            if (f < kKc * 8) st4(lds + (f >> 3) * 32 + 4 * (f & 7), v[i]);
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ float4 panel_frag(const float* __restrict__ lds, int r, int kk) {
+    if (KC) return ld4(lds + r * kLdk + kk);
+    return make_float4(lds[(kk + 0) * 32 + r], lds[(kk + 1) * 32 + r], lds[(kk + 2) * 32 + r], lds[(kk + 3) * 32 + r]);
+}
+
+// VA / VB: 16-byte global loads are legal for that operand in THIS tile (alignment, leading dimension, K % 4 for the KC form,
+// a full 32-column tile for the RC form)
+// MULTI: K spans several chunks -> the next chunk's global loads are prefetched into registers during the MFMAs;
+// single-chunk products (every forward product at d <= 304) prefetch all of a wave's LDS fragments instead.
+template <bool TA, bool TB, bool VA, bool VB, bool MULTI>
+__device__ __forceinline__ void grouped_tile(const GTask& t, int tile, float* __restrict__ lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
-    // K split over the waves in 8-deep steps
-    const int nsteps = (K + 7) / 8;
+    const int m0 = (tile / t.tiles_n) * 32, n0 = (tile % t.tiles_n) * 32;
+    const int M = t.M, N = t.N, K = t.K;
+    float* la = lds;
+    float* lb = lds + kPanel;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    // op(A)(m, k): TA ? A[k][m] : A[m][k]  -> k contiguous unless TA;   op(B)(k, n): TB ? B[n][k] : B[k][n] -> k contiguous if TB
-    auto fa = [&](int step) { return load_frag<!TA, VEC>(A, lda, m0 + r, M, step * 8 + 4 * h, K); };
-    auto fb = [&](int step) { return load_frag<TB, VEC>(B, ldb, n0 + r, N, step * 8 + 4 * h, K); };
-    // a ring of kAhead fragment pairs: the loads of kAhead steps are in flight while one step's MFMAs run.
-    // Each wave owns a CONTIGUOUS run of steps, so the 128-byte lines of a k-contiguous operand (4 steps each) are
-    // fetched by one wave instead of four.
-    const int per = (nsteps + kWaves - 1) / kWaves;
-    const int sbeg = wave * per, send = min(nsteps, sbeg + per);
-    float4 ra[kAhead], rb[kAhead];
-#pragma unroll
-    for (int j = 0; j < kAhead; ++j) {
-        ra[j] = f4zero();
-        rb[j] = f4zero();
-        if (sbeg + j < send) {
-            ra[j] = fa(sbeg + j);
-            rb[j] = fb(sbeg + j);
+    // chunk loop: the NEXT chunk's global loads are issued before this chunk's MFMAs (registers), so a long-K product
+    // (the weight gradients: K = the ~10^3 relation rows, four chunks) pays one exposed round trip, not four
+    float4 va[kStage], vb[kStage];
+    if constexpr (VA) panel_load<!TA>(t.A, m0, M, 0, K, va);            // 10 loads per thread in flight
+    if constexpr (VB) panel_load<TB>(t.B, n0, N, 0, K, vb);
+    for (int k0 = 0; k0 < K; k0 += kKc) {
+        if (k0 > 0) __syncthreads();                           // the previous chunk's fragments have been read
+        if constexpr (VA) panel_store<!TA>(la, va);
+        else panel_stage_scalar<!TA>(t.A, m0, M, k0, K, la);
+        if constexpr (VB) panel_store<TB>(lb, vb);
+        else panel_stage_scalar<TB>(t.B, n0, N, k0, K, lb);
+        // UNCONDITIONAL (a load issued inside a branch is waited for before the branch is left): past the last chunk the
+        // clamped addresses hit lines this block has just read and the values are never stored
+        if constexpr (MULTI) {
+            if constexpr (VA) panel_load<!TA>(t.A, m0, M, k0 + kKc, K, va);
+            if constexpr (VB) panel_load<TB>(t.B, n0, N, k0 + kKc, K, vb);
         }
-    }
-    for (int base = sbeg; base < send; base += kAhead) {
+        __syncthreads();
+        // wave w takes steps w, w + 8, ... (<= kSteps of them): all their fragments are read first (one LDS latency), the
+        // dependent MFMA chain follows; steps past the chunk read a clamped address and are skipped (wave-uniform test)
+        const int steps = (min(K - k0, kKc) + 7) / 8;          // <= 38
+        if constexpr (!MULTI) {
+            float4 fa[kSteps], fb[kSteps];
 #pragma unroll
-        for (int j = 0; j < kAhead; ++j) {
-            const int s = base + j;
-            if (s < send) {                                    // wave-uniform
-                const float4 a = ra[j], b = rb[j];
-                if (s + kAhead < send) {
-                    ra[j] = fa(s + kAhead);
-                    rb[j] = fb(s + kAhead);
+            for (int j = 0; j < kSteps; ++j) {
+                const int kk = min(wave + j * kWaves, kKc / 8 - 1) * 8 + 4 * h;
+                fa[j] = panel_frag<!TA>(la, r, kk);
+                fb[j] = panel_frag<TB>(lb, r, kk);
+            }
+#pragma unroll
+            for (int j = 0; j < kSteps; ++j) {
+                if (wave + j * kWaves < steps) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].x, fb[j].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].y, fb[j].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].z, fb[j].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].w, fb[j].w, acc, 0, 0, 0);
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            }
+        } else {
+            float4 a = panel_frag<!TA>(la, r, min(wave, kKc / 8 - 1) * 8 + 4 * h), b = panel_frag<TB>(lb, r, min(wave, kKc / 8 - 1) * 8 + 4 * h);
+#pragma unroll
+            for (int j = 0; j < kSteps; ++j) {
+                const int kn = min(wave + (j + 1) * kWaves, kKc / 8 - 1) * 8 + 4 * h;
+                const float4 an = panel_frag<!TA>(la, r, kn), bn = panel_frag<TB>(lb, r, kn);      // one step ahead
+                if (wave + j * kWaves < steps) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+                }
+                a = an;
+                b = bn;
             }
         }
     }
-    // sum the partial tiles in wave order (0 + 1 + ... ): fixed order, bitwise reproducible
-    if (wave > 0) {
+    __syncthreads();                                           // panels are dead: their memory carries the partial tiles
+    // every wave leaves its 16 accumulator registers in LDS; wave w then finishes registers 2w and 2w + 1 of the tile: the
+    // eight partials are summed in wave order (bitwise reproducible), the epilogue's own loads (act' source, accumulate)
+    // are issued together and unconditionally at clamped addresses, the two stores come last with nothing waiting on them
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(lds);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) red[wave - 1][i][lane] = acc[i];
-    }
+    for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
     __syncthreads();
-    if (wave == 0) {
+    const int n = n0 + r, nc = min(n, N - 1);
+    float v[2], msk[2] = {0.f, 0.f}, old[2] = {0.f, 0.f};
+    float* cp[2];
+    const float* mp[2];
+    bool ok[2];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float v = acc[i];
+    for (int j = 0; j < 2; ++j) {
+        const int i = 2 * wave + j;
+        float sum = red[0][i][lane];
 #pragma unroll
-            for (int w = 0; w < kWaves - 1; ++w) v += red[w][i][lane];
-            // C/D map of the 32x32 MFMA: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
-            const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h, n = n0 + r;
-            if (m < M && n < N) C[(int64_t)m * ldc + n] = v;
-        }
+        for (int w = 1; w < kWaves; ++w) sum += red[w][i][lane];
+        v[j] = sum;
+        const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h, mc = min(m, M - 1);
+        ok[j] = m < M && n < N;
+        cp[j] = mc < t.c_split ? t.C + (int64_t)mc * t.ldc + nc : t.C2 + (int64_t)(mc - t.c_split) * t.ldc + nc;
+        mp[j] = t.mask + (int64_t)mc * t.ldmask + nc;
     }
+    // block-uniform branches: a task without these epilogue inputs pays no round trip for them
+    if (t.act == JMAC_GEMM_DACT_LEAKY || t.act == JMAC_GEMM_DACT_RELU) {
+        msk[0] = gld(mp[0]);
+        msk[1] = gld(mp[1]);
+    }
+    if (t.accumulate) {
+        old[0] = gld(cp[0]);
+        old[1] = gld(cp[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float x = v[j];
+        if (t.act == JMAC_GEMM_ACT_LEAKY) x = x > 0.f ? x : x * t.slope;
+        else if (t.act == JMAC_GEMM_ACT_RELU) x = x > 0.f ? x : 0.f;
+        else if (t.act == JMAC_GEMM_DACT_LEAKY) x = msk[j] > 0.f ? x : x * t.slope;
+        else if (t.act == JMAC_GEMM_DACT_RELU) x = msk[j] > 0.f ? x : 0.f;
+        if (t.accumulate) x += old[j];
+        v[j] = x;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (ok[j]) gst(cp[j], v[j]);
 }
 
-inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+__global__ __launch_bounds__(kBlock, 4) void grouped_gemm_kernel(const GTable tab) {   // 4 waves per SIMD = two blocks per CU
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // The table is a by-value kernel argument indexed by a run-time task id.  Indexing `tab` itself makes the compiler copy
+    // all 3.6 KB of it into per-lane scratch; the kernarg segment is ordinary constant memory, so the scan and the one task
+    // this block runs are read from there with scalar loads instead.
+    typedef const GTable __attribute__((address_space(4))) * KTab;
+    KTab kt = (KTab)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)tab;
+    // grid = (largest tile count of the launch, tasks): the task index is blockIdx.y, so the block's only dependent scalar
+    // round trip is the read of its own task (a prefix scan over the table cost two more: ~1 us each from a kernarg buffer
+    // the host has just written); blocks past their task's tile count leave at once
+    GTask t;                                                                 // 38 dwords, block-uniform: SGPRs
+    {
+        typedef const uint32_t __attribute__((address_space(4))) * KWords;
+        KWords src = (KWords)&kt->t[blockIdx.y];
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&t);
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(GTask) / 4; ++i) dst[i] = src[i];
+    }
+    if ((int)blockIdx.x >= t.tile_begin) return;                             // tile_begin holds the task's tile COUNT
+    const int tile = (int)blockIdx.x;
+    // an RC panel (32 tile columns contiguous) takes vector loads only where the whole 32-column tile lies inside the operand
+    const int m0t = (tile / t.tiles_n) * 32, n0t = (tile % t.tiles_n) * 32;
+    const bool va = (t.vec & 1) != 0 && (!t.ta || m0t + 32 <= t.M), vb = (t.vec & 2) != 0 && (t.tb || n0t + 32 <= t.N);
+    const bool multi = t.K > kKc;
+#define JMAC_GG(TA, TB)                                                                   \
+    do {                                                                                  \
+        if (va && vb) {                                                                   \
+            if (multi) grouped_tile<TA, TB, true, true, true>(t, tile, lds);              \
+            else grouped_tile<TA, TB, true, true, false>(t, tile, lds);                   \
+        } else if (va) grouped_tile<TA, TB, true, false, true>(t, tile, lds);             \
+        else if (vb) grouped_tile<TA, TB, false, true, true>(t, tile, lds);               \
+        else grouped_tile<TA, TB, false, false, true>(t, tile, lds);                      \
+    } while (0)
+    if (t.ta && t.tb) JMAC_GG(true, true);
+    else if (t.ta) JMAC_GG(true, false);
+    else if (t.tb) JMAC_GG(false, true);
+    else JMAC_GG(false, false);
+#undef JMAC_GG
+}
 
 }  // namespace
 
@@ -124,28 +315,58 @@ extern "C" {
 
 int jmac_gemm_f32(const float* A, int64_t lda, int32_t transA, const float* B, int64_t ldb, int32_t transB, int64_t M, int64_t N,
                   int64_t K, float* C, int64_t ldc, jmac_stream_t stream) {
-    if (M < 0 || N < 0 || K < 0) return JMAC_EINVAL;
-    if (M == 0 || N == 0) return JMAC_OK;
-    if (!C || (K > 0 && (!A || !B))) return JMAC_EINVAL;
-    if (M >= INT32_MAX || N >= INT32_MAX || K >= INT32_MAX) return JMAC_ERANGE;
-    const int tiles_m = (int)((M + 31) / 32), tiles_n = (int)((N + 31) / 32);
-    if ((int64_t)tiles_m * tiles_n >= INT32_MAX) return JMAC_ERANGE;
-    const dim3 grid((unsigned)(tiles_m * tiles_n)), block(kBlock);
-    hipStream_t st = (hipStream_t)stream;
-    // the 16-byte fragment loads need K % 4 == 0 and 16-byte aligned rows on whichever operands are k-contiguous
-    const bool vec = K >= 4 && K % 4 == 0 && (transA || (lda % 4 == 0 && aligned16(A))) && (!transB || (ldb % 4 == 0 && aligned16(B)));
-#define JMAC_GEMM_LAUNCH(TA, TB)                                                                                            \
-    do {                                                                                                                    \
-        if (vec) hipLaunchKernelGGL((small_gemm_kernel<TA, TB, true>), grid, block, 0, st, A, lda, B, ldb, (int)M, (int)N,  \
-                                    (int)K, C, ldc, tiles_n);                                                               \
-        else hipLaunchKernelGGL((small_gemm_kernel<TA, TB, false>), grid, block, 0, st, A, lda, B, ldb, (int)M, (int)N,     \
-                                (int)K, C, ldc, tiles_n);                                                                   \
-    } while (0)
-    if (transA && transB) JMAC_GEMM_LAUNCH(true, true);
-    else if (transA) JMAC_GEMM_LAUNCH(true, false);
-    else if (transB) JMAC_GEMM_LAUNCH(false, true);
-    else JMAC_GEMM_LAUNCH(false, false);
-#undef JMAC_GEMM_LAUNCH
+    jmac_gemm_task_t t{};                              // one product = a grouped launch of one task
+    t.A = A; t.lda = lda; t.transA = transA; t.B = B; t.ldb = ldb; t.transB = transB;
+    t.C = C; t.ldc = ldc; t.M = M; t.N = N; t.K = K;
+    return jmac_gemm_grouped_f32(&t, 1, stream);
+}
+
+int jmac_gemm_grouped_f32(const jmac_gemm_task_t* tasks, int32_t n_tasks, jmac_stream_t stream) {
+    if (n_tasks < 0 || n_tasks > kMaxTasks || (n_tasks > 0 && !tasks)) return JMAC_EINVAL;
+    GTable tab{};
+    int64_t tiles = 0;
+    int n = 0;
+    for (int i = 0; i < n_tasks; ++i) {
+        const jmac_gemm_task_t& u = tasks[i];
+        if (u.M < 0 || u.N < 0 || u.K < 0) return JMAC_EINVAL;
+        if (u.M == 0 || u.N == 0) continue;
+        if (u.K == 0) return JMAC_EINVAL;                  // an empty contraction: nothing to launch for
+        if (!u.C || (u.K > 0 && (!u.A || !u.B))) return JMAC_EINVAL;
+        if (u.M >= INT32_MAX || u.N >= INT32_MAX || u.K >= INT32_MAX) return JMAC_ERANGE;
+        if (u.act < 0 || u.act > JMAC_GEMM_DACT_RELU) return JMAC_EINVAL;
+        if ((u.act == JMAC_GEMM_DACT_LEAKY || u.act == JMAC_GEMM_DACT_RELU) && !u.act_src) return JMAC_EINVAL;
+        if ((u.a_split > 0 && !u.A2) || (u.c_split > 0 && !u.C2)) return JMAC_EINVAL;
+        GTask& t = tab.t[n++];
+        // the memory rows of A are its M rows (no transpose) or its K rows (transposed); a_split counts memory rows
+        t.A = GOperand{u.A, u.A2, u.lda, u.a_split > 0 ? (int32_t)u.a_split : INT32_MAX};
+        t.B = GOperand{u.B, nullptr, u.ldb, INT32_MAX};
+        t.C = u.C; t.C2 = u.C2; t.ldc = u.ldc; t.c_split = u.c_split > 0 ? (int32_t)u.c_split : INT32_MAX;
+        t.mask = u.act_src; t.ldmask = u.ld_act_src;
+        t.M = (int32_t)u.M; t.N = (int32_t)u.N; t.K = (int32_t)u.K;
+        t.ta = u.transA ? 1 : 0; t.tb = u.transB ? 1 : 0;
+        t.act = u.act; t.accumulate = u.accumulate ? 1 : 0; t.slope = u.slope;
+        // 16-byte staging loads per operand.  KC form (k contiguous): K % 4 == 0, 16-byte aligned rows.  RC form (the 32
+        // tile columns contiguous): 16-byte aligned rows (tile column offsets are multiples of 32 floats).
+        const bool a_kc = !u.transA, b_kc = u.transB != 0;
+        const bool a_al = u.lda % 4 == 0 && aligned16(u.A) && (u.a_split <= 0 || aligned16(u.A2));
+        const bool b_al = u.ldb % 4 == 0 && aligned16(u.B);
+        const bool k4 = u.K >= 4 && u.K % 4 == 0;
+        t.vec = ((a_al && (!a_kc || k4)) ? 1 : 0) | ((b_al && (!b_kc || k4)) ? 2 : 0);
+        t.tiles_n = (int32_t)((u.N + 31) / 32);
+        const int64_t nt = (int64_t)((u.M + 31) / 32) * t.tiles_n;
+        if (nt >= 65536 * 16) return JMAC_ERANGE;
+        t.tile_begin = (int32_t)nt;                    // this launch form: the task's tile count
+        tiles = nt > tiles ? nt : tiles;
+    }
+    if (tiles == 0) return JMAC_OK;
+    static bool lds_ok = false;                       // 77 KB of dynamic LDS per block: above the 64 KB default
+    if (!lds_ok) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kGroupedLds) != hipSuccess)
+            return (int)hipGetLastError();
+        lds_ok = true;
+    }
+    hipLaunchKernelGGL(grouped_gemm_kernel, dim3((unsigned)tiles, (unsigned)n), dim3(kBlock), kGroupedLds, (hipStream_t)stream, tab);
     return (int)hipGetLastError();
 }
 

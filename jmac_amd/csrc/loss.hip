@@ -278,6 +278,49 @@ inline bool vec_ok(int64_t d, std::initializer_list<int64_t> lds, std::initializ
     return true;
 }
 
+// ---- margin ranking loss of completion_loss (src/jmac_model.py:351-378) --------------------------------------------------
+//   pos = score[:B].view(-1, B).permute(1, 0)  [B,1];  neg = score[B:].view(-1, B).permute(1, 0)  [B,K]  (n-major, as consumed)
+//   loss = mean_{b,k} max(pos_b - neg_{b,k}, -gamma) + gamma          with neg_{b,k} = score[B + k*B + b]
+// The reference spends ~10 element-wise launches each way on 26 000 scores; here one block each way.  The sum is reduced
+// in a fixed order (bitwise reproducible).  torch.max(a, b) hands a tie half of the gradient: kept.
+constexpr int kMarginBlock = 1024;
+__global__ __launch_bounds__(kMarginBlock) void margin_loss_fwd_kernel(const float* __restrict__ score, int B, int K,
+                                                                        const float* __restrict__ gamma_p, float* __restrict__ loss) {
+    __shared__ float red[kMarginBlock];
+    const float gamma = gamma_p[0];
+    float acc = 0.f;
+    const int64_t total = (int64_t)B * K;
+    for (int64_t i = threadIdx.x; i < total; i += kMarginBlock) {       // i = k*B + b: coalesced over b
+        const int b = (int)(i % B);
+        acc += fmaxf(score[b] - score[B + i], -gamma);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kMarginBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = red[0] / (float)total + gamma;
+}
+
+// dscore[b] = g/(BK) sum_k w_{b,k};  dscore[B + k*B + b] = -g/(BK) w_{b,k};  w = 1 (diff > -gamma), 1/2 (tie), 0
+__global__ __launch_bounds__(kBlock) void margin_loss_bwd_kernel(const float* __restrict__ score, int B, int K,
+                                                                 const float* __restrict__ gamma_p, const float* __restrict__ gloss,
+                                                                 float* __restrict__ dscore) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    const float gamma = gamma_p[0], c = gloss[0] / ((float)B * (float)K), pos = score[b];
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int64_t j = (int64_t)B + (int64_t)k * B + b;
+        const float diff = pos - score[j];
+        const float w = diff > -gamma ? 1.f : (diff == -gamma ? 0.5f : 0.f);
+        dscore[j] = -c * w;
+        sum += w;
+    }
+    dscore[b] = c * sum;
+}
+
 }  // namespace
 
 extern "C" {
@@ -351,6 +394,22 @@ int jmac_pair_cosine_bwd_f32(const float* e1, int64_t ld1, const float* e2, int6
     else
         hipLaunchKernelGGL(pair_cosine_bwd_kernel<false>, dim3(wave_grid(L)), dim3(kBlock), 0, st, e1, ld1, e2, ld2, i1, i2, L, (int)d,
                            gdist, de1, ldd1, de2, ldd2);
+    return (int)hipGetLastError();
+}
+
+int jmac_margin_loss_fwd_f32(const float* score, int64_t B, int64_t K, const float* gamma, float* loss, jmac_stream_t stream) {
+    if (B <= 0 || K <= 0 || B >= INT32_MAX || K >= INT32_MAX) return JMAC_EINVAL;
+    if (!score || !gamma || !loss) return JMAC_EINVAL;
+    hipLaunchKernelGGL(margin_loss_fwd_kernel, dim3(1), dim3(kMarginBlock), 0, (hipStream_t)stream, score, (int)B, (int)K, gamma, loss);
+    return (int)hipGetLastError();
+}
+
+int jmac_margin_loss_bwd_f32(const float* score, int64_t B, int64_t K, const float* gamma, const float* gloss, float* dscore,
+                             jmac_stream_t stream) {
+    if (B <= 0 || K <= 0 || B >= INT32_MAX || K >= INT32_MAX) return JMAC_EINVAL;
+    if (!score || !gamma || !gloss || !dscore) return JMAC_EINVAL;
+    hipLaunchKernelGGL(margin_loss_bwd_kernel, dim3((unsigned)((B + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, score,
+                       (int)B, (int)K, gamma, gloss, dscore);
     return (int)hipGetLastError();
 }
 

@@ -159,7 +159,8 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, con
 __global__ __launch_bounds__(kBlock) void bn_tanh_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t N, int D4,
                                                                const float* __restrict__ weight, const float* __restrict__ bias,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                               float* __restrict__ y, int64_t ldy) {
+                                                               float* __restrict__ y, int64_t ldy, float* __restrict__ y2,
+                                                               int64_t ldy2) {
     const int64_t total = N * D4;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int64_t r = i / D4;
@@ -172,13 +173,15 @@ __global__ __launch_bounds__(kBlock) void bn_tanh_apply_kernel(const float* __re
         o.z = tanhf(fmaf((v.z - mu.z) * is.z, w.z, b.z));
         o.w = tanhf(fmaf((v.w - mu.w) * is.w, w.w, b.w));
         st4(y + r * ldy + c4 * 4, o);
+        if (y2) st4(y2 + r * ldy2 + c4 * 4, o);         // the same rows into a second (strided) destination: a cat operand
     }
 }
 
 // backward column sums: partial[b][0][c] = sum gz, partial[b][1][c] = sum gz * xhat, gz = gy*(1-y^2)
 __global__ __launch_bounds__(kBlock) void bn_bwd_partial_kernel(const float* __restrict__ x, int64_t ldx,
                                                                 const float* __restrict__ y, int64_t ldy,
-                                                                const float* __restrict__ gy, int64_t ldgy, int64_t N, int D4,
+                                                                const float* __restrict__ gy, int64_t ldgy,
+                                                                const float* __restrict__ gy2, int64_t ldgy2, int64_t N, int D4,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -193,7 +196,12 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_partial_kernel(const float* __r
         if (active) {
             const float4 mu = ld4(mean + c4 * 4), is = ld4(invstd + c4 * 4);
             for (int64_t r = (int64_t)blockIdx.x * rpb + rsub; r < N; r += (int64_t)gridDim.x * rpb) {
-                const float4 xv = ld4(x + r * ldx + c4 * 4), yv = ld4(y + r * ldy + c4 * 4), g = ld4(gy + r * ldgy + c4 * 4);
+                const float4 xv = ld4(x + r * ldx + c4 * 4), yv = ld4(y + r * ldy + c4 * 4);
+                float4 g = ld4(gy + r * ldgy + c4 * 4);
+                if (gy2) {                              // the output fed two consumers: their gradients are summed here
+                    const float4 g2 = ld4(gy2 + r * ldgy2 + c4 * 4);
+                    g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+                }
                 const float gz0 = g.x * (1.f - yv.x * yv.x), gz1 = g.y * (1.f - yv.y * yv.y);
                 const float gz2 = g.z * (1.f - yv.z * yv.z), gz3 = g.w * (1.f - yv.w * yv.w);
                 s1.x += gz0; s1.y += gz1; s1.z += gz2; s1.w += gz3;
@@ -237,7 +245,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int d, fl
 
 __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx,
                                                               const float* __restrict__ y, int64_t ldy,
-                                                              const float* __restrict__ gy, int64_t ldgy, int64_t N, int D4,
+                                                              const float* __restrict__ gy, int64_t ldgy,
+                                                              const float* __restrict__ gy2, int64_t ldgy2, int64_t N, int D4,
                                                               const float* __restrict__ weight, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, const float* __restrict__ gweight,
                                                               const float* __restrict__ gbias, int training, float invn,
@@ -246,7 +255,12 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int64_t r = i / D4;
         const int c4 = (int)(i % D4);
-        const float4 xv = ld4(x + r * ldx + c4 * 4), yv = ld4(y + r * ldy + c4 * 4), g = ld4(gy + r * ldgy + c4 * 4);
+        const float4 xv = ld4(x + r * ldx + c4 * 4), yv = ld4(y + r * ldy + c4 * 4);
+        float4 g = ld4(gy + r * ldgy + c4 * 4);
+        if (gy2) {
+            const float4 g2 = ld4(gy2 + r * ldgy2 + c4 * 4);
+            g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+        }
         const float4 mu = ld4(mean + c4 * 4), is = ld4(invstd + c4 * 4), w = ld4(weight + c4 * 4);
         const float4 gw = ld4(gweight + c4 * 4), gb = ld4(gbias + c4 * 4);
         float4 o;
@@ -316,6 +330,82 @@ __global__ __launch_bounds__(kBlock) void row_normalize_bwd_kernel(const float* 
     }
 }
 
+// ---- F.normalize followed by dropout (src/jmac_model.py:179,191: completion_dropout(F.normalize(.))), one pass each way --------
+// y = x * inv * m  with m = mask * scale (mask: the caller's {0,1} draws; NULL = no dropout).  The backward recomputes the
+// normalised row from x and inv (nothing but inv [N] is kept from the forward):
+//   gn = g * m;  gx (+)= inv * (gn - xn (gn . xn)),  xn = x * inv   (no radial term on rows whose norm was clamped)
+// one wave per row, 16 bytes per lane (d % 4 == 0, leading dimensions % 4 == 0).
+__global__ __launch_bounds__(kBlock) void row_normalize_drop_fwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t N, int D4,
+                                                                        float eps, const float* __restrict__ mask, int64_t ldm,
+                                                                        float scale, float* __restrict__ y, int64_t ldy,
+                                                                        float* __restrict__ inv) {
+    const int lane = lane_id();
+    const int64_t w0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t r = w0; r < N; r += nw) {
+        const float* xr = x + r * ldx;
+        float ss = 0.f;
+        for (int c = lane; c < D4; c += 64) {
+            const float4 v = ld4(xr + c * 4);
+            ss = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ss))));
+        }
+        ss = wave_sum(ss);
+        const float iv = 1.f / fmaxf(sqrtf(ss), eps);
+        for (int c = lane; c < D4; c += 64) {
+            float4 v = ld4(xr + c * 4);
+            v.x *= iv; v.y *= iv; v.z *= iv; v.w *= iv;
+            if (mask) {
+                const float4 m = ld4(mask + r * ldm + c * 4);
+                v.x *= m.x * scale; v.y *= m.y * scale; v.z *= m.z * scale; v.w *= m.w * scale;
+            }
+            st4(y + r * ldy + c * 4, v);
+        }
+        if (lane == 0) inv[r] = iv;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void row_normalize_drop_bwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                        const float* __restrict__ inv,
+                                                                        const float* __restrict__ mask, int64_t ldm, float scale,
+                                                                        const float* __restrict__ g, int64_t ldg, int64_t N, int D4,
+                                                                        float eps, float* __restrict__ gx, int64_t ldgx,
+                                                                        int accumulate) {
+    const int lane = lane_id();
+    const int64_t w0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t r = w0; r < N; r += nw) {
+        const float* xr = x + r * ldx;
+        const float* gr = g + r * ldg;
+        const float iv = inv[r];
+        float dot = 0.f;
+        for (int c = lane; c < D4; c += 64) {
+            const float4 v = ld4(xr + c * 4);
+            float4 q = ld4(gr + c * 4);
+            if (mask) {
+                const float4 m = ld4(mask + r * ldm + c * 4);
+                q.x *= m.x * scale; q.y *= m.y * scale; q.z *= m.z * scale; q.w *= m.w * scale;
+            }
+            dot = fmaf(q.x, v.x * iv, fmaf(q.y, v.y * iv, fmaf(q.z, v.z * iv, fmaf(q.w, v.w * iv, dot))));
+        }
+        dot = wave_sum(dot);
+        if (iv * eps >= 1.f) dot = 0.f;                // ||x|| <= eps: y = x / eps, no radial term
+        for (int c = lane; c < D4; c += 64) {
+            const float4 v = ld4(xr + c * 4);
+            float4 q = ld4(gr + c * 4);
+            if (mask) {
+                const float4 m = ld4(mask + r * ldm + c * 4);
+                q.x *= m.x * scale; q.y *= m.y * scale; q.z *= m.z * scale; q.w *= m.w * scale;
+            }
+            float4 o;
+            o.x = iv * (q.x - v.x * iv * dot); o.y = iv * (q.y - v.y * iv * dot);
+            o.z = iv * (q.z - v.z * iv * dot); o.w = iv * (q.w - v.w * iv * dot);
+            if (accumulate) {
+                const float4 p = ld4(gx + r * ldgx + c * 4);
+                o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+            }
+            st4(gx + r * ldgx + c * 4, o);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -325,11 +415,12 @@ size_t jmac_bn_tanh_workspace_bytes(int64_t N, int64_t d) {
     return align_up((size_t)(kStatBlocks + 1) * 2 * (d > 0 ? d : 0) * 4) + 256;
 }
 
-int jmac_bn_tanh_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, const float* weight, const float* bias,
-                         float* running_mean, float* running_var, int32_t training, float momentum, float eps, float* y,
-                         int64_t ldy, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+int jmac_bn_tanh_fwd2_f32(const float* x, int64_t ldx, int64_t N, int64_t d, const float* weight, const float* bias,
+                          float* running_mean, float* running_var, int32_t training, float momentum, float eps, float* y,
+                          int64_t ldy, float* y2, int64_t ldy2, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                          jmac_stream_t stream) {
     if (N < 0 || !weight || !bias || !save_mean || !save_invstd) return JMAC_EINVAL;
-    if (d <= 0 || d % 4 || ldx % 4 || ldy % 4) return JMAC_EDIM;
+    if (d <= 0 || d % 4 || ldx % 4 || ldy % 4 || (y2 && ldy2 % 4)) return JMAC_EDIM;
     if (N == 0) return JMAC_OK;
     if (!x || !y) return JMAC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -347,16 +438,31 @@ int jmac_bn_tanh_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, cons
                            (int)d, eps, save_mean, save_invstd);
     }
     hipLaunchKernelGGL(bn_tanh_apply_kernel, dim3(stream_grid(N * D4)), dim3(kBlock), 0, st, x, ldx, N, D4, weight, bias,
-                       save_mean, save_invstd, y, ldy);
+                       save_mean, save_invstd, y, ldy, y2, ldy2);
     return (int)hipGetLastError();
+}
+
+int jmac_bn_tanh_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, const float* weight, const float* bias,
+                         float* running_mean, float* running_var, int32_t training, float momentum, float eps, float* y,
+                         int64_t ldy, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    return jmac_bn_tanh_fwd2_f32(x, ldx, N, d, weight, bias, running_mean, running_var, training, momentum, eps, y, ldy, nullptr, 0,
+                                 save_mean, save_invstd, ws, ws_bytes, stream);
 }
 
 int jmac_bn_tanh_bwd_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy, int64_t ldgy, int64_t N,
                          int64_t d, const float* weight, const float* save_mean, const float* save_invstd, int32_t training,
                          float* gx, int64_t ldgx, float* gweight, float* gbias, void* ws, size_t ws_bytes,
                          jmac_stream_t stream) {
+    return jmac_bn_tanh_bwd2_f32(x, ldx, y, ldy, gy, ldgy, nullptr, 0, N, d, weight, save_mean, save_invstd, training, gx, ldgx,
+                                 gweight, gbias, ws, ws_bytes, stream);
+}
+
+int jmac_bn_tanh_bwd2_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
+                          const float* gy2, int64_t ldgy2, int64_t N, int64_t d, const float* weight, const float* save_mean,
+                          const float* save_invstd, int32_t training, float* gx, int64_t ldgx, float* gweight, float* gbias,
+                          void* ws, size_t ws_bytes, jmac_stream_t stream) {
     if (N < 0 || !weight || !save_mean || !save_invstd || !gweight || !gbias) return JMAC_EINVAL;
-    if (d <= 0 || d % 4 || ldx % 4 || ldy % 4 || ldgy % 4 || ldgx % 4) return JMAC_EDIM;
+    if (d <= 0 || d % 4 || ldx % 4 || ldy % 4 || ldgy % 4 || ldgx % 4 || (gy2 && ldgy2 % 4)) return JMAC_EDIM;
     if (!ws || ws_bytes < jmac_bn_tanh_workspace_bytes(N, d)) return JMAC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int D4 = (int)(d / 4);
@@ -365,8 +471,8 @@ int jmac_bn_tanh_bwd_f32(const float* x, int64_t ldx, const float* y, int64_t ld
     if (N > 0) {
         if (!x || !y || !gy || !gx) return JMAC_EINVAL;
         g = stat_grid(N, D4);
-        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g), dim3(kBlock), stat_smem(D4), st, x, ldx, y, ldy, gy, ldgy, N, D4,
-                           save_mean, save_invstd, partial);
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g), dim3(kBlock), stat_smem(D4), st, x, ldx, y, ldy, gy, ldgy, gy2, ldgy2, N,
+                           D4, save_mean, save_invstd, partial);
     }
     if (gweight == gbias + d) {                  // [gbias | gweight] contiguous: the reduction writes them directly
         launch_reduce_rows(partial, (int)g, (int)(2 * d), 1.f, gbias, st);
@@ -376,8 +482,8 @@ int jmac_bn_tanh_bwd_f32(const float* x, int64_t ldx, const float* y, int64_t ld
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, sums, (int)d, gweight, gbias);
     }
     if (N > 0)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(N * D4)), dim3(kBlock), 0, st, x, ldx, y, ldy, gy, ldgy, N, D4,
-                           weight, save_mean, save_invstd, gweight, gbias, training, 1.f / (float)N, gx, ldgx);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(N * D4)), dim3(kBlock), 0, st, x, ldx, y, ldy, gy, ldgy, gy2, ldgy2, N,
+                           D4, weight, save_mean, save_invstd, gweight, gbias, training, 1.f / (float)N, gx, ldgx);
     return (int)hipGetLastError();
 }
 
@@ -402,6 +508,35 @@ int jmac_row_normalize_bwd_f32(const float* y, int64_t ldy, const float* g, int6
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(row_normalize_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, y, ldy, g, ldg, inv, N,
                        (int)d, eps, gx, ldgx);
+    return (int)hipGetLastError();
+}
+
+int jmac_row_normalize_drop_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, float eps, const float* mask, int64_t ldm,
+                                    float scale, float* y, int64_t ldy, float* inv, jmac_stream_t stream) {
+    if (N < 0 || d <= 0 || d >= INT32_MAX) return JMAC_EINVAL;
+    if (d % 4 || ldx % 4 || ldy % 4 || (mask && ldm % 4)) return JMAC_EDIM;
+    if (N == 0) return JMAC_OK;
+    if (!x || !y || !inv) return JMAC_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)mask) & 15) != 0) return JMAC_EDIM;
+    int64_t blocks = (N + kBlock / 64 - 1) / (kBlock / 64);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(row_normalize_drop_fwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, N,
+                       (int)(d / 4), eps, mask, ldm, scale, y, ldy, inv);
+    return (int)hipGetLastError();
+}
+
+int jmac_row_normalize_drop_bwd_f32(const float* x, int64_t ldx, const float* inv, const float* mask, int64_t ldm, float scale,
+                                    const float* g, int64_t ldg, int64_t N, int64_t d, float eps, float* gx, int64_t ldgx,
+                                    int32_t accumulate, jmac_stream_t stream) {
+    if (N < 0 || d <= 0 || d >= INT32_MAX) return JMAC_EINVAL;
+    if (d % 4 || ldx % 4 || ldg % 4 || ldgx % 4 || (mask && ldm % 4)) return JMAC_EDIM;
+    if (N == 0) return JMAC_OK;
+    if (!x || !inv || !g || !gx) return JMAC_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)g | (uintptr_t)gx | (uintptr_t)mask) & 15) != 0) return JMAC_EDIM;
+    int64_t blocks = (N + kBlock / 64 - 1) / (kBlock / 64);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(row_normalize_drop_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, inv, mask,
+                       ldm, scale, g, ldg, N, (int)(d / 4), eps, gx, ldgx, accumulate ? 1 : 0);
     return (int)hipGetLastError();
 }
 
@@ -432,7 +567,7 @@ int jmac_bn_tanh_apply_f32(const float* x, int64_t ldx, int64_t N, int64_t d, co
     if (!x || !y) return JMAC_EINVAL;
     const int D4 = (int)(d / 4);
     hipLaunchKernelGGL(bn_tanh_apply_kernel, dim3(stream_grid(N * D4)), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, N, D4, weight,
-                       bias, mean, invstd, y, ldy);
+                       bias, mean, invstd, y, ldy, (float*)nullptr, (int64_t)0);
     return (int)hipGetLastError();
 }
 
@@ -449,8 +584,8 @@ int jmac_bn_tanh_bwd_sums_f32(const float* x, int64_t ldx, const float* y, int64
     if (N > 0) {
         if (!x || !y || !gy) return JMAC_EINVAL;
         g = stat_grid(N, D4);
-        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g), dim3(kBlock), stat_smem(D4), st, x, ldx, y, ldy, gy, ldgy, N, D4, mean,
-                           invstd, partial);
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g), dim3(kBlock), stat_smem(D4), st, x, ldx, y, ldy, gy, ldgy,
+                           (const float*)nullptr, (int64_t)0, N, D4, mean, invstd, partial);
     }
     launch_reduce_rows(partial, (int)g, (int)(2 * d), 1.f, sums, st);     // sums[0:d] = sum gz, sums[d:2d] = sum gz * xhat
     return (int)hipGetLastError();
@@ -465,7 +600,8 @@ int jmac_bn_tanh_bwd_apply_f32(const float* x, int64_t ldx, const float* y, int6
     if (!x || !y || !gy || !gx) return JMAC_EINVAL;
     const int D4 = (int)(d / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(N * D4)), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, y, ldy, gy, ldgy,
-                       N, D4, weight, mean, invstd, sums + d, sums, 1, 1.f / (float)n_total, gx, ldgx);
+                       (const float*)nullptr, (int64_t)0, N, D4, weight, mean, invstd, sums + d, sums, 1, 1.f / (float)n_total, gx,
+                       ldgx);
     return (int)hipGetLastError();
 }
 

@@ -1013,11 +1013,11 @@ int launch_sim(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t
     // 33 KB of LDS), rounded down to a multiple of 8 so that a block's tile ids stay on its XCD
     static int resident_of[64] = {0};                                   // per device: CU counts may differ between devices
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     int& resident = resident_of[dev >= 0 && dev < 64 ? dev : 0];
     if (resident == 0 || dev >= 64) {
         int cus = 256, occ = 3;
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(sim_gemm_kernel), kBlock, 0) != hipSuccess || occ < 1)
             occ = 3;
         resident = (cus * occ) / 8 * 8;

@@ -52,6 +52,25 @@ def get_kg_edges_for_each(kg_dir: str, language: str, is_target_KG: bool = False
     return np.vstack((np.concatenate(send), np.concatenate(recv))), np.concatenate(typ)
 
 
+def edges_from_triples(triples: np.ndarray, bidirectional: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """(edge_index [2,E] int64, edge_type [E] int64) of a triple list: the train-mode graph of align_data_processing
+    (train.py:116-135: row 0 = heads = aggregation destinations, row 1 = tails), or the loader's bidirectional form
+    (src/utils.py:127-149: every triple in both directions, the reverse edge reusing the relation id)."""
+    t = np.asarray(triples, dtype=np.int64).reshape(-1, 3)
+    if not bidirectional:
+        return np.ascontiguousarray(t[:, [0, 2]].T), np.ascontiguousarray(t[:, 1])
+    return (np.vstack((np.concatenate((t[:, 0], t[:, 2])), np.concatenate((t[:, 2], t[:, 0])))),
+            np.concatenate((t[:, 1], t[:, 1])))
+
+
+def load_dbp5l_arrays(path: str) -> Dict[str, np.ndarray]:
+    """The DBP-5L triples / seed pairs kept as integer arrays in one .npz (``<lang>.train|val|test`` [T,3],
+    ``<lang>.num_entity``, ``n_relation_lines``, ``seed_{train,test}_pairs``): the same content as the on-disk
+    directory ``load_dbp5l`` reads, without the text files."""
+    with np.load(path, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
 def true_tail_dict(triples: np.ndarray) -> Dict[Tuple[int, int], np.ndarray]:
     """get_true_tail, src/knowledgegraph.py:62-86: {(h, r): distinct tails} (the evaluator's filter)."""
     t = np.asarray(triples, dtype=np.int64).reshape(-1, 3)

@@ -1,0 +1,525 @@
+"""JMAC.forward_name / forward_no_name as ONE autograd node each (rows a9, a2-a8 of SURVEY.md section 8).
+
+The reference's encoder (src/jmac_model.py:172-220) is a chain of ~60 small torch ops around three
+RelationAwareLayer calls.  Run op by op on the device, a DBP-5L-size training step spends four fifths of
+its time outside the aggregation kernels: ~40 launch-bound products on the ~10^3-row relation tables,
+cat copies, the zero-fills / copies / adds autograd generates for slices and fan-outs, LeakyReLU passes.
+Here the same function is evaluated by one ``torch.autograd.Function`` with a hand-written backward:
+
+* every product on the relation side -- the layers' two relation transforms and the hoisted R''[Wb|Wg]
+  (src/jmac_model.py:39-42), the two relation MLPs (:195-196), the folded name projection -- goes out in
+  dependency LEVELS through ``jmac_gemm_grouped_f32``: 5 launches forward, 5 backward, activations and their
+  derivatives fused into the products, ``cat(rel_emb, loop_rel)`` read in place from two buffers;
+* the operands of the three concatenations (:180, :192, :203) are WRITTEN into their cat buffers by the
+  kernels that produce them (normalise+dropout, BatchNorm+tanh with two destinations, the library GEMM
+  with a strided output), and their gradients are read from the adjoint buffers in place (BatchNorm's
+  backward sums its two incoming gradients while it reads them);
+* N-row products stay library GEMMs (torch.mm on hipBLASLt / rocBLAS), with ``out=`` views and
+  ``addmm_`` accumulation instead of separate adds; the constant name embeddings get no input gradient.
+
+Same arithmetic as the op-by-op path in ``jmac_amd.model`` (which stays as the second implementation and
+serves every configuration this node does not cover); tests/test_gpu_encoder.py holds the two to each other.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+from ._lib import GemmTask, check, lib, ptr, require_device, stream
+from .graph import RelGraph
+
+ACT_NONE, ACT_LEAKY, ACT_RELU, DACT_LEAKY, DACT_RELU = 0, 1, 2, 3, 4
+MAX_TASKS = 24
+# tests set this to a dict to receive {layer name: (ent_emb, rel_emb)} -- the inputs each RelationAwareLayer call of the
+# encoder sees (what a forward pre-hook on the layer modules shows on the op-by-op path)
+CAPTURE = None
+
+
+# ---- grouped small GEMM -------------------------------------------------------------------------------------------------
+def gemm_task(A, B, Cout, *, ta=False, tb=False, A2=None, C2=None, act=ACT_NONE, act_src=None, slope=0.0, accumulate=False):
+    """One product ``Cout (+)= epilogue(op(A) op(B))`` for jmac_gemm_grouped_f32.  ``A2`` / ``C2``: the rows of A (its
+    MEMORY rows: the K rows when ``ta``) / of the output that follow A's / Cout's own rows live in a second buffer."""
+    for t in (A, B, Cout, A2, C2, act_src):
+        if t is not None and (t.dtype != torch.float32 or t.stride(-1) != 1):
+            raise TypeError("grouped GEMM operands are fp32 with unit inner stride")
+    a_rows = A.shape[0] + (A2.shape[0] if A2 is not None else 0)
+    M, K = (A.shape[1], a_rows) if ta else (a_rows, A.shape[1])
+    Kb, N = (B.shape[1], B.shape[0]) if tb else (B.shape[0], B.shape[1])
+    c_rows = Cout.shape[0] + (C2.shape[0] if C2 is not None else 0)
+    if K != Kb or c_rows != M or Cout.shape[1] != N:
+        raise ValueError("grouped GEMM shapes: op(A) [%d,%d] op(B) [%d,%d] -> C [%d,%d]" % (M, K, Kb, N, c_rows, Cout.shape[1]))
+    if A2 is not None and (A2.shape[1] != A.shape[1] or A2.stride(0) != A.stride(0)) and A2.shape[0] > 1:
+        raise ValueError("A2 must share A's width and leading dimension")
+    t = GemmTask()
+    t.A, t.A2, t.lda, t.a_split = ptr(A), ptr(A2), A.stride(0), (A.shape[0] if A2 is not None else 0)
+    t.transA, t.transB = int(ta), int(tb)
+    t.B, t.ldb = ptr(B), B.stride(0)
+    t.C, t.C2, t.ldc, t.c_split = ptr(Cout), ptr(C2), Cout.stride(0), (Cout.shape[0] if C2 is not None else 0)
+    t.M, t.N, t.K = M, N, K
+    t.act_src, t.ld_act_src = ptr(act_src), (act_src.stride(0) if act_src is not None else 0)
+    t.act, t.accumulate, t.slope = int(act), int(bool(accumulate)), float(slope)
+    t._keep = (A, B, Cout, A2, C2, act_src)          # the tensors outlive the (asynchronous) launch
+    return t
+
+
+def grouped_gemm(tasks: Sequence[GemmTask]) -> None:
+    """All ``tasks`` in one launch (they must not depend on each other's outputs)."""
+    tasks = [t for t in tasks if t is not None]
+    for i in range(0, len(tasks), MAX_TASKS):
+        chunk = tasks[i:i + MAX_TASKS]
+        arr = (GemmTask * len(chunk))(*chunk)
+        check(lib().jmac_gemm_grouped_f32(arr, len(chunk), stream()), "jmac_gemm_grouped_f32")
+
+
+def run_levels(levels: List[List[GemmTask]]) -> None:
+    for lv in levels:
+        if lv:
+            grouped_gemm(lv)
+
+
+# ---- raw kernel wrappers (no autograd: the node below owns the backward) --------------------------------------------------
+def _empty(dev, *shape):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+def _agg_fwd(PQZ, RR, a, graph: RelGraph, slope, out_scale=0.5):
+    """jmac_rel_attn_aggregate_fwd_f32 on the [P|Q|Z] table; the self loop is the last relation row."""
+    L = lib()
+    N, d3 = PQZ.shape
+    d = d3 // 3
+    dev = PQZ.device
+    out, smax, sden = _empty(dev, N, d), _empty(dev, max(N, 1)), _empty(dev, max(N, 1))
+    s = graph.by_dst
+    wsb = int(L.jmac_rel_attn_fwd_workspace_bytes(s.n_parts_max, d))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    ev0 = ops._ev() if ops.PROFILE is not None else None
+    check(L.jmac_rel_attn_aggregate_fwd_f32(
+        ptr(PQZ), d3, PQZ.data_ptr() + d * 4, d3, ptr(RR), RR.stride(0), ptr(a), ptr(graph.col), ptr(graph.etype),
+        C.byref(s.view()), N, d, float(slope), RR.shape[0] - 1, 0, float(out_scale), ptr(out), d, ptr(smax), ptr(sden),
+        ptr(ws), wsb, stream()), "jmac_rel_attn_aggregate_fwd_f32")
+    if ev0 is not None:
+        ops.PROFILE.append(("rel_attn_fwd", ev0, ops._ev()))
+    return out, smax, sden
+
+
+def _agg_bwd(PQZ, RR, a, graph: RelGraph, slope, out, smax, sden, G, out_scale=0.5):
+    """Deterministic backward (three launches): dPQZ [N,3d], dRR [nrel,2d], da [d]."""
+    L = lib()
+    N, d3 = PQZ.shape
+    d = d3 // 3
+    dev = PQZ.device
+    nrel = RR.shape[0]
+    graph.ensure_backward_views()
+    dPQZ, dRR, da = _empty(dev, N, d3), _empty(dev, nrel, 2 * d), _empty(dev, d)
+    vd, vs, vr = graph.by_dst.view(), graph.by_src.view(), graph.by_rel.view()
+    wsb = int(L.jmac_rel_attn_bwd_workspace_bytes(N, graph.E, nrel, d, graph.by_dst.n_parts_max, graph.by_src.n_parts_max,
+                                                  graph.by_rel.n_parts_max, 1))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    ev0 = ops._ev() if ops.PROFILE is not None else None
+    check(L.jmac_rel_attn_aggregate_bwd_f32(
+        ptr(PQZ), d3, PQZ.data_ptr() + d * 4, d3, ptr(RR), RR.stride(0), ptr(a), ptr(graph.col), ptr(graph.etype),
+        ptr(graph.dst_of_slot), C.byref(vd), C.byref(vs), C.byref(vr), N, N, graph.E, nrel, d, float(slope), nrel - 1, 0,
+        float(out_scale), ptr(out), d, ptr(smax), ptr(sden), ptr(G), G.stride(0), ptr(dPQZ), d3, dPQZ.data_ptr() + d * 4, d3,
+        ptr(dRR), 2 * d, ptr(da), 1, ptr(ws), wsb, stream()), "jmac_rel_attn_aggregate_bwd_f32")
+    if ev0 is not None:
+        ops.PROFILE.append(("rel_attn_bwd", ev0, ops._ev()))
+    return dPQZ, dRR, da
+
+
+def _bn_fwd(x, bn, training, y, y2=None):
+    """tanh(BatchNorm1d(x)) into y (and y2), nn.BatchNorm1d bookkeeping included (src/jmac_model.py:52)."""
+    L = lib()
+    N, d = x.shape
+    dev = x.device
+    mean, invstd = _empty(dev, d), _empty(dev, d)
+    wsb = int(L.jmac_bn_tanh_workspace_bytes(N, d))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    use_batch = bool(training or not bn.track_running_stats)
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    check(L.jmac_bn_tanh_fwd2_f32(ptr(x), x.stride(0), N, d, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+                                  ptr(bn.running_var), 1 if use_batch else 0, float(bn.momentum), float(bn.eps), ptr(y),
+                                  y.stride(0), ptr(y2), y2.stride(0) if y2 is not None else 0, ptr(mean), ptr(invstd), ptr(ws),
+                                  wsb, stream()), "jmac_bn_tanh_fwd2_f32")
+    return mean, invstd, use_batch
+
+
+def _bn_bwd(x, y, gy, gy2, weight, mean, invstd, use_batch):
+    L = lib()
+    N, d = x.shape
+    dev = x.device
+    gx, gbw = _empty(dev, N, d), _empty(dev, 2 * d)            # gbw = [grad bias | grad weight]
+    wsb = int(L.jmac_bn_tanh_workspace_bytes(N, d))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    check(L.jmac_bn_tanh_bwd2_f32(ptr(x), x.stride(0), ptr(y), y.stride(0), ptr(gy), gy.stride(0), ptr(gy2),
+                                  gy2.stride(0) if gy2 is not None else 0, N, d, ptr(weight), ptr(mean), ptr(invstd),
+                                  1 if use_batch else 0, ptr(gx), d, gbw.data_ptr() + d * 4, ptr(gbw), ptr(ws), wsb, stream()),
+          "jmac_bn_tanh_bwd2_f32")
+    return gx, gbw
+
+
+def _norm_drop_fwd(x, p_drop, training, y):
+    """completion_dropout(F.normalize(x)) into y (src/jmac_model.py:179,191): (inv, mask, scale)."""
+    N, d = x.shape
+    mask, scale = None, 1.0
+    if training and p_drop > 0.0:
+        mask = torch.empty((N, d), dtype=torch.float32, device=x.device).bernoulli_(1.0 - p_drop)
+        scale = 1.0 / (1.0 - p_drop)
+    inv = _empty(x.device, max(N, 1))
+    check(lib().jmac_row_normalize_drop_fwd_f32(ptr(x), x.stride(0), N, d, 1e-12, ptr(mask), d, scale, ptr(y), y.stride(0),
+                                                ptr(inv), stream()), "jmac_row_normalize_drop_fwd_f32")
+    return inv, mask, scale
+
+
+def _norm_drop_bwd(x, inv, mask, scale, g, gx, accumulate):
+    N, d = x.shape
+    check(lib().jmac_row_normalize_drop_bwd_f32(ptr(x), x.stride(0), ptr(inv), ptr(mask), d, scale, ptr(g), g.stride(0), N, d,
+                                                1e-12, ptr(gx), gx.stride(0), 1 if accumulate else 0, stream()),
+          "jmac_row_normalize_drop_bwd_f32")
+
+
+# ---- layer pieces -------------------------------------------------------------------------------------------------------
+LAYER_PARAMS = ("rel_transform_weight1", "rel_transform_weight2", "loop_rel", "w_att", "a_att", "gcn_weight")
+
+
+def _layer_inputs(lay):
+    return [getattr(lay, n) for n in LAYER_PARAMS] + [lay.bn.weight, lay.bn.bias]
+
+
+def _wcat(w_att, gcn, d):
+    """[Wt | Wb | Wgcn] [d, 3d] (w_att = [Wt; Wb] stacked by rows, src/jmac_model.py:24,75-76)."""
+    return torch.cat((w_att[:d], w_att[d:], gcn), dim=1)
+
+
+class _Chain:
+    """The relation side of one layer: R'' = act(cat(R, loop) W1) W2 (src/jmac_model.py:39-42), RR = R'' [Wb|Wg]."""
+
+    def __init__(self, lay, R, W1, W2, loop, wc, d):
+        dev, nr = R.device, R.shape[0]
+        self.R, self.W1, self.W2, self.loop, self.wc, self.d, self.nr = R, W1, W2, loop, wc, d, nr
+        self.relu = lay.rel_activation == "relu"
+        self.slope = float(lay.atv_mlp.negative_slope)
+        self.T, self.R2, self.RR = _empty(dev, nr + 1, d), _empty(dev, nr + 1, d), _empty(dev, nr + 1, 2 * d)
+
+    def fwd_tasks(self):
+        """three dependent products: one task per level"""
+        return [gemm_task(self.R, self.W1, self.T, A2=self.loop, act=ACT_RELU if self.relu else ACT_LEAKY, slope=self.slope),
+                gemm_task(self.T, self.W2, self.R2),
+                gemm_task(self.R2, self.wc[:, self.d:], self.RR)]
+
+    def bwd_tasks(self, dRR, dwc, dR, dR_accumulate):
+        """three levels; weight gradients ride along.  dwc[:, d:] accumulates (the node side wrote it first); dR receives
+        d R (rows < nr).  Returns (levels, (dW1, dW2, dloop)) -- the gradients are NOT kept on self: a second reference
+        makes autograd's AccumulateGrad clone every one of them instead of taking the buffer."""
+        dev, d, nr = dRR.device, self.d, self.nr
+        dR2, dT = _empty(dev, nr + 1, d), _empty(dev, nr + 1, d)
+        dW1, dW2, dloop = _empty(dev, d, d), _empty(dev, d, d), _empty(dev, 1, d)
+        dact = DACT_RELU if self.relu else DACT_LEAKY
+        return [[gemm_task(dRR, self.wc[:, d:], dR2, tb=True),
+                 gemm_task(self.R2, dRR, dwc[:, d:], ta=True, accumulate=True)],
+                [gemm_task(dR2, self.W2, dT, tb=True, act=dact, act_src=self.T, slope=self.slope),
+                 gemm_task(self.T, dR2, dW2, ta=True)],
+                [gemm_task(dT, self.W1, dR, tb=True, C2=dloop, accumulate=dR_accumulate),
+                 gemm_task(self.R, dT, dW1, ta=True, A2=self.loop)]], (dW1, dW2, dloop)
+
+
+class _RelMLP:
+    """leaky(R W1) W2 (src/jmac_model.py:195-196)."""
+
+    def __init__(self, R, W1, W2, slope):
+        dev, nr, d = R.device, R.shape[0], W1.shape[1]
+        self.R, self.W1, self.W2, self.slope = R, W1, W2, float(slope)
+        self.M, self.out = _empty(dev, nr, d), _empty(dev, nr, W2.shape[1])
+
+    def fwd_tasks(self):
+        return [gemm_task(self.R, self.W1, self.M, act=ACT_LEAKY, slope=self.slope), gemm_task(self.M, self.W2, self.out)]
+
+    def bwd_tasks(self, g, dR, dR_accumulate):
+        """two levels -> (levels, (dW1, dW2))"""
+        dev = g.device
+        dM = _empty(dev, *self.M.shape)
+        dW1, dW2 = _empty(dev, *self.W1.shape), _empty(dev, *self.W2.shape)
+        return [[gemm_task(g, self.W2, dM, tb=True, act=DACT_LEAKY, act_src=self.M, slope=self.slope),
+                 gemm_task(self.M, g, dW2, ta=True)],
+                [gemm_task(dM, self.W1, dR, tb=True, accumulate=dR_accumulate),
+                 gemm_task(self.R, dM, dW1, ta=True)]], (dW1, dW2)
+
+
+def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None):
+    """Node side of one RelationAwareLayer (src/jmac_model.py:44-52) given its relation tables: state for the backward."""
+    PQZ = torch.mm(X, wc)                                             # [P|Q|Z]: one library GEMM
+    slope = float(lay.atv_mlp.negative_slope)
+    pre, smax, sden = _agg_fwd(PQZ, RR, a, graph, slope)
+    mean, invstd, use_batch = _bn_fwd(pre, lay.bn, training, y, y2)
+    return SimpleNamespace(X=X, wc=wc, RR=RR, a=a, PQZ=PQZ, pre=pre, smax=smax, sden=sden, y=y, mean=mean, invstd=invstd,
+                           use_batch=use_batch, slope=slope, bn_weight=lay.bn.weight)
+
+
+def _layer_bwd(st, graph, gy, gy2, dX, dX_accumulate):
+    """Backward of _layer_fwd.  dX: destination of the input gradient (None: not needed).  Returns dRR, dwc (node part),
+    da, gbw."""
+    gpre, gbw = _bn_bwd(st.pre, st.y, gy, gy2, st.bn_weight, st.mean, st.invstd, st.use_batch)
+    dPQZ, dRR, da = _agg_bwd(st.PQZ, st.RR, st.a, graph, st.slope, st.pre, st.smax, st.sden, gpre)
+    if dX is not None:
+        if dX_accumulate:
+            dX.addmm_(dPQZ, st.wc.t())
+        else:
+            torch.mm(dPQZ, st.wc.t(), out=dX)
+    dwc = torch.mm(st.X.t(), dPQZ)                                    # [d, 3d]
+    return dRR, dwc, da, gbw
+
+
+def _layer_grads(chain_grads, dwc, da, gbw, d):
+    """Gradients of one layer's parameters in LAYER_PARAMS + (bn.weight, bn.bias) order."""
+    dW1, dW2, dloop = chain_grads
+    d_watt = torch.cat((dwc[:, :d], dwc[:, d:2 * d]), dim=0)          # back to the [2d, d] stacking of w_att
+    return [dW1, dW2, dloop, d_watt, da.view(d, 1), dwc[:, 2 * d:], gbw[d:], gbw[:d]]
+
+
+def supported(model, info_dim: Optional[int]) -> bool:
+    """What the fused nodes cover: comp_op 'sub', fp32 tables, d % 4 == 0 (16-byte rows), tanh layers with an ordinary
+    BatchNorm momentum, two GNN layers.  Everything else runs op by op (jmac_amd.model)."""
+    a = model.args
+    d = model.entity_dim
+    lays = (model.conv1_alignment, model.conv2_alignment, model.conv1_completion)
+    return (getattr(a, "num_gcn_layer", 2) == 2 and d % 4 == 0 and (info_dim is None or info_dim % 4 == 0)
+            and getattr(model, "table_dtype", torch.float32) == torch.float32
+            and all(l.comp_op == "sub" and l.layer_act is torch.tanh and l.bn.momentum is not None and l.bn.affine
+                    and l.table_dtype == torch.float32 and l.in_channels == d and l.out_channels == d for l in lays))
+
+
+# ---- forward_name ---------------------------------------------------------------------------------------------------------
+class _EncoderName(torch.autograd.Function):
+    """JMAC.forward_name (src/jmac_model.py:172-204), num_gcn_layer = 2.
+
+    inputs : cfg, E (comp_att), Rc (rel_comp), Ra (rel_align), info, name_linear, uni_linear1_1, uni_linear2_1,
+             all_linear_completion, rel_linear11, rel_linear12, rel_linear11_uni, rel_linear12_uni,
+             8 tensors per layer (conv1_alignment, conv1_completion, conv2_alignment)
+    outputs: align_out [N,d], c1 = completion layer 1 [N,d], rel_c1 [nr,d]"""
+
+    @staticmethod
+    def forward(ctx, cfg, E, Rc, Ra, info, NL, U11, U21, Wall, L11, L12, L11u, L12u, *lp):
+        require_device(E, Rc, Ra, info)
+        la, lc, l2 = cfg.layers
+        pa, pc, p2 = lp[0:8], lp[8:16], lp[16:24]
+        graph, training, p_drop, mslope = cfg.graph, cfg.training, cfg.p_drop, cfg.mlp_slope
+        dev = E.device
+        N, d = E.shape
+        di = info.shape[1]
+        t = SimpleNamespace()
+        # weights: [Wt|Wb|Wg] per layer
+        t.wc = [_wcat(p[3], p[5], d) for p in (pa, pc, p2)]
+        # ---- relation side: five dependency levels, one launch each
+        t.cha = _Chain(la, Ra, pa[0], pa[1], pa[2], t.wc[0], d)
+        t.chc = _Chain(lc, Rc, pc[0], pc[1], pc[2], t.wc[1], d)
+        t.mlc = _RelMLP(Rc, L11, L12, mslope)                          # rel_c1      (:195)
+        t.mla = _RelMLP(Ra, L11u, L12u, mslope)                        # rel_a_in    (:196)
+        t.ch2 = _Chain(l2, t.mla.out, p2[0], p2[1], p2[2], t.wc[2], d)
+        # :177 + :180  cat(comp0, info @ name_linear) @ U11  ==  cat(comp0, info) @ [U11_top ; name_linear @ U11_bottom]
+        t.w = _empty(dev, d + di, d)
+        t.w[:d].copy_(U11[:d])
+        fa, fc, f2, ma, mc = t.cha.fwd_tasks(), t.chc.fwd_tasks(), t.ch2.fwd_tasks(), t.mla.fwd_tasks(), t.mlc.fwd_tasks()
+        run_levels([[fa[0], fc[0], ma[0], mc[0], gemm_task(NL, U11[d:], t.w[d:])],
+                    [fa[1], fc[1], ma[1], mc[1]],
+                    [fa[2], fc[2], f2[0]],
+                    [f2[1]],
+                    [f2[2]]])
+        # ---- node side.  cat buffers: cat0 = [comp0 | info] (:180), cat1 = [c1n | a1] (:192), catA = [align0 | a1 | a2] (:203)
+        t.cat0, t.cat1, t.catA = _empty(dev, N, d + di), _empty(dev, N, 2 * d), _empty(dev, N, 3 * d)
+        t.inv0, t.mask0, t.scale0 = _norm_drop_fwd(E, p_drop, training, t.cat0[:, :d])          # :179
+        t.cat0[:, d:].copy_(info)
+        align0 = t.catA[:, :d]
+        torch.mm(t.cat0, t.w, out=align0)                                                       # :180
+        a_att = [p[4].reshape(-1) for p in (pa, pc, p2)]
+        t.sa = _layer_fwd(la, align0, t.wc[0], t.cha.RR, a_att[0], graph, training, t.catA[:, d:2 * d], t.cat1[:, d:])   # :183
+        c1 = _empty(dev, N, d)
+        t.sc = _layer_fwd(lc, E, t.wc[1], t.chc.RR, a_att[1], graph, training, c1)              # :190
+        t.inv1, t.mask1, t.scale1 = _norm_drop_fwd(c1, p_drop, training, t.cat1[:, :d])         # :191
+        t.a_in = torch.mm(t.cat1, U21)                                                          # :192
+        t.s2 = _layer_fwd(l2, t.a_in, t.wc[2], t.ch2.RR, a_att[2], graph, training, t.catA[:, 2 * d:])               # :197
+        align_out = torch.mm(t.catA, Wall)                                                      # :203
+        if CAPTURE is not None:
+            CAPTURE.update(conv1_alignment=(align0.clone(), Ra.detach()), conv1_completion=(E.detach(), Rc.detach()),
+                           conv2_alignment=(t.a_in.clone(), t.mla.out.clone()))
+            for name, st in (("conv1_alignment", t.sa), ("conv1_completion", t.sc), ("conv2_alignment", t.s2)):
+                CAPTURE[name + ".tables"] = (st.PQZ, st.RR)              # the very tables the aggregation kernel gathered
+        # c1 and rel_c1 are OUTPUTS: they reach the backward through save_for_backward / not at all (an attribute on ctx
+        # would tie the output to its own grad_fn in a reference cycle)
+        rel_c1, t.mlc.out, t.sc.y = t.mlc.out, None, None
+        ctx.t, ctx.cfg, ctx.dims = t, cfg, (N, d, di)
+        ctx.save_for_backward(E, Rc, Ra, NL, U11, U21, Wall, L11, L12, L11u, L12u, c1)
+        return align_out, c1, rel_c1
+
+    @staticmethod
+    def backward(ctx, g_align, g_c1, g_relc1):
+        t, cfg = ctx.t, ctx.cfg
+        N, d, di = ctx.dims
+        E, Rc, Ra, NL, U11, U21, Wall, L11, L12, L11u, L12u, c1 = ctx.saved_tensors
+        # c1 is an OUTPUT of this node (the unpacked tensor carries this node as grad_fn): it must not be stored on ctx.t --
+        # that cycle keeps the whole graph (and the parameters' AccumulateGrad nodes, with the stream they were created on)
+        # alive past the step, which breaks a later stream capture
+        sc = SimpleNamespace(**vars(t.sc))
+        sc.y = c1
+        graph = cfg.graph
+        dev = E.device
+        have_align = g_align is not None
+        have_c = have_align or g_c1 is not None
+        dE = None
+        dRa = dRc = None
+        dWall = dU21 = dU11 = dNL = gL11 = gL12 = gL11u = gL12u = None
+        ga = gc = g2 = [None] * 8
+        levels: List[List[GemmTask]] = [[] for _ in range(5)]
+
+        def add(first_level, tasks_and_grads):
+            task_levels, grads = tasks_and_grads
+            for i, lv in enumerate(task_levels):
+                levels[first_level + i].extend(lv)
+            return grads
+
+        if have_align:
+            g_align = g_align.contiguous()
+            dcatA = torch.mm(g_align, Wall.t())                                  # [N,3d]: d align0 | d a1 | d a2
+            dWall = torch.mm(t.catA.t(), g_align)
+            # conv2_alignment
+            d_ain = _empty(dev, N, d)
+            dRR2, dwc2, da2, gbw2 = _layer_bwd(t.s2, graph, dcatA[:, 2 * d:], None, d_ain, False)
+            dcat1 = torch.mm(d_ain, U21.t())                                     # [N,2d]: d c1n | d a1
+            dU21 = torch.mm(t.cat1.t(), d_ain)
+        # conv1_completion: gradient of c1 = normalise/dropout adjoint of d c1n (+ the loss' own gradient)
+        if have_c:
+            gy, gy2 = None, None
+            if have_align:
+                gy = _empty(dev, N, d)
+                _norm_drop_bwd(c1, t.inv1, t.mask1, t.scale1, dcat1[:, :d], gy, False)
+                gy2 = g_c1.contiguous() if g_c1 is not None else None
+            else:
+                gy = g_c1.contiguous()
+            dE = _empty(dev, N, d)
+            dRRc, dwcc, dac, gbwc = _layer_bwd(sc, graph, gy, gy2, dE, False)
+        if have_align:
+            # conv1_alignment: its output fed cat1 and catA -> two gradient sources; its input is align0 = catA[:, :d]
+            d_align0 = dcatA[:, :d]
+            dRRa, dwca, daa, gbwa = _layer_bwd(t.sa, graph, dcatA[:, d:2 * d], dcat1[:, d:], d_align0, True)
+            # align0 = cat0 @ w: only comp0 needs an input gradient (the name embeddings are constants)
+            d_comp0 = torch.mm(d_align0, t.w[:d].t())
+            dw = torch.mm(t.cat0.t(), d_align0)                                  # [d+di, d]
+            _norm_drop_bwd(E, t.inv0, t.mask0, t.scale0, d_comp0, dE, True)
+            dU11 = _empty(dev, 2 * d, d)
+            dU11[:d].copy_(dw[:d])
+            dNL = _empty(dev, di, d)
+            levels[0].extend([gemm_task(dw[d:], U11[d:], dNL, tb=True), gemm_task(NL, dw[d:], dU11[d:], ta=True)])
+        # ---- relation side
+        if have_align or g_relc1 is not None or have_c:
+            dRa_buf, dRc_buf = _empty(dev, *Ra.shape), _empty(dev, *Rc.shape)
+            wrote_a = wrote_c = False
+            if have_align:
+                d_rain = _empty(dev, *t.mla.out.shape)
+                cg2 = add(0, t.ch2.bwd_tasks(dRR2, dwc2, d_rain, False))          # levels 0-2 -> d rel_a_in
+                cga = add(0, t.cha.bwd_tasks(dRRa, dwca, dRa_buf, False))        # levels 0-2 -> d rel_align (first writer)
+                wrote_a = True
+                gL11u, gL12u = add(3, t.mla.bwd_tasks(d_rain, dRa_buf, True))    # levels 3-4 -> d rel_align +=
+            if have_c:
+                cgc = add(0, t.chc.bwd_tasks(dRRc, dwcc, dRc_buf, False))        # levels 0-2 -> d rel_comp (first writer)
+                wrote_c = True
+            if g_relc1 is not None:
+                gL11, gL12 = add(3, t.mlc.bwd_tasks(g_relc1.contiguous(), dRc_buf, wrote_c))   # levels 3-4 -> d rel_comp (+)=
+                wrote_c = True
+            run_levels(levels)
+            dRa = dRa_buf if wrote_a else None
+            dRc = dRc_buf if wrote_c else None
+        if have_align:
+            ga = _layer_grads(cga, dwca, daa, gbwa, d)
+            g2 = _layer_grads(cg2, dwc2, da2, gbw2, d)
+        if have_c:
+            gc = _layer_grads(cgc, dwcc, dac, gbwc, d)
+        return (None, dE, dRc, dRa, None, dNL, dU11, dU21, dWall, gL11, gL12, gL11u, gL12u, *ga, *gc, *g2)
+
+
+# ---- forward_no_name ------------------------------------------------------------------------------------------------------
+class _EncoderNoName(torch.autograd.Function):
+    """JMAC.forward_no_name (src/jmac_model.py:207-220), num_gcn_layer = 2: c1 = conv1_completion(E, Rc), rel_c1 = MLP(Rc).
+
+    inputs: cfg, E, Rc, rel_linear11, rel_linear12, 8 tensors of conv1_completion;  outputs: c1, rel_c1"""
+
+    @staticmethod
+    def forward(ctx, cfg, E, Rc, L11, L12, *pc):
+        require_device(E, Rc)
+        (lc,) = cfg.layers
+        N, d = E.shape
+        t = SimpleNamespace()
+        t.wc = _wcat(pc[3], pc[5], d)
+        t.chc = _Chain(lc, Rc, pc[0], pc[1], pc[2], t.wc, d)
+        t.mlc = _RelMLP(Rc, L11, L12, cfg.mlp_slope)
+        fc, mc = t.chc.fwd_tasks(), t.mlc.fwd_tasks()
+        run_levels([[fc[0], mc[0]], [fc[1], mc[1]], [fc[2]]])
+        c1 = _empty(E.device, N, d)
+        t.sc = _layer_fwd(lc, E, t.wc, t.chc.RR, pc[4].reshape(-1), cfg.graph, cfg.training, c1)
+        if CAPTURE is not None:
+            CAPTURE.update(conv1_completion=(E.detach(), Rc.detach()))
+            CAPTURE["conv1_completion.tables"] = (t.sc.PQZ, t.sc.RR)
+        rel_c1, t.mlc.out, t.sc.y = t.mlc.out, None, None
+        ctx.t, ctx.cfg, ctx.dims = t, cfg, (N, d)
+        ctx.save_for_backward(E, Rc, L11, L12, c1)
+        return c1, rel_c1
+
+    @staticmethod
+    def backward(ctx, g_c1, g_relc1):
+        t, cfg = ctx.t, ctx.cfg
+        N, d = ctx.dims
+        E, Rc, L11, L12, c1 = ctx.saved_tensors
+        sc = SimpleNamespace(**vars(t.sc))                   # c1 is an output: never stored on ctx.t (reference cycle)
+        sc.y = c1
+        dev = E.device
+        dE = dRc = None
+        gc = [None] * 8
+        levels: List[List[GemmTask]] = [[] for _ in range(5)]
+        dRc_buf = _empty(dev, *Rc.shape)
+        wrote = False
+        if g_c1 is not None:
+            dE = _empty(dev, N, d)
+            dRRc, dwcc, dac, gbwc = _layer_bwd(sc, cfg.graph, g_c1.contiguous(), None, dE, False)
+            lv, cgc = t.chc.bwd_tasks(dRRc, dwcc, dRc_buf, False)
+            for i, l in enumerate(lv):
+                levels[i].extend(l)
+            wrote = True
+        gL11 = gL12 = None
+        if g_relc1 is not None:
+            lv, (gL11, gL12) = t.mlc.bwd_tasks(g_relc1.contiguous(), dRc_buf, wrote)
+            for i, l in enumerate(lv):
+                levels[3 + i].extend(l)
+            wrote = True
+        run_levels(levels)
+        if g_c1 is not None:
+            gc = _layer_grads(cgc, dwcc, dac, gbwc, d)
+        dRc = dRc_buf if wrote else None
+        return (None, dE, dRc, gL11, gL12, *gc)
+
+
+def _cfg(model, layers, graph):
+    training = model.training
+    return SimpleNamespace(layers=layers, graph=graph, training=training,
+                           p_drop=float(model.completion_dropout.p) if model.completion_dropout.training else 0.0,
+                           mlp_slope=float(model.atv_mlp.negative_slope))
+
+
+def forward_name(model, comp_att, rel_comp, rel_align, info, graph: RelGraph):
+    """(align_out, c1, rel_c1) of JMAC.forward_name on the fused node."""
+    la, lc, l2 = model.conv1_alignment, model.conv1_completion, model.conv2_alignment
+    cfg = _cfg(model, (la, lc, l2), graph)
+    cfg.training = la.training                                           # BatchNorm follows the layers' own mode
+    return _EncoderName.apply(cfg, comp_att, rel_comp, rel_align, info, model.name_linear, model.uni_linear1_1,
+                              model.uni_linear2_1, model.all_linear_completion, model.rel_linear11, model.rel_linear12,
+                              model.rel_linear11_uni, model.rel_linear12_uni, *_layer_inputs(la), *_layer_inputs(lc),
+                              *_layer_inputs(l2))
+
+
+def forward_no_name(model, comp_att, rel_comp, graph: RelGraph):
+    """(c1, rel_c1) of JMAC.forward_no_name on the fused node."""
+    lc = model.conv1_completion
+    cfg = _cfg(model, (lc,), graph)
+    cfg.training = lc.training
+    return _EncoderNoName.apply(cfg, comp_att, rel_comp, model.rel_linear11, model.rel_linear12, *_layer_inputs(lc))

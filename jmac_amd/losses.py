@@ -96,3 +96,39 @@ def pair_cosine_distance(e1: torch.Tensor, i1: torch.Tensor, e2: torch.Tensor, i
     """``1 - sum(F.normalize(e1[i1], 2, -1) * F.normalize(e2[i2], 2, -1), 1)`` -> [L]."""
     dev = e1.device
     return _PairCosine.apply(e1, e2, _index(i1, e1.shape[0], dev), _index(i2, e2.shape[0], dev))
+
+
+class _MarginLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, score, margin, B, K):
+        require_device(score, margin)
+        score = score.contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=score.device)
+        check(lib().jmac_margin_loss_fwd_f32(ptr(score), B, K, ptr(margin), ptr(loss), stream()), "jmac_margin_loss_fwd_f32")
+        ctx.save_for_backward(score, margin)
+        ctx.bk = (B, K)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        score, margin = ctx.saved_tensors
+        B, K = ctx.bk
+        g = g.contiguous()
+        dscore = torch.empty_like(score)
+        check(lib().jmac_margin_loss_bwd_f32(ptr(score), B, K, ptr(margin), ptr(g), ptr(dscore), stream()), "jmac_margin_loss_bwd_f32")
+        return dscore, None, None, None
+
+
+def margin_loss(score: torch.Tensor, batch_size: int, margin: torch.Tensor) -> torch.Tensor:
+    """``torch.max(pos - neg, -margin).mean() + margin`` of completion_loss (src/jmac_model.py:351-378) on one batch's score
+    vector [B + B*K]: ``pos = score[:B].view(-1, B).permute(1, 0)``, ``neg = score[B:].view(-1, B).permute(1, 0)`` -- the
+    reference consumes its b-major negative block as n-major; kept as is.  ``margin``: the model's fixed one-element
+    parameter (no gradient).  One launch each way instead of ~10; shape [1] like the reference's expression."""
+    T, B = int(score.numel()), int(batch_size)
+    if score.dim() != 1 or score.dtype != torch.float32 or margin.numel() != 1 or margin.requires_grad \
+            or T <= B or (T - B) % B != 0:
+        pos, neg = score[:B], score[B:]                           # ragged / exotic inputs: the reference's own expression
+        pos = pos.view(-1, min(B, len(pos))).permute(1, 0)
+        neg = neg.view(-1, min(B, len(neg))).permute(1, 0)
+        return torch.max(pos - neg, -margin).mean() + margin
+    return _MarginLoss.apply(score, margin.reshape(1).to(torch.float32), B, (T - B) // B)

@@ -130,20 +130,28 @@ def _message_and_aggregate(x: Tensor, rel: Tensor, edge_index: Tensor, edge_type
     return scatter_sum(o * alpha, dst, n)                       # :27-28
 
 
-def transform_relations(p: Dict[str, Tensor], rel_emb: Tensor, slope: float, rel_act: str) -> Tensor:
+def _leaky(x: Tensor, slope: float, mask: Optional[Tensor] = None) -> Tensor:
+    """LeakyReLU; ``mask`` (tests only, same shape as x): evaluate it as ``where(mask, x, slope*x)`` -- the other
+    evaluation's side of every kink (see ``_message_and_aggregate``)."""
+    return F.leaky_relu(x, slope) if mask is None else torch.where(mask, x, x * slope)
+
+
+def transform_relations(p: Dict[str, Tensor], rel_emb: Tensor, slope: float, rel_act: str,
+                        kink_mask: Optional[Tensor] = None) -> Tensor:
     """jmac_model.py:39-42 (LeakyReLU) / DBPv1 jmac_model.py:48-52 (ReLU)."""
     rel = torch.cat([rel_emb, p["loop_rel"]], dim=0)
     rel = rel @ p["rel_transform_weight1"]
-    rel = F.leaky_relu(rel, slope) if rel_act == "leaky_relu" else F.relu(rel)
+    rel = _leaky(rel, slope, kink_mask) if rel_act == "leaky_relu" else F.relu(rel)
     return rel @ p["rel_transform_weight2"]
 
 
 def layer_pre_bn(p: Dict[str, Tensor], ent_emb: Tensor, rel_emb: Tensor, edge_index: Tensor,
                  edge_type: Tensor, slope: float = 0.05, comp_op: str = "sub",
-                 rel_act: str = "leaky_relu", kink_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+                 rel_act: str = "leaky_relu", kink_mask: Optional[Tensor] = None,
+                 rel_kink_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """(message_neighbors, message_self, (nb+self)/2) of jmac_model.py:39-52, before BN/tanh."""
     n = ent_emb.shape[0]
-    rel = transform_relations(p, rel_emb, slope, rel_act)
+    rel = transform_relations(p, rel_emb, slope, rel_act, rel_kink_mask)
     loop = torch.arange(n)
     loop_index = torch.stack([loop, loop])                      # :44
     loop_type = torch.full((n,), rel.shape[0] - 1, dtype=torch.long)   # :45
@@ -158,12 +166,12 @@ def layer_forward(p: Dict[str, Tensor], ent_emb: Tensor, rel_emb: Tensor, edge_i
                   rel_act: str = "leaky_relu", training: bool = True,
                   running_mean: Optional[Tensor] = None, running_var: Optional[Tensor] = None,
                   momentum: float = 0.1, eps: float = 1e-5, act=torch.tanh,
-                  kink_mask: Optional[Tensor] = None) -> Tensor:
+                  kink_mask: Optional[Tensor] = None, rel_kink_mask: Optional[Tensor] = None) -> Tensor:
     """RelationAwareLayer.forward, jmac_model.py:33-53: act(BatchNorm1d((nb+self)/2)).
 
     ``running_mean/var`` are updated in place in training mode exactly like nn.BatchNorm1d.
     """
-    _, _, pre = layer_pre_bn(p, ent_emb, rel_emb, edge_index, edge_type, slope, comp_op, rel_act, kink_mask)
+    _, _, pre = layer_pre_bn(p, ent_emb, rel_emb, edge_index, edge_type, slope, comp_op, rel_act, kink_mask, rel_kink_mask)
     d = pre.shape[1]
     if running_mean is None:
         running_mean = torch.zeros(d, dtype=pre.dtype)
@@ -191,7 +199,9 @@ def forward_name(params: Dict[str, Tensor], name_emb: Tensor, edge_index: Tensor
 
     ``params`` uses the reference's state_dict names. ``bn_state`` maps e.g.
     'conv1_alignment.bn.running_mean' -> tensor (defaults to fresh BN statistics).
-    ``kink_masks`` (tests only) maps a layer name to the ``kink_mask`` of ``_message_and_aggregate``.
+    ``kink_masks`` (tests only) maps a layer name to the ``kink_mask`` of ``_message_and_aggregate``, ``<layer>.rel`` to the
+    mask of that layer's relation transform (:41), ``rel_linear11`` / ``rel_linear11_uni`` to the masks of the two relation
+    MLPs (:195-196).
     """
     bn_state = bn_state if bn_state is not None else {}
     kink_masks = kink_masks if kink_masks is not None else {}
@@ -200,7 +210,8 @@ def forward_name(params: Dict[str, Tensor], name_emb: Tensor, edge_index: Tensor
         return layer_forward(_sub(params, name), x, r, edge_index, edge_type, slope, comp_op,
                              "leaky_relu", training,
                              bn_state.get(name + ".bn.running_mean"),
-                             bn_state.get(name + ".bn.running_var"), kink_mask=kink_masks.get(name))
+                             bn_state.get(name + ".bn.running_var"), kink_mask=kink_masks.get(name),
+                             rel_kink_mask=kink_masks.get(name + ".rel"))
 
     e0, e1 = ent_bases
     r0, r1 = rel_bases
@@ -218,8 +229,9 @@ def forward_name(params: Dict[str, Tensor], name_emb: Tensor, edge_index: Tensor
         c1 = conv("conv1_completion", comp_att, rel_comp)                     # :190
         c1n = F.normalize(c1)                                                 # :191
         a_in = torch.cat((c1n, a1), dim=1) @ params["uni_linear2_1"]          # :192
-        rel_c1 = F.leaky_relu(rel_comp @ params["rel_linear11"], slope) @ params["rel_linear12"]       # :195
-        rel_a_in = F.leaky_relu(rel_align @ params["rel_linear11_uni"], slope) @ params["rel_linear12_uni"]  # :196
+        rel_c1 = _leaky(rel_comp @ params["rel_linear11"], slope, kink_masks.get("rel_linear11")) @ params["rel_linear12"]   # :195
+        rel_a_in = (_leaky(rel_align @ params["rel_linear11_uni"], slope, kink_masks.get("rel_linear11_uni"))
+                    @ params["rel_linear12_uni"])                                                       # :196
         a2 = conv("conv2_alignment", a_in, rel_a_in)                          # :197
         align_layers.append(a2)
         comp_layers.append(c1)

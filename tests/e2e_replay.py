@@ -1,6 +1,6 @@
 """Replay of the end-to-end fixture tests/golden/e2e_ja_sub.npz (tests/golden/gen_golden.py:gen_e2e): the reference's
-JMAC trained for 120 seeded steps (dropout 0, captured batches) on ja / el sub-graphs of DBP-5L and scored by its own
-CompletionEvaluator.test.  The same steps are replayed through the oracle (CPU) and through the HIP path (GPU); both must
+JMAC -- first trained by itself for 250 steps to a state with filtered Hits@1 ~ 10 % (``state0``), then for 120 recorded
+seeded steps (dropout 0, captured batches) -- on ja / el sub-graphs of DBP-5L, scored by its own CompletionEvaluator.test.  The same steps are replayed through the oracle (CPU) and through the HIP path (GPU); both must
 end at the reference's Hits@1 / Hits@10 / MRR and ranks."""
 import numpy as np
 import torch
@@ -57,6 +57,9 @@ def check_outcome(g, losses, ranks_ckpt, ranks_after, what):
     # ---- end of the run
     got, ref_m = metrics(ranks_after), g["metrics_after"]
     assert (np.abs(got - ref_m) <= np.array([2.0 / n, 0.015, 3e-3])).all(), (what, got, ref_m)
-    # ... and the run did learn: Hits@10 moved well away from the initial model's at both evaluations
-    assert g["metrics_ckpt"][1] > 5 * g["metrics_before"][1] and got[1] > 8 * g["metrics_before"][1]
+    # ... and the metric discriminates: the replay starts from a state the reference trained itself to (250 steps before
+    # ``state0``), so Hits@1 is far from the 1/len(val) an untrained L1 translation model scores whatever the implementation
+    assert g["metrics_untrained"][0] <= 1.5 / n
+    assert g["metrics_before"][0] >= 0.05 and g["metrics_ckpt"][0] >= 0.05 and got[0] >= 0.10
+    assert g["metrics_ckpt"][1] > 10 * g["metrics_untrained"][1] and got[1] > g["metrics_ckpt"][1]
     return got

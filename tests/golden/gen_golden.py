@@ -407,10 +407,43 @@ def gen_e2e():
               "e2_index": ei2, "e2_type": et2, "train1": kg1.train_data, "val1": kg1.val_data, "test1": kg1.test_data,
               "train2": kg2.train_data, "neg_right": _np(feed["neg_right"]), "neg2_left": _np(feed["neg2_left"]),
               "lr": np.float64(5e-3), "batch_size": B, "num_negative": K}
-    for k, v in model.state_dict().items():
-        arrays["state0." + k] = _np(v)
     lg = logging.getLogger("golden"); lg.setLevel(logging.ERROR)
     ev = CompletionEvaluator(kg1, model, "cpu", None)
+
+    def one_step(kind, tr, nent, opt_a, opt_c):
+        """One step of train.py's loop: an alignment step (train.py:367-378) or a completion batch (train.py:338-352)."""
+        if kind == "a":
+            opt_a.zero_grad()
+            loss = model.alignment_loss(feed, e1i, e1t, e2i, e2t)
+            loss.backward(); opt_a.step()
+            return loss, None
+        trip = torch.from_numpy(tr[rng.permutation(len(tr))[:B]].astype(np.int64))
+        neg = torch.from_numpy(rng.integers(0, nent, (B, K)).astype(np.int64))
+        data = {"batch_h": trip[:, 0].repeat(K + 1), "batch_r": trip[:, 1].repeat(K + 1),
+                "batch_t": torch.cat((trip[:, 2], neg.view(-1)))}            # train.py:347-352
+        opt_c.zero_grad()
+        loss = model.completion_loss(data, e1i, e1t, e2i, e2t, feed, kind == "c1")
+        loss.backward(); opt_c.step()
+        return loss, data
+    EPOCH = [("c1", kg1.train_data, n1)] * 6 + [("c2", kg2.train_data, n2)] * 3 + [("a", None, 0)]   # train.py:486-489
+
+    # ---- phase 0 (not replayed): the reference trains ITSELF from its random initialisation until the filtered Hits@1 of the
+    # validation split is well away from zero -- an untrained or barely trained L1 translation model ranks the head entity
+    # itself first (h + r ~ h), i.e. Hits@1 = 1/len(val) whatever the implementation does, which pins nothing.  The state it
+    # reaches is the replay's starting point (``state0``); the replayed steps start with fresh optimisers.
+    model.eval()
+    with torch.no_grad():
+        arrays["metrics_untrained"] = np.array(ev.test(margs, is_val=True, filterr=True, logger=lg), dtype=np.float64)
+    model.train()
+    PRE = 25
+    arrays["pretrain_steps"] = PRE * len(EPOCH)
+    opt_a = torch.optim.Adam(model.parameters(), lr=float(arrays["lr"]))
+    opt_c = torch.optim.Adam(model.parameters(), lr=float(arrays["lr"]))
+    for _ in range(PRE):
+        for kind, tr, nent in EPOCH:
+            one_step(kind, tr, nent, opt_a, opt_c)
+    for k, v in model.state_dict().items():
+        arrays["state0." + k] = _np(v)
     model.eval()
     with torch.no_grad():
         arrays["metrics_before"] = np.array(ev.test(margs, is_val=True, filterr=True, logger=lg), dtype=np.float64)
@@ -449,20 +482,11 @@ def gen_e2e():
     for epoch in range(12):
         if epoch == CKPT:
             evaluate("ckpt")
-        for kind, tr, nent in [("c1", kg1.train_data, n1)] * 6 + [("c2", kg2.train_data, n2)] * 3 + [("a", None, 0)]:
-            if kind == "a":
-                opt_a.zero_grad()
-                loss = model.alignment_loss(feed, e1i, e1t, e2i, e2t)
-                loss.backward(); opt_a.step()
+        for kind, tr, nent in EPOCH:
+            loss, data = one_step(kind, tr, nent, opt_a, opt_c)
+            if data is None:
                 h = r = t = np.zeros(B * (K + 1), np.int64)
             else:
-                trip = torch.from_numpy(tr[rng.permutation(len(tr))[:B]].astype(np.int64))
-                neg = torch.from_numpy(rng.integers(0, nent, (B, K)).astype(np.int64))
-                data = {"batch_h": trip[:, 0].repeat(K + 1), "batch_r": trip[:, 1].repeat(K + 1),
-                        "batch_t": torch.cat((trip[:, 2], neg.view(-1)))}            # train.py:347-352
-                opt_c.zero_grad()
-                loss = model.completion_loss(data, e1i, e1t, e2i, e2t, feed, kind == "c1")
-                loss.backward(); opt_c.step()
                 h, r, t = (_np(data[x]) for x in ("batch_h", "batch_r", "batch_t"))
             sched.append({"c1": 0, "c2": 1, "a": 2}[kind]); bh.append(h); br.append(r); bt.append(t)
             losses.append(loss.item())
@@ -471,9 +495,10 @@ def gen_e2e():
     evaluate("after")
     for k, v in model.state_dict().items():
         arrays["state1." + k] = _np(v)
-    print("e2e: n1=%d E1=%d val=%d | n2=%d E2=%d | links=%d | steps=%d | loss %.4f -> %.4f | H@1/H@10/MRR %s -> %s -> %s" % (
-        n1, ei1.shape[1], len(kg1.val_data), n2, ei2.shape[1], len(links), len(sched), losses[0], losses[-1],
-        np.round(arrays["metrics_before"], 4), np.round(arrays["metrics_ckpt"], 4), np.round(arrays["metrics_after"], 4)))
+    print("e2e: n1=%d E1=%d val=%d | n2=%d E2=%d | links=%d | steps=%d (+%d before state0) | loss %.4f -> %.4f | H@1/H@10/MRR %s -> %s -> %s -> %s" % (
+        n1, ei1.shape[1], len(kg1.val_data), n2, ei2.shape[1], len(links), len(sched), int(arrays["pretrain_steps"]), losses[0],
+        losses[-1], np.round(arrays["metrics_untrained"], 4), np.round(arrays["metrics_before"], 4),
+        np.round(arrays["metrics_ckpt"], 4), np.round(arrays["metrics_after"], 4)))
     _save("e2e_ja_sub", **arrays)
 
 

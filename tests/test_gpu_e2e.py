@@ -1,6 +1,7 @@
 """GPU, BASELINE metric "Hits@1 parity" end to end: the HIP path replays the reference's 120 seeded training steps
 (tests/golden/e2e_ja_sub.npz: ja / el sub-graphs of DBP-5L, dropout 0, captured batches, two Adam optimisers as
-train.py:406-407) through jmac_amd.model.JMAC -- three HIP layers, fused losses, deterministic backward -- and scores the
+train.py:406-407; the replay starts from the state the reference trained itself to in 250 earlier steps, filtered
+Hits@1 ~ 10 %) through jmac_amd.model.JMAC -- three HIP layers, fused losses, deterministic backward -- and scores the
 validation split with the HIP evaluator path (forward_linkpred + filtered_rank, src/validate.py:22-80).  It must land on the
 reference's losses, ranks (30-step checkpoint: identical) and Hits@1 / Hits@10 / MRR (end of run: within seed noise)."""
 import numpy as np
@@ -31,13 +32,23 @@ def test_hip_path_replays_reference_training_run():
     val = g["val1"]
     fp, fi = torch.from_numpy(g["filt_ptr"]).to(dev), torch.from_numpy(g["filt_idx"]).to(dev)
 
+    # the evaluator path the harness runs by default: harness.evaluate_completion(fused=True) -> JMAC.linkpred_ranks ->
+    # jmac_linkpred_rank_f32 (no [B, N] matrix; its per-candidate sum runs over both layers in one accumulator, the
+    # reference adds two cdist matrices, src/jmac_model.py:312).  It is held to the reference's ranks as well.
+    from jmac_amd.data import KnowledgeGraph, true_tail_dict
+    kg1 = KnowledgeGraph("ja", g["train1"], val, g["test1"], m["n1"], m["nrel"], False, 0, 0, m["n1"], m["nrel"])
+    kg1.true_tail = true_tail_dict(np.concatenate((g["train1"], val, g["test1"])))      # src/knowledgegraph.py:45-46
+
     def val_ranks():
         model.eval()
         with torch.no_grad():
             dist = model.forward_linkpred(val[:, 0].tolist(), val[:, 1].tolist(), e1i, e1t, range(m["n1"]), m["eb1"], m["rb1"])
             rk = scoring.filtered_rank(dist, val[:, 2], fp, fi).cpu().numpy()
+            rk_fused = model.linkpred_ranks(val[:, 0].tolist(), val[:, 1].tolist(), val[:, 2].tolist(), e1i, e1t, m["eb1"],
+                                            m["rb1"], fp, fi).cpu().numpy()
+            met_fused = harness.evaluate_completion(model, kg1, e1i, e1t, args, split="val", filtered=True, fused=True)
         model.train()
-        return rk
+        return rk, rk_fused, np.array(met_fused)
 
     model.train()
     losses, ranks_ckpt = [], None
@@ -56,6 +67,18 @@ def test_hip_path_replays_reference_training_run():
             loss.backward()
             opt_c.step()
         losses.append(float(loss.detach()))
-    got = check_outcome(g, losses, ranks_ckpt, val_ranks(), "hip")
+    ranks_ckpt, fused_ckpt, met_ckpt = ranks_ckpt
+    ranks_after, fused_after, met_after = val_ranks()
+    got = check_outcome(g, losses, ranks_ckpt, ranks_after, "hip")
+    # the fused evaluator: same acceptance (decided ranks identical at the checkpoint, metrics within seed noise at the end);
+    # what harness.evaluate_completion reports IS the metric of those ranks (its own filter CSR from kg.true_tail included)
+    from e2e_replay import metrics
+    check_outcome(g, losses, fused_ckpt, fused_after, "hip-fused")
+    assert np.allclose(met_ckpt, metrics(fused_ckpt), atol=1e-12) and np.allclose(met_after, metrics(fused_after), atol=1e-12)
+    assert met_ckpt[0] >= 0.05                               # Hits@1 is not the vacuous 1/len(val) here
+    print("fused evaluator: Hits@1 %.4f Hits@10 %.4f MRR %.4f at the checkpoint (reference %s); ranks identical: %d / %d; differing "
+          "from the materialised path: %d" % (met_ckpt[0], met_ckpt[1], met_ckpt[2], np.round(g["metrics_ckpt"], 4),
+                                             int((fused_ckpt == g["ranks_ckpt"]).sum()), len(fused_ckpt),
+                                             int((fused_ckpt != ranks_ckpt).sum())))
     print("HIP replay: Hits@1 %.4f Hits@10 %.4f MRR %.4f (reference %s); ranks identical at the checkpoint: %d / %d" % (
         got[0], got[1], got[2], np.round(g["metrics_after"], 4), int((ranks_ckpt == g["ranks_ckpt"]).sum()), len(ranks_ckpt)))

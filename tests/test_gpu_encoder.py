@@ -1,0 +1,263 @@
+"""GPU: the fused encoder nodes (jmac_amd/encoder.py: JMAC.forward_name / forward_no_name as one autograd node each) and
+the kernels they add -- jmac_gemm_grouped_f32, jmac_bn_tanh_{fwd,bwd}2_f32, jmac_row_normalize_drop_{fwd,bwd}_f32.
+
+The reference fixtures reach the fused node through every model-level test (test_gpu_model.py, test_gpu_e2e.py,
+test_gpu_ja_oracle.py, ...); here it is additionally held to the op-by-op path of jmac_amd.model -- an independent second
+implementation of the same function (src/jmac_model.py:172-220) -- on outputs and on every gradient, for each pattern of
+used outputs a caller produces (alignment loss: align_out only; completion loss: completion layers + relation layers only;
+the bench step: all of them)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from util import assert_close, random_graph
+
+DEV = "cuda"
+
+
+def _args(d, no_name=False, dropout=0.0):
+    return types.SimpleNamespace(dim=d, dropout=dropout, leaky_relu_w=0.05, comp_op="sub", num_gcn_layer=2, num_negative=5,
+                                 margin_align=1.0, margin_completion=5.0, batch_size=64, no_name_info=no_name, device=DEV)
+
+
+def _model(d, n, nr, di, no_name, seed):
+    from jmac_amd.model import JMAC
+    torch.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    m = JMAC(_args(d, no_name), rng.standard_normal((n, di)).astype(np.float32), nr, n).to(DEV)
+    m.ent_info_att = m.ent_info_att.to(DEV)
+    with torch.no_grad():
+        for lay in (m.conv1_alignment, m.conv2_alignment, m.conv1_completion):   # non-trivial BN affine
+            lay.bn.weight.add_(0.1 * torch.randn_like(lay.bn.weight))
+            lay.bn.bias.add_(0.1 * torch.randn_like(lay.bn.bias))
+    return m
+
+
+def _run(m, fused, ei, et, n, nr, use, G):
+    """One forward + backward; ``use`` selects which outputs feed the scalar loss."""
+    m.fused_encoder = fused
+    m.zero_grad(set_to_none=True)
+    state = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    align_out, comp, rel = m.forward_base(ei, et, [0, n], [0, nr])
+    loss = 0
+    if "align" in use:
+        loss = loss + (align_out * G["align"]).sum()
+    if "comp" in use:
+        loss = loss + (comp[1] * G["c1"]).sum() + (comp[0] * G["c0"]).sum()
+    if "rel" in use:
+        loss = loss + (rel[1] * G["r1"]).sum() + (rel[0] * G["r0"]).sum()
+    loss.backward()
+    grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+    after = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    m.load_state_dict(state, strict=False)                       # both runs start from the same BN statistics
+    return (align_out.detach(), comp[1].detach(), rel[1].detach()), grads, after
+
+
+@pytest.mark.parametrize("use", [("align", "comp", "rel"), ("align",), ("comp", "rel"), ("rel",), ("comp",)])
+@pytest.mark.parametrize("no_name", [False, True], ids=["name", "no-name"])
+def test_fused_encoder_equals_op_by_op_path(no_name, use):
+    if no_name and use == ("align",):
+        use = ("comp",)                                          # forward_no_name's "align" output IS completion layer 1
+    n, nr, d, di = 700, 37, 32, 20
+    rng = np.random.default_rng(5)
+    ei, et = random_graph(rng, n, nr, 2600, hub=300)
+    ei, et = torch.from_numpy(ei).to(DEV), torch.from_numpy(et).to(DEV)
+    m = _model(d, n, nr, di, no_name, 11)
+    from jmac_amd import encoder
+    assert encoder.supported(m, None if no_name else di)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    G = {k: torch.randn(s, device=DEV, generator=gen) for k, s in
+         (("align", (n, d)), ("c1", (n, d)), ("c0", (n, d)), ("r1", (nr, d)), ("r0", (nr, d)))}
+    m.train()
+    out_f, g_f, bn_f = _run(m, True, ei, et, n, nr, use, G)
+    out_o, g_o, bn_o = _run(m, False, ei, et, n, nr, use, G)
+    for a, b, what in zip(out_f, out_o, ("align_out", "c1", "rel_c1")):
+        assert_close(a, b, 2e-5, 1e-6, what)
+    for k in bn_o:
+        assert_close(bn_f[k], bn_o[k], 1e-5, 1e-7, k)
+    scale = max(float(g.abs().max()) for g in g_o.values() if g is not None)
+    n_checked = 0
+    for k, ref in g_o.items():
+        got = g_f[k]
+        if ref is None:
+            assert got is None or float(got.abs().max()) == 0.0, k
+            continue
+        assert got is not None, k
+        atol = 1e-4 * scale if k.endswith("loop_rel") else 1e-6 * scale       # loop_rel: zero gradient under train-mode BN
+        assert_close(got, ref, 1e-4, atol, "grad " + k)
+        n_checked += 1
+    assert n_checked >= 3, n_checked
+    # eval mode: running statistics, no dropout, no graph
+    m.eval()
+    with torch.no_grad():
+        m.fused_encoder = True
+        a1, c1, r1 = m.forward_base(ei, et, [0, n], [0, nr])
+        m.fused_encoder = False
+        a2, c2, r2 = m.forward_base(ei, et, [0, n], [0, nr])
+    assert_close(a1, a2, 2e-5, 1e-6, "eval align_out")
+    assert_close(c1[1], c2[1], 2e-5, 1e-6, "eval c1")
+    assert_close(r1[1], r2[1], 2e-5, 1e-6, "eval rel_c1")
+
+
+def test_fused_encoder_on_a_slice_of_the_tables():
+    """ent_bases / rel_bases select one KG of a multi-KG model (src/jmac_model.py:173-176): the node sees row slices of the
+    parameters and autograd scatters its gradients back."""
+    n_all, nr_all, d, di = 500, 40, 16, 8
+    rng = np.random.default_rng(9)
+    m = _model(d, n_all, nr_all, di, False, 4)
+    e0, e1, r0, r1 = 120, 420, 20, 40
+    n, nr = e1 - e0, r1 - r0
+    ei, et = random_graph(rng, n, nr, 900)
+    ei, et = torch.from_numpy(ei).to(DEV), torch.from_numpy(et).to(DEV)
+    outs, grads = [], []
+    for fused in (True, False):
+        m.fused_encoder = fused
+        m.zero_grad(set_to_none=True)
+        st = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+        a, c, r = m.forward_base(ei, et, [e0, e1], [r0, r1])
+        (a.sum() + (c[1] ** 2).sum() + r[1].sum()).backward()
+        outs.append((a.detach(), c[1].detach(), r[1].detach()))
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        m.load_state_dict(st, strict=False)
+    for x, y in zip(*outs):
+        assert_close(x, y, 2e-5, 1e-6)
+    assert set(grads[0]) == set(grads[1])
+    scale = max(float(g.abs().max()) for g in grads[1].values())
+    for k in grads[1]:
+        assert_close(grads[0][k], grads[1][k], 1e-4, (1e-4 if k.endswith("loop_rel") else 1e-6) * scale, k)
+    ge = grads[0]["ent_init_att_completion"]
+    assert float(ge[:e0].abs().max()) == 0.0 and float(ge[e1:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_grouped_gemm_forms_and_epilogues(seed):
+    from jmac_amd.encoder import (ACT_LEAKY, ACT_RELU, DACT_LEAKY, DACT_RELU, gemm_task, grouped_gemm)
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    r = lambda *s: torch.randn(s, device=DEV, generator=gen)
+    M, K, N = 203, 76, 50
+    A, A2, B, Bt, At = r(M - 1, K), r(1, K), r(K, N), r(N, K), r(K, M)
+    big = r(M, 3 * N)                                             # strided operands / outputs
+    src = r(M, N)
+    C0 = r(M, N)
+    outs = {k: torch.empty(M, N, device=DEV) for k in ("nn", "nt", "tn", "leaky", "relu", "dleaky", "drelu")}
+    acc = C0.clone()
+    c_hi, c_lo = torch.empty(M - 3, N, device=DEV), torch.empty(3, N, device=DEV)
+    strided_out = torch.zeros(M, 3 * N, device=DEV)
+    Afull = torch.cat((A, A2))
+    tasks = [gemm_task(A, B, outs["nn"], A2=A2),
+             gemm_task(Afull, Bt, outs["nt"], tb=True),
+             gemm_task(At, B, outs["tn"], ta=True),
+             gemm_task(Afull, B, outs["leaky"], act=ACT_LEAKY, slope=0.05),
+             gemm_task(Afull, B, outs["relu"], act=ACT_RELU),
+             gemm_task(Afull, B, outs["dleaky"], act=DACT_LEAKY, act_src=src, slope=0.05),
+             gemm_task(Afull, B, outs["drelu"], act=DACT_RELU, act_src=src),
+             gemm_task(Afull, B, acc, accumulate=True),
+             gemm_task(Afull, B, c_hi, C2=c_lo),
+             gemm_task(big[:, N:2 * N], r(N, N), strided_out[:, 2 * N:]),
+             # transposed A whose K rows continue in a second buffer (the adjoint of cat(rel_emb, loop_rel))
+             gemm_task(A, r(M, N), torch.empty(K, N, device=DEV), ta=True, A2=A2)]
+    grouped_gemm(tasks)
+    ref = Afull.double() @ B.double()
+    tol = dict(rtol=1e-5, atol=1e-5)
+    assert_close(outs["nn"], ref, **tol)
+    assert_close(outs["nt"], Afull.double() @ Bt.double().t(), **tol)
+    assert_close(outs["tn"], At.double().t() @ B.double(), **tol)
+    assert_close(outs["leaky"], torch.nn.functional.leaky_relu(ref, 0.05), **tol)
+    assert_close(outs["relu"], torch.relu(ref), **tol)
+    assert_close(outs["dleaky"], torch.where(src > 0, ref, ref * 0.05), **tol)
+    assert_close(outs["drelu"], torch.where(src > 0, ref, torch.zeros_like(ref)), **tol)
+    assert_close(acc, C0.double() + ref, **tol)
+    assert_close(torch.cat((c_hi, c_lo)), ref, **tol)
+    t9, t10 = tasks[9]._keep, tasks[10]._keep
+    assert_close(strided_out[:, 2 * N:], t9[0].double() @ t9[1].double(), **tol)
+    assert float(strided_out[:, :2 * N].abs().max()) == 0.0       # nothing outside the output slice was touched
+    assert_close(t10[2], Afull.double().t() @ t10[1].double(), **tol)
+    # bitwise reproducible
+    again = torch.empty(M, N, device=DEV)
+    grouped_gemm([gemm_task(A, B, again, A2=A2)])
+    assert torch.equal(again, outs["nn"])
+
+
+def test_grouped_gemm_many_tasks_and_odd_shapes():
+    from jmac_amd.encoder import gemm_task, grouped_gemm
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    tasks, refs = [], []
+    for i in range(30):                                           # more than one launch's worth of tasks
+        M, K, N = 1 + 37 * i % 211, 1 + 13 * i % 97, 1 + 29 * i % 131
+        A, B = torch.randn(M, K, device=DEV, generator=gen), torch.randn(K, N, device=DEV, generator=gen)
+        out = torch.empty(M, N, device=DEV)
+        tasks.append(gemm_task(A, B, out))
+        refs.append((out, A.double() @ B.double()))
+    grouped_gemm(tasks)
+    for out, ref in refs:
+        assert_close(out, ref, 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_normalize_dropout_kernels(with_mask):
+    from jmac_amd._lib import check, lib, ptr, stream
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    N, d = 333, 40
+    x = torch.randn(N, d, device=DEV, generator=gen)
+    x[5] = 0.0                                                    # clamped norm
+    mask = (torch.rand(N, d, device=DEV, generator=gen) > 0.4).float() if with_mask else None
+    scale = 1.0 / 0.6 if with_mask else 1.0
+    buf = torch.zeros(N, 3 * d, device=DEV)
+    y = buf[:, d:2 * d]
+    inv = torch.empty(N, device=DEV)
+    check(lib().jmac_row_normalize_drop_fwd_f32(ptr(x), d, N, d, 1e-12, ptr(mask), d, scale, ptr(y), 3 * d, ptr(inv), stream()))
+    xr = x.double().requires_grad_(True)
+    ref = torch.nn.functional.normalize(xr, 2, -1)
+    if with_mask:
+        ref = ref * mask.double() * scale
+    assert_close(y, ref.detach(), 1e-6, 1e-7)
+    assert float(buf[:, :d].abs().max()) == 0.0 and float(buf[:, 2 * d:].abs().max()) == 0.0
+    gbuf = torch.randn(N, 2 * d, device=DEV, generator=gen)
+    g = gbuf[:, d:]
+    ref.backward(g.double())
+    gx = torch.full((N, d), 7.0, device=DEV)
+    base = torch.randn(N, d, device=DEV, generator=gen)
+    gacc = base.clone()
+    for out, accumulate in ((gx, 0), (gacc, 1)):
+        check(lib().jmac_row_normalize_drop_bwd_f32(ptr(x), d, ptr(inv), ptr(mask), d, scale, ptr(g), 2 * d, N, d, 1e-12, ptr(out),
+                                                    d, accumulate, stream()))
+    want = xr.grad.clone()
+    want[5] = (g[5].double() * (mask[5].double() * scale if with_mask else 1.0)) * 1e12   # ||x|| <= eps: y = x / eps
+    assert_close(gx[torch.arange(N) != 5], want[torch.arange(N) != 5], 1e-5, 1e-6)
+    assert_close(gx[5], want[5], 1e-5)
+    assert_close(gacc[torch.arange(N) != 5], (base.double() + want)[torch.arange(N) != 5], 1e-5, 1e-6)
+
+
+def test_bn_tanh_two_destinations_two_gradients():
+    from jmac_amd import ops
+    from jmac_amd.encoder import _bn_bwd, _bn_fwd
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    N, d = 517, 24
+    x = torch.randn(N, d, device=DEV, generator=gen) * 0.3 + 0.1
+    bn = torch.nn.BatchNorm1d(d).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.2, 0.2)
+    b1, b2 = torch.zeros(N, 2 * d, device=DEV), torch.zeros(N, 3 * d, device=DEV)
+    mean, invstd, use_batch = _bn_fwd(x, bn, True, b1[:, d:], b2[:, :d])
+    xr = x.clone().requires_grad_(True)
+    bn2 = torch.nn.BatchNorm1d(d).to(DEV)
+    bn2.load_state_dict({k: v for k, v in bn.state_dict().items()}, strict=True)
+    bn2.running_mean.zero_(); bn2.running_var.fill_(1.0); bn2.num_batches_tracked.zero_()
+    ref = torch.tanh(bn2(xr))
+    assert_close(b1[:, d:], ref.detach(), 1e-5, 1e-6)
+    assert torch.equal(b1[:, d:], b2[:, :d])
+    assert_close(bn.running_mean, bn2.running_mean, 1e-5, 1e-7)
+    assert_close(bn.running_var, bn2.running_var, 1e-5, 1e-7)
+    assert int(bn.num_batches_tracked) == 1
+    g1b, g2 = torch.randn(N, 2 * d, device=DEV, generator=gen), torch.randn(N, d, device=DEV, generator=gen)
+    g1 = g1b[:, :d]
+    gx, gbw = _bn_bwd(x, b1[:, d:], g1, g2, bn.weight, mean, invstd, use_batch)
+    ref.backward(g1 + g2)
+    assert_close(gx, xr.grad, 1e-4, 1e-6)
+    assert_close(gbw[:d], bn2.bias.grad, 1e-4, 1e-6)
+    assert_close(gbw[d:], bn2.weight.grad, 1e-4, 1e-6)

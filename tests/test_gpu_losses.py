@@ -134,3 +134,36 @@ def test_row_normalize_fwd_bwd(N, d):
         assert torch.isfinite(xg.grad).all()
         assert_close(xg.grad.cpu()[3] * 1e-12, x64.grad[3] * 1e-12, 1e-5)
     assert_close(xg.grad.cpu()[keep], x64.grad[keep], 1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,K", [(64, 5), (1000, 25), (7, 1)])
+def test_margin_loss_matches_reference_expression(B, K):
+    """losses.margin_loss == torch.max(pos - neg, -margin).mean() + margin with the reference's n-major consumption of the
+    negative block (src/jmac_model.py:351-378), forward and backward; ties at diff == -margin get half the gradient."""
+    from jmac_amd import losses
+    gen = torch.Generator(device="cuda").manual_seed(B + K)
+    score = (torch.randn(B + B * K, device="cuda", generator=gen) * 4).requires_grad_(True)
+    margin = torch.nn.Parameter(torch.tensor([5.0], device="cuda"), requires_grad=False)
+    with torch.no_grad():                                      # a clipped pair and an exact tie
+        score[B] = score[0] + 9.0
+        if K > 1:
+            score[B + B + 1] = score[1] + 5.0
+    got = losses.margin_loss(score, B, margin)
+    assert got.shape == (1,)
+    (got * 3.0).sum().backward()
+    g_got, score.grad = score.grad.clone(), None
+    s64 = score.detach().double().requires_grad_(True)
+    pos = s64[:B].view(-1, B).permute(1, 0)
+    neg = s64[B:].view(-1, B).permute(1, 0)
+    ref = torch.max(pos - neg, -margin.double()).mean() + margin.double()
+    (ref * 3.0).sum().backward()
+    assert abs(float(got) - float(ref)) <= 1e-6 * abs(float(ref))
+    assert torch.allclose(g_got.double(), s64.grad, rtol=1e-5, atol=1e-9)
+    assert float(g_got[B]) == 0.0                              # clipped at -margin: no gradient
+    # bitwise reproducible
+    assert torch.equal(losses.margin_loss(score.detach(), B, margin), losses.margin_loss(score.detach(), B, margin))
+    # ragged input: the reference's own expression
+    rag = torch.randn(B + B * K + 3, device="cuda", generator=gen)
+    if (3 % B) != 0:
+        with pytest.raises(RuntimeError):
+            losses.margin_loss(rag, B, margin)
