@@ -387,7 +387,7 @@ int jmac_gemm_f32(const float* A, int64_t lda, int32_t transA, const float* B, i
  *        JMAC_GEMM_DACT_LEAKY / _RELU multiply the product by act'(z) where act_src holds act(z) (same shape as C; the
  *        sign of act(z) is the sign of z for slope > 0) -- the activation's backward fused into the product that
  *        produces its incoming gradient;
- *   accumulate != 0: C += (applied after the epilogue).
+ *   accumulate != 0: C += (applied after the epilogue); rows that go to C2 are always stored, never accumulated.
  * Exact fp32 products (fp32-input MFMA), fixed summation order per element (bitwise reproducible). */
 #define JMAC_GEMM_MAX_TASKS 24
 #define JMAC_GEMM_ACT_NONE 0

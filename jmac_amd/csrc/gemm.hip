@@ -16,7 +16,13 @@ using namespace jmac;
 
 namespace {
 
-constexpr int kWaves = 8;             // waves per 32x32 tile = K split factor
+#ifndef JMAC_GG_WAVES
+#define JMAC_GG_WAVES 8
+#endif
+#ifndef JMAC_GG_KC
+#define JMAC_GG_KC 304
+#endif
+constexpr int kWaves = JMAC_GG_WAVES;  // waves per 32x32 tile = K split factor
 constexpr int kBlock = 64 * kWaves;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -76,8 +82,8 @@ struct GTable {
 //   RC ("r contiguous": A transposed, B not transposed)  lds[k * 32 + r]: fragment = four ds_read_b32, lanes r consecutive
 // Fragment of one 8-deep K step for the 32x32x2 MFMA: lane (r = lane & 31, h = lane >> 5) holds the operand's values for
 // row/column r and k = k0 + 4h + s, s = 0..3; MFMA step s contracts k = {k0 + s, k0 + 4 + s}.
-constexpr int kKc = 304;                       // K chunk (38 steps of 8)
-constexpr int kLdk = 308;                      // row pitch of a KC panel (floats)
+constexpr int kKc = JMAC_GG_KC;                // K chunk (38 steps of 8)
+constexpr int kLdk = kKc + 4;                  // row pitch of a KC panel (floats): 4 * odd
 constexpr int kPanel = 32 * kLdk;              // floats per panel (KC form; the RC form needs kKc * 32 <= this)
 constexpr int kStage = (32 * (kKc / 4) + kBlock - 1) / kBlock;      // float4s per thread per panel = 5
 constexpr int kSteps = (kKc / 8 + kWaves - 1) / kWaves;             // K steps per wave per chunk = 5
@@ -228,13 +234,15 @@ __device__ __forceinline__ void grouped_tile(const GTask& t, int tile, float* __
     for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
     __syncthreads();
     const int n = n0 + r, nc = min(n, N - 1);
-    float v[2], msk[2] = {0.f, 0.f}, old[2] = {0.f, 0.f};
-    float* cp[2];
-    const float* mp[2];
-    bool ok[2];
+    constexpr int kRegs = 16 / kWaves;
+    float v[kRegs], msk[kRegs], old[kRegs];
+    float* cp[kRegs];
+    const float* mp[kRegs];
+    bool ok[kRegs], acc_ok[kRegs];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int i = 2 * wave + j;
+    for (int j = 0; j < kRegs; ++j) {
+        msk[j] = old[j] = 0.f;
+        const int i = kRegs * wave + j;
         float sum = red[0][i][lane];
 #pragma unroll
         for (int w = 1; w < kWaves; ++w) sum += red[w][i][lane];
@@ -242,33 +250,34 @@ __device__ __forceinline__ void grouped_tile(const GTask& t, int tile, float* __
         const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h, mc = min(m, M - 1);
         ok[j] = m < M && n < N;
         cp[j] = mc < t.c_split ? t.C + (int64_t)mc * t.ldc + nc : t.C2 + (int64_t)(mc - t.c_split) * t.ldc + nc;
+        acc_ok[j] = mc < t.c_split;                            // accumulate is a property of C; C2 rows are always stored
         mp[j] = t.mask + (int64_t)mc * t.ldmask + nc;
     }
     // block-uniform branches: a task without these epilogue inputs pays no round trip for them
     if (t.act == JMAC_GEMM_DACT_LEAKY || t.act == JMAC_GEMM_DACT_RELU) {
-        msk[0] = gld(mp[0]);
-        msk[1] = gld(mp[1]);
+#pragma unroll
+        for (int j = 0; j < kRegs; ++j) msk[j] = gld(mp[j]);
     }
     if (t.accumulate) {
-        old[0] = gld(cp[0]);
-        old[1] = gld(cp[1]);
+#pragma unroll
+        for (int j = 0; j < kRegs; ++j) old[j] = gld(cp[j]);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < kRegs; ++j) {
         float x = v[j];
         if (t.act == JMAC_GEMM_ACT_LEAKY) x = x > 0.f ? x : x * t.slope;
         else if (t.act == JMAC_GEMM_ACT_RELU) x = x > 0.f ? x : 0.f;
         else if (t.act == JMAC_GEMM_DACT_LEAKY) x = msk[j] > 0.f ? x : x * t.slope;
         else if (t.act == JMAC_GEMM_DACT_RELU) x = msk[j] > 0.f ? x : 0.f;
-        if (t.accumulate) x += old[j];
+        if (t.accumulate && acc_ok[j]) x += old[j];
         v[j] = x;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < kRegs; ++j)
         if (ok[j]) gst(cp[j], v[j]);
 }
 
-__global__ __launch_bounds__(kBlock, 4) void grouped_gemm_kernel(const GTable tab) {   // 4 waves per SIMD = two blocks per CU
+__global__ __launch_bounds__(kBlock, 4) void grouped_gemm_kernel(const GTable tab) {   // 4 waves per SIMD (two 8-wave blocks per CU)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // The table is a by-value kernel argument indexed by a run-time task id.  Indexing `tab` itself makes the compiler copy
     // all 3.6 KB of it into per-lane scratch; the kernarg segment is ordinary constant memory, so the scan and the one task

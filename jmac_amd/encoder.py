@@ -304,6 +304,7 @@ class _EncoderName(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, E, Rc, Ra, info, NL, U11, U21, Wall, L11, L12, L11u, L12u, *lp):
         require_device(E, Rc, Ra, info)
+        ctx.set_materialize_grads(False)          # an unused output's gradient arrives as None (whole branches are skipped)
         la, lc, l2 = cfg.layers
         pa, pc, p2 = lp[0:8], lp[8:16], lp[16:24]
         graph, training, p_drop, mslope = cfg.graph, cfg.training, cfg.p_drop, cfg.mlp_slope
@@ -422,11 +423,11 @@ class _EncoderName(torch.autograd.Function):
                 cga = add(0, t.cha.bwd_tasks(dRRa, dwca, dRa_buf, False))        # levels 0-2 -> d rel_align (first writer)
                 wrote_a = True
                 gL11u, gL12u = add(3, t.mla.bwd_tasks(d_rain, dRa_buf, True))    # levels 3-4 -> d rel_align +=
-            if have_c:
-                cgc = add(0, t.chc.bwd_tasks(dRRc, dwcc, dRc_buf, False))        # levels 0-2 -> d rel_comp (first writer)
+            if g_relc1 is not None:                                               # rel_c1 = MLP(rel_comp) needs only the loss' gradient:
+                gL11, gL12 = add(0, t.mlc.bwd_tasks(g_relc1.contiguous(), dRc_buf, False))   # levels 0-1 -> d rel_comp (first writer)
                 wrote_c = True
-            if g_relc1 is not None:
-                gL11, gL12 = add(3, t.mlc.bwd_tasks(g_relc1.contiguous(), dRc_buf, wrote_c))   # levels 3-4 -> d rel_comp (+)=
+            if have_c:
+                cgc = add(0, t.chc.bwd_tasks(dRRc, dwcc, dRc_buf, wrote_c))      # levels 0-2 -> d rel_comp (+)= at level 2
                 wrote_c = True
             run_levels(levels)
             dRa = dRa_buf if wrote_a else None
@@ -448,6 +449,7 @@ class _EncoderNoName(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, E, Rc, L11, L12, *pc):
         require_device(E, Rc)
+        ctx.set_materialize_grads(False)
         (lc,) = cfg.layers
         N, d = E.shape
         t = SimpleNamespace()

@@ -146,6 +146,7 @@ def test_grouped_gemm_forms_and_epilogues(seed):
     outs = {k: torch.empty(M, N, device=DEV) for k in ("nn", "nt", "tn", "leaky", "relu", "dleaky", "drelu")}
     acc = C0.clone()
     c_hi, c_lo = torch.empty(M - 3, N, device=DEV), torch.empty(3, N, device=DEV)
+    acc_hi, acc_lo = C0[:M - 3].clone(), torch.full((3, N), float("nan"), device=DEV)
     strided_out = torch.zeros(M, 3 * N, device=DEV)
     Afull = torch.cat((A, A2))
     tasks = [gemm_task(A, B, outs["nn"], A2=A2),
@@ -157,6 +158,7 @@ def test_grouped_gemm_forms_and_epilogues(seed):
              gemm_task(Afull, B, outs["drelu"], act=DACT_RELU, act_src=src),
              gemm_task(Afull, B, acc, accumulate=True),
              gemm_task(Afull, B, c_hi, C2=c_lo),
+             gemm_task(Afull, B, acc_hi, C2=acc_lo, accumulate=True),       # accumulate applies to C; C2 rows are stored
              gemm_task(big[:, N:2 * N], r(N, N), strided_out[:, 2 * N:]),
              # transposed A whose K rows continue in a second buffer (the adjoint of cat(rel_emb, loop_rel))
              gemm_task(A, r(M, N), torch.empty(K, N, device=DEV), ta=True, A2=A2)]
@@ -172,7 +174,9 @@ def test_grouped_gemm_forms_and_epilogues(seed):
     assert_close(outs["drelu"], torch.where(src > 0, ref, torch.zeros_like(ref)), **tol)
     assert_close(acc, C0.double() + ref, **tol)
     assert_close(torch.cat((c_hi, c_lo)), ref, **tol)
-    t9, t10 = tasks[9]._keep, tasks[10]._keep
+    assert_close(acc_hi, C0[:M - 3].double() + ref[:M - 3], **tol)
+    assert_close(acc_lo, ref[M - 3:], **tol)
+    t9, t10 = tasks[10]._keep, tasks[11]._keep
     assert_close(strided_out[:, 2 * N:], t9[0].double() @ t9[1].double(), **tol)
     assert float(strided_out[:, :2 * N].abs().max()) == 0.0       # nothing outside the output slice was touched
     assert_close(t10[2], Afull.double().t() @ t10[1].double(), **tol)
