@@ -15,6 +15,7 @@ Extra objects on the same line:
   cpu_baseline  the oracle (un-factorised reference formulation, PyTorch CPU) timed on the same step
   scoring       scored triples/s: B=1000 queries x all N candidates x 2 layers + filtered rank
   sim           config-5 shape: fp32 MFMA similarity GEMM (TFLOP/s, fraction of the f32 matrix peak), get_neg, CSLS test
+  union         config 3 (union of the five KGs, bf16 tables): encoder forward + fused scoring vs all 56 589 entities
   synth         config 4 (1M entities / 20M triples / 1k relations): aggregation kernel GB/s at HBM scale
 """
 import argparse
@@ -651,6 +652,110 @@ def sim_bench(device, iters=10, cpu=True):
     return res
 
 
+def union_bench(a, device, cpu=True):
+    """BASELINE configs[2]: the block-diagonal union of the five DBP-5L-shaped KGs (N = 56 589 entities, 5 x 961 relation
+    rows, E = 197 604 = train + validation triples of the four supporters + the target's train triples) with bf16 tables:
+    the encoder forward (three layers, bf16 [P|Q|Z] / [Rq|Rz] tables, fp32 logits / softmax / sums / BN) and the fused
+    completion scoring of B = 1000 queries against ALL 56 589 entities over 2 layers (jmac_linkpred_rank_bf16: filtered
+    ranks, no [B, N] matrix).  The reference scores inside the target KG only (src/validate.py:43-44); the union is the
+    scale-up BASELINE names, with its parity checked in tests/test_gpu_fullsize.py.  CPU beside it: the oracle's encoder
+    forward and its cdist + filter + rank on the same tables (fp32: the reference has no bf16 form)."""
+    from jmac_amd import ops, scoring, synth
+    from jmac_amd.graph import RelGraph
+    from jmac_amd.model import JMAC
+    ei, et, n, nr, ent_bases, rel_bases = synth.dbp5l_union(1234, target="ja")
+    E, d, B = int(ei.shape[1]), a.dim, a.batch
+    rng = np.random.default_rng(11)
+    torch.manual_seed(11)
+    margs = make_args(d, B, a.negatives, device)
+    name_emb = rng.standard_normal((n, 300)).astype(np.float32)
+    m = JMAC(margs, name_emb, nr, n).to(device)
+    m.ent_info_att = m.ent_info_att.to(device)
+    m.set_table_dtype(torch.bfloat16)
+    m.eval()
+    ei_t, et_t = torch.from_numpy(ei).to(device), torch.from_numpy(et).to(device)
+    hb, rb, gold_h = rng.integers(0, n, B), rng.integers(0, nr, B), rng.integers(0, n, B)
+    fptr_h = np.arange(0, 3 * B + 1, 3, dtype=np.int32)
+    fidx_h = rng.integers(0, n, 3 * B).astype(np.int32)
+    hb_d, rb_d, gold = (torch.from_numpy(x).to(device) for x in (hb, rb, gold_h))
+    fptr, fidx = torch.from_numpy(fptr_h).to(device), torch.from_numpy(fidx_h).to(device)
+    with torch.no_grad():
+        enc = lambda: m.forward_base(ei_t, et_t, [0, n], [0, nr])
+        enc_ms = _median_ms(enc, n=10, warm=3)
+        cached = enc()
+        rank_fn = lambda: scoring.linkpred_ranks(cached[1], cached[2], hb_d, rb_d, gold, fptr, fidx, table_dtype=torch.bfloat16)
+        for _ in range(3):
+            rank_fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            rank_fn()
+        e1.record()
+        torch.cuda.synchronize()
+        rank_ms = e0.elapsed_time(e1) / 10
+        ranks16 = rank_fn().cpu().numpy()
+        ranks32 = scoring.linkpred_ranks(cached[1], cached[2], hb_d, rb_d, gold, fptr, fidx).cpu().numpy()
+        # the bf16 aggregation kernel alone on the union graph: HIP events around back-to-back launches
+        g = RelGraph(ei_t, et_t, n, nr + 1)
+        gen = torch.Generator(device=device).manual_seed(0)
+        PQZ = (torch.randn(n, 3 * d, device=device, generator=gen) * 0.3).to(torch.bfloat16)
+        RR = (torch.randn(nr + 1, 2 * d, device=device, generator=gen) * 0.3).to(torch.bfloat16)
+        av = torch.randn(d, device=device, generator=gen) * 0.1
+        agg = lambda: ops.rel_attn_aggregate(PQZ, RR, av, g, 0.05, nr, 0.5)
+        for _ in range(3):
+            agg()
+        e0.record()
+        for _ in range(50):
+            agg()
+        e1.record()
+        torch.cuda.synchronize()
+        agg_ms = e0.elapsed_time(e1) / 50
+    fb16 = synth.fwd_algorithmic_bytes(n, E, d, 2)
+    elems = float(B) * n * d * 2                                   # (b, n, k) triples over the two layers
+    res = {"workload": "config 3: union of the five DBP-5L-shaped KGs, N=%d E=%d nr=%d d=%d, bf16 tables; scoring B=%d x N x 2 layers"
+                       % (n, E, nr, d, B),
+           "encoder_fwd_ms": enc_ms, "encoder_fwd_edges_per_s": 3 * E / (enc_ms * 1e-3),
+           "encoder": "JMAC.forward_base, eval mode, three RelationAwareLayer calls on bf16 tables (wall time, eager)",
+           "scored_triples_per_s": B / (rank_ms * 1e-3), "pair_scores_per_s": B * n * 2 / (rank_ms * 1e-3), "rank_ms_per_batch": rank_ms,
+           "scoring": "jmac_linkpred_rank_bf16: query rows + gold distances + filter correction + L1 tiles with a "
+                      "compare-and-count epilogue (HIP events around 10 batches)",
+           "mean_relative_rank_difference_vs_fp32_tables": float((np.abs(ranks16 - ranks32) / np.maximum(ranks32, 1)).mean()),
+           "rank_note": "random-init embeddings: candidates are near-ties, so bf16 rounding moves a rank by a few percent of "
+                        "itself (tests/test_gpu_fullsize.py bounds it at 2 %)",
+           "roofline": {"bound": "valu", "kernel": "link_rank_tile_kernel<bf16>", "achieved": 2.0 * elems / (rank_ms * 1e-3) / 1e12,
+                        "peak": VALU_ISSUE_PEAK / 1e12, "unit": "T lane-instructions/s", "frac": 2.0 * elems / (rank_ms * 1e-3) / VALU_ISSUE_PEAK,
+                        "note": "2 VALU lane-instructions per (b, n, k); L1 distance is not a contraction (no MFMA form)"},
+           "aggregation_roofline": {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<..., bf16>", "avg_launch_ms": agg_ms,
+                                    "algorithmic_bytes_per_launch": fb16, "achieved": fb16 / (agg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": fb16 / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "%.0f MB per launch: Infinity-Cache resident" % (fb16 / 1e6)}}
+    if cpu:
+        import oracle.jmac_oracle as orc
+        st = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        bn = {k: v.clone() for k, v in st.items() if "running" in k}
+        eic, etc_ = torch.from_numpy(ei), torch.from_numpy(et)
+        ne = torch.from_numpy(name_emb)
+
+        def cpu_enc():
+            with torch.no_grad():
+                return orc.forward_name(st, ne, eic, etc_, [0, n], [0, nr], 2, 0.05, "sub", False, bn)
+        ce_s, n1 = _cpu_median_s(cpu_enc, n=2, warm=0, budget_s=10.0)
+        comp = [c.detach().cpu().float() for c in cached[1]]
+        rel = [r.detach().cpu().float() for r in cached[2]]
+
+        def cpu_rank():
+            d_ = orc.linkpred_dist(comp, rel, hb.tolist(), rb.tolist())
+            return orc.filtered_ranks(d_, gold_h.tolist(), fptr_h, fidx_h)
+        cr_s, n2 = _cpu_median_s(cpu_rank, n=2, warm=0, budget_s=10.0)
+        res["cpu"] = {"kind": "port", "cores": torch.get_num_threads(), "encoder_fwd_s": ce_s, "encoder_fwd_edges_per_s": 3 * E / ce_s,
+                      "scored_triples_per_s": B / cr_s,
+                      "sample": "%d encoder forward(s) of the oracle (un-factorised, fp32) on the union graph; %d scoring batch(es): "
+                                "torch.cdist(p=1) x 2 layers + filter + rank count on the same B / N / d (fp32)" % (n1, n2)}
+        res["gpu_over_cpu_encoder"] = ce_s / (enc_ms * 1e-3)
+        res["gpu_over_cpu_scoring"] = cr_s / (rank_ms * 1e-3)
+    return res
+
+
 def synth_cpu_layer(scale, d):
     """config 4 down-scaled (E = 20M x scale) through the oracle's layer on the host cores, fwd and
     fwd+bwd, one call each; the full-size figure is the linear extrapolation in E (stated in the output)."""
@@ -731,6 +836,26 @@ def synth_measure(a, device, cpu=True):
     return res
 
 
+def complete_sharded_line(line, a):
+    """Rank 0, sharded workload: the CPU baseline beside it (the oracle's layer on config 4 down-scaled, as in ``synth``) and
+    the forward kernel's HBM traffic from the committed PMC pass -- the N > 1 line is a complete record by itself."""
+    if not a.no_cpu_baseline:
+        try:
+            torch.set_num_threads(min(os.cpu_count() or 1, 16))
+            c = synth_cpu_layer(0.1 * a.synth_scale, a.dim)
+            line["cpu_baseline"] = {"value": c["fwdbwd_edges_per_s"], "unit": "edges/s", "cores": c["cores"], "kind": "port",
+                                    "sample": c["sample"] + "; value = edges through ONE layer forward + backward per second "
+                                              "(the line's value counts the same unit: 2 layers x E per step)",
+                                    "fwd_edges_per_s": c["fwd_edges_per_s"], "cpu_model": _cpu_model()}
+            line["gpu_over_cpu"] = line["value"] / c["fwdbwd_edges_per_s"]
+        except Exception as ex:                              # pragma: no cover
+            line["cpu_baseline"] = {"error": str(ex)}
+    if a.dim == 300 and a.synth_scale == 1.0:
+        line["roofline"]["traffic"] = pmc_traffic("config4", "rel_attn_fwd_kernel")
+        line["roofline"]["traffic_source"] = ("profiles/r2_pmc_config4.json (committed rocprofv3 --pmc passes of the same kernel on "
+                                              "one rank's graph; not collected by this run)")
+
+
 def pmc_traffic(key, kernel_prefix):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r2_pmc_<key>.json), or None.
     PMC collection needs rocprofv3 around the process, so bench.py reports the committed measurement."""
@@ -797,6 +922,8 @@ def main():
             init_dist()
         from bench_dist import run_sharded          # destination-sharded synthetic graph, RCCL all-gather
         line = run_sharded(a, rank, world, device)
+        if rank == 0:
+            complete_sharded_line(line, a)
         if dist_on:
             import torch.distributed as dist
             dist.barrier()
@@ -852,6 +979,7 @@ def main():
         sa.steps, sa.warmup = max(3, min(a.steps, 10)), 2
         line = run_sharded(sa, rank, world, device)
         if rank == 0:
+            complete_sharded_line(line, a)
             line["config"]["scaling_base"] = "the 'sharded' object of the --gpus 1 line (same step, one rank, no collective)"
             line["replicas"] = {"value": value, "unit": "edges/s", "ms_per_step": ms, "steps": a.steps, "exec": exec_mode,
                                 "workload": "one DBP-5L ja-shaped KG per GPU, independent replicas, no collective "
@@ -914,6 +1042,10 @@ def main():
         line["sim"] = sim_bench(device, cpu=cpu_on)
     except Exception as ex:                          # pragma: no cover
         line["sim"] = {"error": str(ex)}
+    try:
+        line["union"] = union_bench(a, device, cpu=cpu_on)
+    except Exception as ex:                          # pragma: no cover
+        line["union"] = {"error": str(ex)}
 
     if cpu_on:
         # PyTorch-CPU scales poorly past one socket's worth of cores on these small ops (256 threads ran 30x

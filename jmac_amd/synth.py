@@ -14,9 +14,11 @@ DBP5L = {  # lang: (N, train triples, distinct relation ids used ~)
 NUM_REL = 961     # relations.txt lines + 1 (src/data_loader.py:214-215)
 
 
-def dbp5l_like(lang: str = "ja", seed: int = 1234, bidirectional: bool = False):
+def dbp5l_like(lang: str = "ja", seed: int = 1234, bidirectional: bool = False, num_triples: int = None):
     """(edge_index [2,E] int64, edge_type [E] int64, N, nr) with the degree profile of a DBP-5L train graph."""
     n, e = DBP5L[lang]
+    if num_triples is not None:
+        e = int(num_triples)
     rng = np.random.default_rng(seed)
     # heads: 46 % of the nodes are non-empty destinations; segment lengths geometric-ish, capped at 28
     heads = rng.permutation(n)[: int(round(n * 0.46))]
@@ -32,13 +34,20 @@ def dbp5l_like(lang: str = "ja", seed: int = 1234, bidirectional: bool = False):
     return np.stack([dst, src]).astype(np.int64), typ.astype(np.int64), n, NUM_REL
 
 
-def dbp5l_union(seed: int = 1234, bidirectional: bool = False):
+# train + validation triples: what a SUPPORTER KG trains on (src/knowledgegraph.py:18-19; SURVEY 8d shape table)
+DBP5L_TRAIN_VAL = {"el": 12822, "en": 72703, "es": 49256, "fr": 44844, "ja": 26612}
+
+
+def dbp5l_union(seed: int = 1234, bidirectional: bool = False, target: str = None):
     """Config 3: block-diagonal union of the five DBP-5L-shaped KGs with the reference's id offsets
     (entity_id_base / relation_id_base, src/data_loader.py:162-181): N = 56 589, 5 x 961 relation rows (+1 loop row
-    added by the layer).  Returns (edge_index, edge_type, N, nr, ent_bases, rel_bases)."""
+    added by the layer).  ``target``: that KG carries its train triples, the other four train + validation (the edge
+    counts the reference trains with: E = 197 604 for target 'ja'); None: train triples everywhere (E = 138 476).
+    Returns (edge_index, edge_type, N, nr, ent_bases, rel_bases)."""
     eis, ets, ent_bases, rel_bases = [], [], [0], [0]
     for k, lang in enumerate(("el", "en", "es", "fr", "ja")):
-        ei, et, n, nr = dbp5l_like(lang, seed + k, bidirectional)
+        e_lang = DBP5L_TRAIN_VAL[lang] if (target is not None and lang != target) else None
+        ei, et, n, nr = dbp5l_like(lang, seed + k, bidirectional, e_lang)
         eis.append(ei + ent_bases[-1])
         ets.append(et + rel_bases[-1])
         ent_bases.append(ent_bases[-1] + n)
