@@ -311,9 +311,14 @@ int jmac_filtered_rank_f32(const float* score, int64_t lds, const int32_t* gold,
 int jmac_sim_matrix_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M,
                         int64_t N, int64_t d, float* C, int64_t ldc, jmac_stream_t stream);
 
-size_t jmac_sim_topk_workspace_bytes(int64_t L, int64_t N);
+size_t jmac_sim_topk_workspace_bytes(int64_t L, int64_t N, int32_t k);
 /* Per row of A: the k largest similarities against all rows of B, descending, ties -> lower index
- * first.  val [L,k] (may be NULL), idx [L,k] int32. */
+ * first.  val [L,k] (may be NULL), idx [L,k] int32.
+ * N >= 8192 and k <= 64: the L x N score matrix is never written (running top-k in the product's epilogue): a column sample
+ * gives every row a threshold (the k-th largest of its first ~N/8 scores, a lower bound of its final k-th score), the full
+ * product appends the scores that reach it to per-row candidate lists, a last pass takes the k best of each list; a row whose
+ * list overflows (mass ties) recomputes its scores with the product's own instruction sequence.  Same scores bit for bit,
+ * hence the same indices as the two-step form; workspace O(L * N / 8) instead of L * N * 4. */
 int jmac_sim_topk_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t L, int64_t N,
                       int64_t d, int32_t k, float* val, int32_t* idx, void* ws, size_t ws_bytes,
                       jmac_stream_t stream);

@@ -92,7 +92,7 @@ _SIGS = {
     "jmac_linkpred_rank_f32": (C.c_int, [vp, i32, vp, vp, i32, vp, vp, vp, i64, i64, i64, vp, vp, sz, vp]),
     "jmac_linkpred_rank_bf16": (C.c_int, [vp, i32, vp, vp, i32, vp, vp, vp, i64, i64, i64, vp, vp, sz, vp]),
     "jmac_sim_matrix_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, vp]),
-    "jmac_sim_topk_workspace_bytes": (sz, [i64, i64]),
+    "jmac_sim_topk_workspace_bytes": (sz, [i64, i64, i32]),
     "jmac_sim_topk_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, i32, vp, vp, vp, sz, vp]),
     "jmac_col_topk_workspace_bytes": (sz, [i64, i64, i32]),
     "jmac_col_topk_f32": (C.c_int, [vp, i64, i64, i64, i32, vp, vp, sz, vp]),

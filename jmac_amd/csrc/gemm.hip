@@ -159,6 +159,14 @@ __device__ __forceinline__ float4 panel_frag(const float* __restrict__ lds, int 
 // a full 32-column tile for the RC form)
 // MULTI: K spans several chunks -> the next chunk's global loads are prefetched into registers during the MFMAs;
 // single-chunk products (every forward product at d <= 304) prefetch all of a wave's LDS fragments instead.
+#ifdef JMAC_GG_TRACE
+// debug builds (tools/gg_trace.py): per-block timestamps of the phases, written behind the output of task 0's C2 pointer
+#define GG_STAMP(i) do { if (threadIdx.x == 0) gg_trace_buf[((int64_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long* gg_trace_buf;
+#else
+#define GG_STAMP(i)
+#endif
+
 template <bool TA, bool TB, bool VA, bool VB, bool MULTI>
 __device__ __forceinline__ void grouped_tile(const GTask& t, int tile, float* __restrict__ lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -172,6 +180,7 @@ __device__ __forceinline__ void grouped_tile(const GTask& t, int tile, float* __
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     // chunk loop: the NEXT chunk's global loads are issued before this chunk's MFMAs (registers), so a long-K product
     // (the weight gradients: K = the ~10^3 relation rows, four chunks) pays one exposed round trip, not four
+    GG_STAMP(1);
     float4 va[kStage], vb[kStage];
     if constexpr (VA) panel_load<!TA>(t.A, m0, M, 0, K, va);            // 10 loads per thread in flight
     if constexpr (VB) panel_load<TB>(t.B, n0, N, 0, K, vb);
@@ -188,6 +197,7 @@ __device__ __forceinline__ void grouped_tile(const GTask& t, int tile, float* __
             if constexpr (VB) panel_load<TB>(t.B, n0, N, k0 + kKc, K, vb);
         }
         __syncthreads();
+        GG_STAMP(2);
         // wave w takes steps w, w + 8, ... (<= kSteps of them): all their fragments are read first (one LDS latency), the
         // dependent MFMA chain follows; steps past the chunk read a clamped address and are skipped (wave-uniform test)
         const int steps = (min(K - k0, kKc) + 7) / 8;          // <= 38
@@ -225,6 +235,7 @@ __device__ __forceinline__ void grouped_tile(const GTask& t, int tile, float* __
             }
         }
     }
+    GG_STAMP(3);
     __syncthreads();                                           // panels are dead: their memory carries the partial tiles
     // every wave leaves its 16 accumulator registers in LDS; wave w then finishes registers 2w and 2w + 1 of the tile: the
     // eight partials are summed in wave order (bitwise reproducible), the epilogue's own loads (act' source, accumulate)
@@ -275,10 +286,12 @@ __device__ __forceinline__ void grouped_tile(const GTask& t, int tile, float* __
 #pragma unroll
     for (int j = 0; j < kRegs; ++j)
         if (ok[j]) gst(cp[j], v[j]);
+    GG_STAMP(4);
 }
 
 __global__ __launch_bounds__(kBlock, 4) void grouped_gemm_kernel(const GTable tab) {   // 4 waves per SIMD (two 8-wave blocks per CU)
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    GG_STAMP(0);
     // The table is a by-value kernel argument indexed by a run-time task id.  Indexing `tab` itself makes the compiler copy
     // all 3.6 KB of it into per-lane scratch; the kernarg segment is ordinary constant memory, so the scan and the one task
     // this block runs are read from there with scalar loads instead.
@@ -288,13 +301,20 @@ __global__ __launch_bounds__(kBlock, 4) void grouped_gemm_kernel(const GTable ta
     // grid = (largest tile count of the launch, tasks): the task index is blockIdx.y, so the block's only dependent scalar
     // round trip is the read of its own task (a prefix scan over the table cost two more: ~1 us each from a kernarg buffer
     // the host has just written); blocks past their task's tile count leave at once
+    // The task is fetched with ONE vector load per wave (lane i <- dword i of the task) and spread to scalars with
+    // v_readlane: a single memory round trip.  Read field by field with scalar loads, the compiler sinks the loads next to
+    // their uses -- three dependent trips to the kernarg buffer (task pointers, dimensions, epilogue parameters) at ~1.7 us
+    // each, half of a block's life (phase timestamps: tools/gg_trace.py).
     GTask t;                                                                 // 38 dwords, block-uniform: SGPRs
     {
-        typedef const uint32_t __attribute__((address_space(4))) * KWords;
-        KWords src = (KWords)&kt->t[blockIdx.y];
+        static_assert(sizeof(GTask) / 4 <= 64, "one lane per dword of the task");
+        typedef const uint32_t __attribute__((address_space(1))) * GWords;
+        GWords src = (GWords)(uintptr_t)(&kt->t[blockIdx.y]);
+        const int l = threadIdx.x & 63;
+        const uint32_t w = src[l < (int)(sizeof(GTask) / 4) ? l : 0];
         uint32_t* dst = reinterpret_cast<uint32_t*>(&t);
 #pragma unroll
-        for (unsigned i = 0; i < sizeof(GTask) / 4; ++i) dst[i] = src[i];
+        for (unsigned i = 0; i < sizeof(GTask) / 4; ++i) dst[i] = (uint32_t)__builtin_amdgcn_readlane((int)w, (int)i);
     }
     if ((int)blockIdx.x >= t.tile_begin) return;                             // tile_begin holds the task's tile COUNT
     const int tile = (int)blockIdx.x;
@@ -329,6 +349,12 @@ int jmac_gemm_f32(const float* A, int64_t lda, int32_t transA, const float* B, i
     t.C = C; t.ldc = ldc; t.M = M; t.N = N; t.K = K;
     return jmac_gemm_grouped_f32(&t, 1, stream);
 }
+
+#ifdef JMAC_GG_TRACE
+int jmac_gemm_trace_buffer(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(gg_trace_buf), &buf, sizeof(buf));
+}
+#endif
 
 int jmac_gemm_grouped_f32(const jmac_gemm_task_t* tasks, int32_t n_tasks, jmac_stream_t stream) {
     if (n_tasks < 0 || n_tasks > kMaxTasks || (n_tasks > 0 && !tasks)) return JMAC_EINVAL;

@@ -389,15 +389,32 @@ constexpr int SG_PLANE = SG_T * 4 + 8;      // floats per (sub-slab q, k-half h)
                                             // instruction touches start on different banks
 constexpr int SG_IMG = 4 * SG_PLANE;        // one operand slab: planes (q, h) = (0,0) (0,1) (1,0) (1,1)
 constexpr int SG_SUPER = 8;                 // super-tile of 8x8 tiles per XCD visit (L2: 2 x 1.2 MB at d=300)
+constexpr int SG_FL_CAP = 256;              // FILTER epilogue: passing elements a wave collects before it claims their slots
 
-__global__ __launch_bounds__(kBlock) void sim_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
+// FILTER = true: the scores are not stored.  An element that reaches its row's threshold tau (a lower bound of the row's k-th
+// largest score, taken from a column sample: jmac_sim_topk_f32) is appended to the row's candidate list instead -- the running
+// top-k of SURVEY K8: the L x N matrix never exists.
+struct SimFilter {
+    const float* tau;        // tau[m * tau_stride]
+    int64_t tau_stride;
+    int* cnt;                // [M] candidates seen per row (may exceed cap: the row then recomputes its scores, see below)
+    float* cval;             // [M, cap]
+    int* cidx;               // [M, cap]
+    int cap;
+};
+
+template <bool FILTER>
+__global__ __launch_bounds__(kBlock, 3) void sim_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
                                                           int64_t ldb, int M, int N, int d, float* __restrict__ C, int64_t ldc,
-                                                          int tiles_m, int tiles_n, int super_order, int n_ids) {
+                                                          int tiles_m, int tiles_n, int super_order, int n_ids, SimFilter flt) {
     // LDS image of one operand slab (16 k): plane (q, h) holds, for every tile row, the 4 floats k = 8q + 4h .. +3.
     // Lane (r = l&31, h = l>>5) of a wave reads its float4 of row r from plane (q, h): 32 lanes x 16 B contiguous,
     // conflict free for ds_read_b128's lane groups.  The MFMA step s of a sub-slab contracts k = {8q+s, 8q+4+s}.
     __shared__ __attribute__((aligned(16))) float As[2][SG_IMG];
     __shared__ __attribute__((aligned(16))) float Bs[2][SG_IMG];
+    __shared__ int fl_m[FILTER ? kBlock / 64 : 1][FILTER ? SG_FL_CAP : 1];      // FILTER: per-wave lists of passing elements
+    __shared__ int fl_n[FILTER ? kBlock / 64 : 1][FILTER ? SG_FL_CAP : 1];
+    __shared__ float fl_v[FILTER ? kBlock / 64 : 1][FILTER ? SG_FL_CAP : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;           // wave grid 2 x 2, each wave 64 x 64
 
@@ -525,6 +542,56 @@ __global__ __launch_bounds__(kBlock) void sim_gemm_kernel(const float* __restric
         }
         // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
         const bool full = m0 + SG_T <= M && n0 + SG_T <= N;      // block-uniform: interior tiles store without bounds tests
+        if constexpr (FILTER) {
+            // Passing elements are rare (~k * N / Ns per row: under 1 % of the tile).  A returned global atomic per passing
+            // element inside the scan would cost one memory round trip each (measured: the product ran 1.6x longer); the wave
+            // first compacts its passing elements into a small LDS list (ballot + prefix popcount, no memory traffic) and
+            // then claims their slots with ONE batch of atomics per flush.
+            int fcount = 0;                                    // wave-uniform
+            auto flush = [&]() {
+                __threadfence_block();                         // the list's LDS writes are visible to the whole wave
+                for (int e = lane; e < fcount; e += 64) {
+                    const int m = fl_m[wave][e];
+                    const int pos = atomicAdd(flt.cnt + m, 1);
+                    if (pos < flt.cap) {
+                        flt.cval[(int64_t)m * flt.cap + pos] = fl_v[wave][e];
+                        flt.cidx[(int64_t)m * flt.cap + pos] = fl_n[wave][e];
+                    }
+                }
+                __threadfence_block();
+                fcount = 0;
+            };
+            // thresholds of the wave's 64 rows: ONE coalesced load (lane l <-> row l of the wave's row block); the value for
+            // accumulator register (i, reg) comes out of it with two v_readlane (rows (i, reg, h = 0 / 1) are 4 apart)
+            const float trow = flt.tau[(int64_t)min(m0 + wm * 64 + lane, M - 1) * flt.tau_stride];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rbase = i * 32 + (reg & 3) + 8 * (reg >> 2);           // compile-time
+                    const int m = m0 + wm * 64 + rbase + 4 * h;
+                    const float tau = h ? bcast_f(trow, rbase + 4) : bcast_f(trow, rbase);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int n = n0 + wn * 64 + j * 32 + r;
+                        const float v = acc[i][j][reg];
+                        const bool pass = m < M && n < N && v >= tau;
+                        const unsigned long long mask = __ballot(pass);
+                        if (mask != 0ull) {                    // wave-uniform
+                            const int np = __popcll(mask);
+                            if (fcount + np > SG_FL_CAP) flush();
+                            if (pass) {
+                                const int slot = fcount + __popcll(mask & ((1ull << lane) - 1ull));
+                                fl_m[wave][slot] = m;
+                                fl_n[wave][slot] = n;
+                                fl_v[wave][slot] = v;
+                            }
+                            fcount += np;
+                        }
+                    }
+                }
+            flush();
+        } else
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -710,6 +777,158 @@ __global__ __launch_bounds__(kBlock) void row_topk_kernel(const float* __restric
             pick_i = bi;
             if (val) val[(int64_t)b * k + r] = bv;
             idx[(int64_t)b * k + r] = bi == INT32_MAX ? -1 : bi;
+        }
+        __syncthreads();
+        pv = pick_v;
+        pi = pick_i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-k of a row from its candidate list (fused similarity + top-k, jmac_sim_topk_f32): every element >= tau was listed, and
+// at least k elements are (tau is the k-th largest of a column sample), so the list's k best ARE the row's k best; order and
+// ties as row_topk_kernel (value descending, lower index first).
+// A row whose list overflowed (more than cap elements reach tau: e.g. a constant row) recomputes its N scores with the
+// SAME instruction sequence per element as sim_gemm_kernel -- v_mfma_f32_32x32x2_f32 over k in the same order, so the bits
+// are the GEMM's -- once per pass of the two-pass selection (and per arg-max round if even that overflows).  Slow by design:
+// it exists so that degenerate inputs still get the exact answer.
+// ------------------------------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ void for_each_row_score(const float* __restrict__ arow, const float* __restrict__ Bm, int64_t ldb, int N,
+                                                   int d, F f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nk = (d + SG_K - 1) / SG_K;
+    for (int n0 = wave * 32; n0 < N; n0 += 32 * (kBlock / 64)) {
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        const float* brow = Bm + (int64_t)min(n0 + r, N - 1) * ldb;
+        for (int kt = 0; kt < nk; ++kt)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = kt * SG_K + 8 * q + 4 * h;
+                float4 a4 = ld4(arow + min(k, d - 4)), b4 = ld4(brow + min(k, d - 4));
+                if (k >= d) a4 = b4 = f4zero();
+                if (r != 0) a4 = f4zero();                     // row 0 of the 32x32 tile is the row; the rest is padding
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+            }
+        if (h == 0 && n0 + r < N) f(n0 + r, acc[0]);           // C/D map: row 0 = register 0 of the lanes with h == 0
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void cand_select_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
+                                                             int64_t ldb, int N, int d, int k, const int* __restrict__ cnt,
+                                                             const float* __restrict__ cval, const int* __restrict__ cidx_g, int cap,
+                                                             float* __restrict__ val, int32_t* __restrict__ idx) {
+    __shared__ int hist[TK_BINS];
+    __shared__ unsigned ckey[TK_CAP];
+    __shared__ int cidx[TK_CAP];
+    __shared__ float cv[TK_CAP];
+    __shared__ int sh_bin, sh_above, sh_cnt;
+    __shared__ float wv[kBlock / 64];
+    __shared__ int wi[kBlock / 64];
+    __shared__ float pick_v;
+    __shared__ int pick_i;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int C = cnt[b];
+    auto select = [&](int Cn) {                                // slot = number of candidates that beat this one
+        for (int c = tid; c < Cn; c += kBlock) {
+            const unsigned kc = ckey[c];
+            const int ic = cidx[c];
+            int better = 0;
+            for (int o = 0; o < Cn; ++o) better += tk_beats(ckey[o], cidx[o], kc, ic) ? 1 : 0;
+            if (better < k) {
+                idx[(int64_t)b * k + better] = ic;
+                if (val) val[(int64_t)b * k + better] = cv[c];
+            }
+        }
+    };
+    if (C <= cap) {                                            // the normal case (cap <= TK_CAP)
+        for (int c = tid; c < C; c += kBlock) {
+            const float v = cval[(int64_t)b * cap + c];
+            ckey[c] = tk_key(v);
+            cidx[c] = cidx_g[(int64_t)b * cap + c];
+            cv[c] = v;
+        }
+        __syncthreads();
+        select(C);
+        return;
+    }
+    // ---- overflow: two-pass selection over recomputed scores
+    const float* arow = A + (int64_t)b * lda;
+    for (int i = tid; i < TK_BINS; i += kBlock) hist[i] = 0;
+    if (tid == 0) sh_cnt = 0;
+    __syncthreads();
+    for_each_row_score(arow, Bm, ldb, N, d, [&](int n, float v) { atomicAdd(&hist[tk_key(v) >> 20], 1); });
+    __syncthreads();
+    if (tid == 0) {                                            // (rare path: a serial scan from the top bin is fine)
+        int above = 0, bin = TK_BINS - 1;
+        for (; bin > 0; --bin) {
+            if (above + hist[bin] >= k) break;
+            above += hist[bin];
+        }
+        sh_bin = bin;
+        sh_above = above;
+    }
+    __syncthreads();
+    const int bstar = sh_bin;
+    C = sh_above + hist[bstar];
+    if (C <= TK_CAP) {
+        for_each_row_score(arow, Bm, ldb, N, d, [&](int n, float v) {
+            const unsigned key = tk_key(v);
+            if ((int)(key >> 20) >= bstar) {
+                const int slot = atomicAdd(&sh_cnt, 1);
+                ckey[slot] = key;
+                cidx[slot] = n;
+                cv[slot] = v;
+            }
+        });
+        __syncthreads();
+        select(C);
+        return;
+    }
+    // ---- even the top bin overflows (e.g. a constant row): k rounds of arg-max after the previous pick
+    float pv = INFINITY;
+    int pi = -1;
+    for (int rr = 0; rr < k; ++rr) {
+        float bv = -INFINITY;
+        int bi = INT32_MAX;
+        for_each_row_score(arow, Bm, ldb, N, d, [&](int n, float v) {
+            const bool after = (v < pv) || (v == pv && n > pi);
+            const bool better = (v > bv) || (v == bv && n < bi);
+            if (after && better) {
+                bv = v;
+                bi = n;
+            }
+        });
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if ((tid & 63) == 0) {
+            wv[tid >> 6] = bv;
+            wi[tid >> 6] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < kBlock / 64; ++w)
+                if (wv[w] > bv || (wv[w] == bv && wi[w] < bi)) {
+                    bv = wv[w];
+                    bi = wi[w];
+                }
+            pick_v = bv;
+            pick_i = bi;
+            if (val) val[(int64_t)b * k + rr] = bv;
+            idx[(int64_t)b * k + rr] = bi == INT32_MAX ? -1 : bi;
         }
         __syncthreads();
         pv = pick_v;
@@ -1001,7 +1220,7 @@ __global__ __launch_bounds__(kBlock) void csls_rank_kernel(const float* __restri
 }
 
 int launch_sim(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t d, float* C, int64_t ldc,
-               hipStream_t st) {
+               hipStream_t st, const SimFilter* flt = nullptr) {
     if (M == 0 || N == 0) return 0;
     const int tiles_m = (int)((M + SG_T - 1) / SG_T), tiles_n = (int)((N + SG_T - 1) / SG_T);
     const int64_t sup = (int64_t)((tiles_m + SG_SUPER - 1) / SG_SUPER) * ((tiles_n + SG_SUPER - 1) / SG_SUPER);
@@ -1018,14 +1237,18 @@ int launch_sim(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t
     if (resident == 0 || dev >= 64) {
         int cus = 256, occ = 3;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(sim_gemm_kernel), kBlock, 0) != hipSuccess || occ < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(sim_gemm_kernel<false>), kBlock, 0) != hipSuccess || occ < 1)
             occ = 3;
         resident = (cus * occ) / 8 * 8;
         if (resident < 8) resident = 8;
     }
     const unsigned grid = (unsigned)(n_ids < resident ? n_ids : resident);
-    hipLaunchKernelGGL(sim_gemm_kernel, dim3(grid), dim3(kBlock), 0, st, A, lda, B, ldb, (int)M, (int)N, (int)d, C, ldc,
-                       tiles_m, tiles_n, super_order, (int)n_ids);
+    if (flt)
+        hipLaunchKernelGGL(sim_gemm_kernel<true>, dim3(grid), dim3(kBlock), 0, st, A, lda, B, ldb, (int)M, (int)N, (int)d, C, ldc,
+                           tiles_m, tiles_n, super_order, (int)n_ids, *flt);
+    else
+        hipLaunchKernelGGL(sim_gemm_kernel<false>, dim3(grid), dim3(kBlock), 0, st, A, lda, B, ldb, (int)M, (int)N, (int)d, C, ldc,
+                           tiles_m, tiles_n, super_order, (int)n_ids, SimFilter{});
     return (int)hipGetLastError();
 }
 
@@ -1154,8 +1377,32 @@ int jmac_sim_matrix_f32(const float* A, int64_t lda, const float* B, int64_t ldb
     return launch_sim(A, lda, B, ldb, M, N, d, C, ldc, (hipStream_t)stream);
 }
 
-size_t jmac_sim_topk_workspace_bytes(int64_t L, int64_t N) {
-    if (L < 0 || N < 0) return 0;
+// fused similarity + running top-k: used when the matrix is wide enough for the column sample to pay
+constexpr int ST_CAP = TK_CAP;            // candidates kept per row
+constexpr int ST_KMAX = 64;
+constexpr int64_t ST_MIN_N = 8192;
+static inline bool st_fused(int64_t N, int64_t k) { return N >= ST_MIN_N && k <= ST_KMAX; }
+static inline int64_t st_sample(int64_t N) {
+    int64_t ns = N / 12 > 2048 ? N / 12 : 2048;            // expected candidates per row ~ k * N / Ns <= 12k (cap: 1024)
+    return (ns + 127) / 128 * 128;
+}
+struct StWs { size_t s0, val0, idx0, cnt, cval, cidx, total; };
+static StWs st_layout(int64_t L, int64_t N, int64_t k) {
+    StWs w{};
+    size_t off = 0;
+    w.s0 = off;   off += align_up((size_t)L * (size_t)st_sample(N) * 4);
+    w.val0 = off; off += align_up((size_t)L * (size_t)k * 4);
+    w.idx0 = off; off += align_up((size_t)L * (size_t)k * 4);
+    w.cnt = off;  off += align_up((size_t)L * 4);
+    w.cval = off; off += align_up((size_t)L * ST_CAP * 4);
+    w.cidx = off; off += align_up((size_t)L * ST_CAP * 4);
+    w.total = off + 256;
+    return w;
+}
+
+size_t jmac_sim_topk_workspace_bytes(int64_t L, int64_t N, int32_t k) {
+    if (L < 0 || N < 0 || k <= 0) return 0;
+    if (st_fused(N, k)) return st_layout(L, N, k).total;      // sample scores + candidate lists: no L x N matrix
     return align_up((size_t)L * (size_t)N * 4) + 256;
 }
 
@@ -1173,10 +1420,31 @@ int jmac_sim_topk_f32(const float* A, int64_t lda, const float* B, int64_t ldb, 
     if (L == 0) return JMAC_OK;
     if (!A || !B || !idx) return JMAC_EINVAL;
     if (lda % 4 || ldb % 4) return JMAC_EDIM;
-    if (!ws || ws_bytes < jmac_sim_topk_workspace_bytes(L, N)) return JMAC_EWORKSPACE;
-    float* S = (float*)ws;
-    if (int rc = launch_sim(A, lda, B, ldb, L, N, d, S, N, (hipStream_t)stream)) return rc;
-    return launch_topk(S, N, L, N, k, val, idx, (hipStream_t)stream);
+    if (!ws || ws_bytes < jmac_sim_topk_workspace_bytes(L, N, k)) return JMAC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (!st_fused(N, k)) {                                   // narrow matrices: scores to the workspace, then the row pass
+        float* S = (float*)ws;
+        if (int rc = launch_sim(A, lda, B, ldb, L, N, d, S, N, st)) return rc;
+        return launch_topk(S, N, L, N, k, val, idx, st);
+    }
+    // 1. tau[m] = k-th largest score of row m among the first Ns columns: a lower bound of the row's final k-th score
+    const StWs w = st_layout(L, N, k);
+    char* wb = (char*)ws;
+    const int64_t Ns = st_sample(N);
+    float* S0 = (float*)(wb + w.s0);
+    float* val0 = (float*)(wb + w.val0);
+    if (int rc = launch_sim(A, lda, B, ldb, L, Ns, d, S0, Ns, st)) return rc;
+    if (int rc = launch_topk(S0, Ns, L, Ns, k, val0, (int32_t*)(wb + w.idx0), st)) return rc;
+    // 2. the full product with the filtering epilogue: candidates instead of the matrix
+    SimFilter f{};
+    f.tau = val0 + (k - 1); f.tau_stride = k;
+    f.cnt = (int*)(wb + w.cnt); f.cval = (float*)(wb + w.cval); f.cidx = (int*)(wb + w.cidx); f.cap = ST_CAP;
+    if (hipMemsetAsync(f.cnt, 0, (size_t)L * 4, st) != hipSuccess) return (int)hipGetLastError();
+    if (int rc = launch_sim(A, lda, B, ldb, L, N, d, nullptr, 0, st, &f)) return rc;
+    // 3. the k best of every candidate list
+    hipLaunchKernelGGL(cand_select_kernel, dim3((unsigned)L), dim3(kBlock), 0, st, A, lda, B, ldb, (int)N, (int)d, (int)k, f.cnt, f.cval,
+                       f.cidx, ST_CAP, val, idx);
+    return (int)hipGetLastError();
 }
 
 size_t jmac_softmax_entropy_workspace_bytes(int64_t n1, int64_t n2) {

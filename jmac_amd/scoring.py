@@ -156,7 +156,7 @@ def sim_topk(a: torch.Tensor, b: torch.Tensor, k: int, return_values: bool = Fal
     L = lib()
     idx = torch.empty((L_, k), dtype=torch.int32, device=a.device)
     val = torch.empty((L_, k), dtype=torch.float32, device=a.device) if return_values else None
-    ws_bytes = int(L.jmac_sim_topk_workspace_bytes(L_, N))
+    ws_bytes = int(L.jmac_sim_topk_workspace_bytes(L_, N, int(k)))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=a.device)
     check(L.jmac_sim_topk_f32(ptr(a), d, ptr(b), d, L_, N, d, int(k), ptr(val), ptr(idx), ptr(ws), ws_bytes, stream()),
           "jmac_sim_topk_f32")

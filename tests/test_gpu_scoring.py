@@ -322,3 +322,48 @@ def test_fused_linkpred_ranks_match_reference_golden():
         ref = g["ranks_filt%d" % int(filt)]                          # the reference's CompletionEvaluator.test
         assert safe.mean() > 0.5 and (got[safe] == ref[safe]).all()
         assert np.allclose(orc.ranking_metrics(got), g["eval_filt%d" % int(filt)], atol=0.02)
+
+
+def _two_step_topk(a, b, k):
+    from jmac_amd import scoring
+    return scoring.row_topk(scoring.sim_matrix(a, b), k)
+
+
+@pytest.mark.parametrize("L,N,d,k", [(700, 20000, 300, 25), (130, 9000, 64, 10), (33, 30000, 300, 64)])
+def test_sim_topk_fused_running_topk_is_bit_identical_to_two_step_form(L, N, d, k):
+    """SURVEY K8 / modules/utils/util.py:52-53: at N >= 8192 jmac_sim_topk_f32 never writes the L x N matrix (threshold from a
+    column sample, candidates from the product's epilogue, selection from the lists).  Same scores bit for bit, so indices AND
+    values must equal sim_matrix + row_topk exactly; the workspace is a fraction of the matrix."""
+    from jmac_amd import scoring
+    from jmac_amd._lib import lib
+    gen = torch.Generator(device="cuda").manual_seed(L + N)
+    b = torch.nn.functional.normalize(torch.randn(N, d, device="cuda", generator=gen))
+    a = b[torch.randperm(N, device="cuda", generator=gen)[:L]] + 0.05 * torch.randn(L, d, device="cuda", generator=gen)
+    idx, val = scoring.sim_topk(a, b, k, return_values=True)
+    val2, idx2 = _two_step_topk(a.contiguous(), b, k)
+    assert torch.equal(idx, idx2)
+    assert torch.equal(val, val2)
+    assert int(lib().jmac_sim_topk_workspace_bytes(L, N, k)) < (0.3 if N >= 20000 else 0.6) * L * N * 4
+
+
+def test_sim_topk_fused_overflowing_rows_recompute_exactly():
+    """Mass ties push more than the list capacity over a row's threshold: those rows recompute their scores with the product's
+    own MFMA sequence and must still return the two-step answer (ties -> lower index first)."""
+    from jmac_amd import scoring
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    N, d, k = 12000, 96, 25
+    base = torch.nn.functional.normalize(torch.randn(40, d, device="cuda", generator=gen))
+    b = base[torch.arange(N, device="cuda") % 40].contiguous()            # every row of b occurs 300 times: 300-way exact ties
+    a = torch.cat((base[:5] + 0.01 * torch.randn(5, d, device="cuda", generator=gen),
+                   torch.zeros(3, d, device="cuda"),                         # constant rows: every score ties
+                   torch.nn.functional.normalize(torch.randn(6, d, device="cuda", generator=gen))))
+    idx, val = scoring.sim_topk(a, b, k, return_values=True)
+    val2, idx2 = _two_step_topk(a, b, k)
+    assert torch.equal(idx, idx2)
+    assert torch.equal(val, val2)
+    assert idx[5].tolist() == list(range(k))                                # all-equal scores: the k lowest indices
+    # and a mix in one call: unique rows (normal lists) beside overflowing ones
+    b2 = torch.cat((b[:6000], torch.nn.functional.normalize(torch.randn(6000, d, device="cuda", generator=gen))))
+    idx, val = scoring.sim_topk(a, b2, k, return_values=True)
+    val2, idx2 = _two_step_topk(a, b2, k)
+    assert torch.equal(idx, idx2) and torch.equal(val, val2)
