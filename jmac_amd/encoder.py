@@ -40,7 +40,8 @@ CAPTURE = None
 
 
 # ---- grouped small GEMM -------------------------------------------------------------------------------------------------
-def gemm_task(A, B, Cout, *, ta=False, tb=False, A2=None, C2=None, act=ACT_NONE, act_src=None, slope=0.0, accumulate=False):
+def gemm_task(A, B, Cout, *, ta=False, tb=False, A2=None, C2=None, act=ACT_NONE, act_src=None, slope=0.0, accumulate=False,
+              defer=False):
     """One product ``Cout (+)= epilogue(op(A) op(B))`` for jmac_gemm_grouped_f32.  ``A2`` / ``C2``: the rows of A (its
     MEMORY rows: the K rows when ``ta``) / of the output that follow A's / Cout's own rows live in a second buffer."""
     for t in (A, B, Cout, A2, C2, act_src):
@@ -63,6 +64,8 @@ def gemm_task(A, B, Cout, *, ta=False, tb=False, A2=None, C2=None, act=ACT_NONE,
     t.act_src, t.ld_act_src = ptr(act_src), (act_src.stride(0) if act_src is not None else 0)
     t.act, t.accumulate, t.slope = int(act), int(bool(accumulate)), float(slope)
     t._keep = (A, B, Cout, A2, C2, act_src)          # the tensors outlive the (asynchronous) launch
+    t._defer = bool(defer)                           # nothing later in the same batch of levels reads the output
+    t._cost = ((M + 31) // 32) * ((N + 31) // 32) * ((K + 303) // 304)      # (tile, K chunk) units of the kernel
     return t
 
 
@@ -75,8 +78,30 @@ def grouped_gemm(tasks: Sequence[GemmTask]) -> None:
         check(lib().jmac_gemm_grouped_f32(arr, len(chunk), stream()), "jmac_gemm_grouped_f32")
 
 
-def run_levels(levels: List[List[GemmTask]]) -> None:
-    for lv in levels:
+def balance_levels(levels: List[List[GemmTask]]) -> List[List[GemmTask]]:
+    """Move deferrable products (weight gradients: long-K products that nothing in the batch reads) from the crowded
+    early levels to later, lighter ones.  A launch costs about as much as its rounds of resident blocks, and the levels of a
+    backward are lopsided: the first carries ten products, the last two carry two each.  Order of execution per output is
+    unchanged (a task only ever moves later; accumulating tasks keep their single predecessor), so results are too."""
+    levels = [list(lv) for lv in levels]
+    total = sum(t._cost for lv in levels for t in lv)
+    if not total or len(levels) < 2:
+        return levels
+    target = total / len(levels)
+    for i in range(len(levels) - 1):
+        cost = sum(t._cost for t in levels[i])
+        movable = sorted((t for t in levels[i] if t._defer), key=lambda t: -t._cost)
+        for t in movable:
+            if cost <= target:
+                break
+            levels[i].remove(t)
+            levels[i + 1].append(t)
+            cost -= t._cost
+    return levels
+
+
+def run_levels(levels: List[List[GemmTask]], balance: bool = False) -> None:
+    for lv in (balance_levels(levels) if balance else levels):
         if lv:
             grouped_gemm(lv)
 
@@ -220,11 +245,11 @@ class _Chain:
         dW1, dW2, dloop = _empty(dev, d, d), _empty(dev, d, d), _empty(dev, 1, d)
         dact = DACT_RELU if self.relu else DACT_LEAKY
         return [[gemm_task(dRR, self.wc[:, d:], dR2, tb=True),
-                 gemm_task(self.R2, dRR, dwc[:, d:], ta=True, accumulate=True)],
+                 gemm_task(self.R2, dRR, dwc[:, d:], ta=True, accumulate=True, defer=True)],
                 [gemm_task(dR2, self.W2, dT, tb=True, act=dact, act_src=self.T, slope=self.slope),
-                 gemm_task(self.T, dR2, dW2, ta=True)],
+                 gemm_task(self.T, dR2, dW2, ta=True, defer=True)],
                 [gemm_task(dT, self.W1, dR, tb=True, C2=dloop, accumulate=dR_accumulate),
-                 gemm_task(self.R, dT, dW1, ta=True, A2=self.loop)]], (dW1, dW2, dloop)
+                 gemm_task(self.R, dT, dW1, ta=True, A2=self.loop, defer=True)]], (dW1, dW2, dloop)
 
 
 class _RelMLP:
@@ -244,9 +269,9 @@ class _RelMLP:
         dM = _empty(dev, *self.M.shape)
         dW1, dW2 = _empty(dev, *self.W1.shape), _empty(dev, *self.W2.shape)
         return [[gemm_task(g, self.W2, dM, tb=True, act=DACT_LEAKY, act_src=self.M, slope=self.slope),
-                 gemm_task(self.M, g, dW2, ta=True)],
+                 gemm_task(self.M, g, dW2, ta=True, defer=True)],
                 [gemm_task(dM, self.W1, dR, tb=True, accumulate=dR_accumulate),
-                 gemm_task(self.R, dM, dW1, ta=True)]], (dW1, dW2)
+                 gemm_task(self.R, dM, dW1, ta=True, defer=True)]], (dW1, dW2)
 
 
 def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None):
@@ -412,7 +437,7 @@ class _EncoderName(torch.autograd.Function):
             dU11 = _empty(dev, 2 * d, d)
             dU11[:d].copy_(dw[:d])
             dNL = _empty(dev, di, d)
-            levels[0].extend([gemm_task(dw[d:], U11[d:], dNL, tb=True), gemm_task(NL, dw[d:], dU11[d:], ta=True)])
+            levels[0].extend([gemm_task(dw[d:], U11[d:], dNL, tb=True, defer=True), gemm_task(NL, dw[d:], dU11[d:], ta=True, defer=True)])
         # ---- relation side
         if have_align or g_relc1 is not None or have_c:
             dRa_buf, dRc_buf = _empty(dev, *Ra.shape), _empty(dev, *Rc.shape)
@@ -429,7 +454,7 @@ class _EncoderName(torch.autograd.Function):
             if have_c:
                 cgc = add(0, t.chc.bwd_tasks(dRRc, dwcc, dRc_buf, wrote_c))      # levels 0-2 -> d rel_comp (+)= at level 2
                 wrote_c = True
-            run_levels(levels)
+            run_levels(levels, balance=True)
             dRa = dRa_buf if wrote_a else None
             dRc = dRc_buf if wrote_c else None
         if have_align:
