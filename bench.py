@@ -823,7 +823,7 @@ def synth_measure(a, device, cpu=True):
            "fwd_ms": r["fwd_ms"], "fwd_edges_per_s": e / (r["fwd_ms"] * 1e-3),
            "fwd_GBps": fb / (r["fwd_ms"] * 1e-3) / 1e9, "fwd_frac_hbm": fb / (r["fwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "fwd_traffic_bytes": pmc_traffic("config4", "rel_attn_fwd_kernel") if (a.dim == 300 and a.synth_scale == 1.0) else None,
-           "fwd_traffic_source": "profiles/r2_pmc_config4.json (committed rocprofv3 --pmc passes; not collected by this run)",
+           "fwd_traffic_source": "profiles/r3_pmc_config4.json (committed rocprofv3 --pmc passes; not collected by this run)",
            "bwd_ms": r["bwd_ms"], "bwd_GBps": bb / (r["bwd_ms"] * 1e-3) / 1e9,
            "bwd_frac_hbm": bb / (r["bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bwd_bytes": "SURVEY 8d backward formula",
            "bwd_edges_per_s": e / (r["bwd_ms"] * 1e-3)}
@@ -852,20 +852,21 @@ def complete_sharded_line(line, a):
             line["cpu_baseline"] = {"error": str(ex)}
     if a.dim == 300 and a.synth_scale == 1.0:
         line["roofline"]["traffic"] = pmc_traffic("config4", "rel_attn_fwd_kernel")
-        line["roofline"]["traffic_source"] = ("profiles/r2_pmc_config4.json (committed rocprofv3 --pmc passes of the same kernel on "
+        line["roofline"]["traffic_source"] = ("profiles/r3_pmc_config4.json (committed rocprofv3 --pmc passes of the same kernel on "
                                               "one rank's graph; not collected by this run)")
 
 
-def pmc_traffic(key, kernel_prefix):
+def pmc_traffic(key, kernel_prefix, rounds=("r3", "r2")):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r2_pmc_<key>.json), or None.
     PMC collection needs rocprofv3 around the process, so bench.py reports the committed measurement."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_%s.json" % key)))
-        for k, v in d["kernels"].items():
-            if k.startswith(kernel_prefix):
-                return v["traffic_bytes_corrected"]
-    except (OSError, KeyError, ValueError):
-        pass
+    for rnd in rounds:
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, key))))
+            for k, v in d["kernels"].items():
+                if k.startswith(kernel_prefix):
+                    return v["traffic_bytes_corrected"]
+        except (OSError, KeyError, ValueError):
+            pass
     return None
 
 
@@ -966,7 +967,7 @@ def main():
     ms = el / a.steps * 1e3
     layer_calls = 3
     value = world * layer_calls * w.E * a.steps / el
-    roof_src = "profiles/r2_pmc_ja.json (committed rocprofv3 --pmc passes; not collected by this run)"
+    roof_src = "profiles/r3_pmc_ja.json (committed rocprofv3 --pmc passes on the same real-graph workload; not collected by this run)"
     if dist_on:
         # N > 1: the headline is the path that actually shards -- BASELINE config 4 weak-scaled, destination-sharded, RCCL
         # all-gather / reduce-scatter per layer (north_star: "Partition ... across the 8 GPUs ... only when the graph
@@ -1007,7 +1008,8 @@ def main():
     fwd_ms = raw["fwd_ms"]
     roof = {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<3, 2, 75, float>", "achieved": fbytes / (fwd_ms * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fbytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("ja", "rel_attn_fwd_kernel") if (w.d == 300 and a.workload == "dbp5l-ja") else None,
+            "traffic": (pmc_traffic("ja", "rel_attn_fwd_kernel", ("r3",) if a.data == "real" else ("r2",))
+                        if (w.d == 300 and a.workload == "dbp5l-ja") else None),
             "traffic_source": roof_src,
             "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": fwd_ms, "launches": raw["fwd_launches"],
             "timing": "HIP events around %d back-to-back C-ABI launches on the launch stream" % raw["fwd_launches"],

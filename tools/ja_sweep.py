@@ -6,7 +6,13 @@ from jmac_amd.graph import RelGraph
 lang = sys.argv[1] if len(sys.argv) > 1 else "ja"
 bid = len(sys.argv) > 2 and sys.argv[2] == "bidir"
 d = 300
-ei, et, n, nrel = synth.dbp5l_like(lang, 1234, bidirectional=bid)
+if lang == "ja-real":      # the REAL DBP-5L ja KG (the bench's default workload): committed integer arrays
+    from jmac_amd.data import edges_from_triples, load_dbp5l_arrays
+    z = load_dbp5l_arrays(os.path.join(ROOT, "tests", "golden", "dbp5l_ja_el_data.npz"))
+    ei, et = edges_from_triples(z["ja.train"], bid)
+    n, nrel = int(z["ja.num_entity"]), int(z["n_relation_lines"]) + 2
+else:
+    ei, et, n, nrel = synth.dbp5l_like(lang, 1234, bidirectional=bid)
 dev = torch.device("cuda")
 g = RelGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(et).to(dev), n, nrel)
 g.ensure_backward_views()
