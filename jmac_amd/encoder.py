@@ -317,6 +317,61 @@ def supported(model, info_dim: Optional[int]) -> bool:
                     and l.table_dtype == torch.float32 and l.in_channels == d and l.out_channels == d for l in lays))
 
 
+# ---- one RelationAwareLayer ---------------------------------------------------------------------------------------------------
+class _LayerNode(torch.autograd.Function):
+    """RelationAwareLayer.forward (src/jmac_model.py:33-53; DBPv1: JMAC_DBPv1/models/jmac_model.py:43-63) as one node: the
+    relation chain in three grouped launches, the projection GEMM, aggregation, BatchNorm + tanh -- and a hand-written
+    backward (no slice / cat / add glue).  inputs: cfg, X, R, 8 layer tensors;  output: the layer's [N, d] output."""
+
+    @staticmethod
+    def forward(ctx, cfg, X, R, *pl):
+        require_device(X, R)
+        (lay,) = cfg.layers
+        N, d = X.shape
+        t = SimpleNamespace()
+        t.wc = _wcat(pl[3], pl[5], d)
+        t.ch = _Chain(lay, R, pl[0], pl[1], pl[2], t.wc, d)
+        run_levels([[f] for f in t.ch.fwd_tasks()])
+        y = _empty(X.device, N, d)
+        t.st = _layer_fwd(lay, X, t.wc, t.ch.RR, pl[4].reshape(-1), cfg.graph, cfg.training, y)
+        t.st.y = None                                            # the output reaches the backward through save_for_backward
+        if CAPTURE is not None:                                  # tests: the very tables the kernel gathered + the relation
+            CAPTURE["layer.tables"] = (t.st.PQZ, t.st.RR)        # transform's activation (its sign is its pre-activation's)
+            CAPTURE["layer.rel_act"] = t.ch.T
+        ctx.t, ctx.cfg, ctx.dims = t, cfg, (N, d)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        t, cfg = ctx.t, ctx.cfg
+        N, d = ctx.dims
+        (y,) = ctx.saved_tensors
+        st = SimpleNamespace(**vars(t.st))
+        st.y = y
+        dev = y.device
+        dX = _empty(dev, N, d) if ctx.needs_input_grad[1] else None
+        dRR, dwc, da, gbw = _layer_bwd(st, cfg.graph, gy.contiguous(), None, dX, False)
+        dR = _empty(dev, *t.ch.R.shape)
+        lv, cg = t.ch.bwd_tasks(dRR, dwc, dR, False)
+        run_levels(lv)
+        return (None, dX, dR, *_layer_grads(cg, dwc, da, gbw, d))
+
+
+def layer_supported(lay, X, R) -> bool:
+    d = lay.out_channels
+    return (lay.comp_op == "sub" and lay.layer_act is torch.tanh and lay.bn.momentum is not None and lay.bn.affine
+            and lay.table_dtype == torch.float32 and lay.in_channels == d and d % 4 == 0 and X.is_cuda
+            and X.dtype == torch.float32 and R.dtype == torch.float32 and X.dim() == 2 and X.stride(1) == 1
+            and X.stride(0) % 4 == 0 and R.is_contiguous() and R.shape[1] == d)
+
+
+def layer_forward(lay, X, R, graph: RelGraph):
+    """The layer's output on the fused node (lay: jmac_amd.layer.RelationAwareLayer / RelationalAwareLayer)."""
+    cfg = SimpleNamespace(layers=(lay,), graph=graph, training=lay.training)
+    return _LayerNode.apply(cfg, X, R, *_layer_inputs(lay))
+
+
 # ---- forward_name ---------------------------------------------------------------------------------------------------------
 class _EncoderName(torch.autograd.Function):
     """JMAC.forward_name (src/jmac_model.py:172-204), num_gcn_layer = 2.

@@ -96,6 +96,9 @@ class RelationAwareLayer(nn.Module):
         # torch.bfloat16: inference form -- the [P|Q|Z] / [Rq|Rz] tables are produced by bf16 GEMMs and gathered as
         # bf16 (half the bytes of the HBM-bound kernel); logits, softmax, sums, BN stay fp32.  Needs no_grad.
         self.table_dtype = torch.float32
+        # True: forward() runs as ONE autograd node (jmac_amd.encoder._LayerNode: grouped relation-side products, hand-written
+        # backward) wherever that node covers the configuration; False: op by op (the second implementation)
+        self.fused = True
 
     # -- pieces ---------------------------------------------------------------------------------
     @staticmethod
@@ -217,6 +220,12 @@ class RelationAwareLayer(nn.Module):
 
     # -- reference signature ----------------------------------------------------------------------
     def forward(self, ent_emb, rel_emb, edge_index, edge_type):
+        if self.fused and self.bwd_mode == ops.BWD_MODE_DETERMINISTIC:    # the whole layer as one autograd node
+            from . import encoder
+            if encoder.layer_supported(self, ent_emb, rel_emb):
+                require_device(ent_emb, rel_emb, edge_index, edge_type)
+                graph = graph_cache.get(edge_index, edge_type, ent_emb.size(0), rel_emb.size(0) + 1, self.chunk)
+                return encoder.layer_forward(self, ent_emb, rel_emb.contiguous(), graph)
         pre = self.pre_bn(ent_emb, rel_emb, edge_index, edge_type)
         bn = self.bn
         d = self.out_channels

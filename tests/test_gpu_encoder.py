@@ -40,6 +40,8 @@ def _model(d, n, nr, di, no_name, seed):
 def _run(m, fused, ei, et, n, nr, use, G):
     """One forward + backward; ``use`` selects which outputs feed the scalar loss."""
     m.fused_encoder = fused
+    for lay in (m.conv1_alignment, m.conv2_alignment, m.conv1_completion):
+        lay.fused = fused                                         # op by op all the way down: no node of encoder.py involved
     m.zero_grad(set_to_none=True)
     state = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
     align_out, comp, rel = m.forward_base(ei, et, [0, n], [0, nr])
@@ -96,7 +98,7 @@ def test_fused_encoder_equals_op_by_op_path(no_name, use):
     with torch.no_grad():
         m.fused_encoder = True
         a1, c1, r1 = m.forward_base(ei, et, [0, n], [0, nr])
-        m.fused_encoder = False
+        m.fused_encoder = False                                  # (the layers are still op by op from the last _run)
         a2, c2, r2 = m.forward_base(ei, et, [0, n], [0, nr])
     assert_close(a1, a2, 2e-5, 1e-6, "eval align_out")
     assert_close(c1[1], c2[1], 2e-5, 1e-6, "eval c1")
@@ -116,6 +118,8 @@ def test_fused_encoder_on_a_slice_of_the_tables():
     outs, grads = [], []
     for fused in (True, False):
         m.fused_encoder = fused
+        for lay in (m.conv1_alignment, m.conv2_alignment, m.conv1_completion):
+            lay.fused = fused
         m.zero_grad(set_to_none=True)
         st = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
         a, c, r = m.forward_base(ei, et, [e0, e1], [r0, r1])
@@ -265,3 +269,42 @@ def test_bn_tanh_two_destinations_two_gradients():
     assert_close(gx, xr.grad, 1e-4, 1e-6)
     assert_close(gbw[:d], bn2.bias.grad, 1e-4, 1e-6)
     assert_close(gbw[d:], bn2.weight.grad, 1e-4, 1e-6)
+
+
+@pytest.mark.parametrize("relu", [False, True], ids=["leaky", "dbpv1-relu"])
+def test_layer_node_equals_op_by_op_layer(relu):
+    """RelationAwareLayer.forward as one node (encoder._LayerNode) against the op-by-op layer: output, running statistics and
+    every gradient, both relation activations (src/jmac_model.py:41 LeakyReLU, JMAC_DBPv1/models/jmac_model.py:51 ReLU)."""
+    from jmac_amd.layer import RelationAwareLayer, RelationalAwareLayer
+    from util import make_args
+    n, nr, d = 900, 23, 40
+    rng = np.random.default_rng(3)
+    ei, et = random_graph(rng, n, nr, 3000, hub=280)
+    ei, et = torch.from_numpy(ei).to(DEV), torch.from_numpy(et).to(DEV)
+    torch.manual_seed(5)
+    lay = (RelationalAwareLayer(d, d, nr, rel_dim=d, act=torch.tanh, args=make_args()) if relu
+           else RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())).to(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    X0 = torch.randn(n, d, device=DEV, generator=gen) * 0.4
+    R0 = torch.randn(nr, d, device=DEV, generator=gen) * 0.4
+    G = torch.randn(n, d, device=DEV, generator=gen)
+    res = []
+    for fused in (True, False):
+        lay.fused = fused
+        lay.zero_grad(set_to_none=True)
+        lay.bn.running_mean.zero_(); lay.bn.running_var.fill_(1.0); lay.bn.num_batches_tracked.zero_()
+        X, R = X0.clone().requires_grad_(True), R0.clone().requires_grad_(True)
+        lay.train()
+        out = lay(X, R, ei, et)
+        (out * G).sum().backward()
+        lay.eval()
+        with torch.no_grad():
+            out_eval = lay(X, R, ei, et)
+        res.append((out.detach(), out_eval, X.grad, R.grad, lay.bn.running_mean.clone(), lay.bn.running_var.clone(),
+                    {k: p.grad.clone() for k, p in lay.named_parameters()}))
+    a, b = res
+    for x, y, what in zip(a[:6], b[:6], ("out", "out_eval", "grad X", "grad R", "running_mean", "running_var")):
+        assert_close(x, y, 1e-4, 1e-6, what)
+    scale = max(float(g.abs().max()) for g in b[6].values())
+    for k in b[6]:
+        assert_close(a[6][k], b[6][k], 1e-4, (1e-4 if k == "loop_rel" else 1e-6) * scale, k)

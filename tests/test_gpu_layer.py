@@ -74,7 +74,7 @@ def _oracle_case(n, nr, d, e, seed, hub=None, slope=0.05):
     return torch.from_numpy(ei), torch.from_numpy(et), X, R, G
 
 
-def _kink_flips(lay, p64, X64, R64, ei, et, Xg, Rg):
+def _kink_flips(lay, p64, X64, R64, ei, et, Xg, Rg, captured=None):
     """Number of attention pre-activations h_e[k] whose SIGN differs between the fp32 tables on the GPU and the
     float64 oracle.  The forward is continuous across the LeakyReLU kink, the gradient is not (slope 1 vs 0.05): with
     E*d ~ 10^6 values of O(1) and fp32 rounding ~1e-6, an element landing on the other side is a matter of chance,
@@ -82,14 +82,21 @@ def _kink_flips(lay, p64, X64, R64, ei, et, Xg, Rg):
     gradient at d=512).  Such cases are compared at a looser gradient tolerance; the forward tolerance never changes."""
     d = X64.shape[1]
     with torch.no_grad():
-        rel32 = lay.transform_relations(Rg)
-        PQZ, RR, _, dp = lay._tables(Xg, rel32)
+        rel_flips = 0
+        if captured and "layer.tables" in captured:      # the fused node: the tables IT gathered (a recomputation through
+            PQZ, RR = captured["layer.tables"]            # the op-by-op products may round differently), and the relation
+            dp = d                                        # transform's own LeakyReLU (src/jmac_model.py:41), same kind of kink
+            pre64 = torch.cat([R64, p64["loop_rel"]], 0) @ p64["rel_transform_weight1"]
+            rel_flips = int(((captured["layer.rel_act"].cpu() > 0) != (pre64 > 0)).sum())
+        else:
+            rel32 = lay.transform_relations(Rg)
+            PQZ, RR, _, dp = lay._tables(Xg, rel32)
         dst, src = ei[0].cuda(), ei[1].cuda()
         h32 = (PQZ[dst, :d] + PQZ[src, dp:dp + d] - RR[et.cuda(), :d]).cpu()
         rel64 = orc.transform_relations(p64, R64, 0.05, "leaky_relu")
         wt, wb = p64["w_att"][:d], p64["w_att"][d:]
         h64 = (X64 @ wt)[ei[0]] + (X64 @ wb)[ei[1]] - (rel64 @ wb)[et]
-    return int(((h32 > 0) != (h64 > 0)).sum())
+    return int(((h32 > 0) != (h64 > 0)).sum()) + rel_flips
 
 
 def _check_random_layer(n, nr, d, e, hub, chunk, mode, seed, lay_seed, strict):
@@ -111,10 +118,17 @@ def _check_random_layer(n, nr, d, e, hub, chunk, mode, seed, lay_seed, strict):
     lay = lay.cuda()
     lay.bwd_mode, lay.chunk = mode, chunk
     Xg, Rg = X.cuda().requires_grad_(True), R.cuda().requires_grad_(True)
-    out = lay(Xg, Rg, ei.cuda(), et.cuda())
+    from jmac_amd import encoder
+    captured = {}
+    encoder.CAPTURE = captured
+    try:
+        out = lay(Xg, Rg, ei.cuda(), et.cuda())
+    finally:
+        encoder.CAPTURE = None
     assert_close(out, ref, RTOL, 1e-6, "out")
     (out * G.cuda()).sum().backward()
-    flips = _kink_flips(lay, {k: v.detach() for k, v in p.items()}, Xc.detach(), Rc.detach(), ei, et, Xg.detach(), Rg.detach())
+    flips = _kink_flips(lay, {k: v.detach() for k, v in p.items()}, Xc.detach(), Rc.detach(), ei, et, Xg.detach(), Rg.detach(),
+                        captured)
     if strict:
         assert flips == 0, flips                                     # seed chosen flip-free (tools/flip_probe.py)
     assert flips <= 3, flips                                         # a handful at most out of e*d pre-activations
@@ -140,12 +154,13 @@ def test_layer_matches_oracle_random(n, nr, d, e, hub, chunk, mode):
     _check_random_layer(n, nr, d, e, hub, chunk, mode, seed=n + d, lay_seed=d, strict=False)
 
 
-@pytest.mark.parametrize("seed", [100, 101, 102])
+@pytest.mark.parametrize("seed", [101, 102, 103])
 @pytest.mark.parametrize("n,nr,d,e,hub,chunk", [(600, 25, 300, 5000, 700, 64), (500, 17, 256, 4000, 300, 128)])
 def test_layer_gradients_at_1e4_on_flip_free_seeds(n, nr, d, e, hub, chunk, seed):
     """The BASELINE dims (d=300, and the reference's default d=256) with NO tolerance escape: these seeds have no attention
-    pre-activation whose sign differs between the fp32 tables and the float64 oracle (tools/flip_probe.py scanned seeds
-    100-139: 0 flips for 100-119 at d=300, for 100-106 at d=256), so forward and every gradient must meet 1e-4 outright."""
+    pre-activation (and no pre-activation of the relation transform's own LeakyReLU) whose sign differs between the fp32
+    tables the layer node gathered and the float64 oracle (tools/flip_probe.py scanned seeds 100-139 on the round-3 node:
+    0 flips for 100-104 at d=300 and for 101-106 at d=256), so forward and every gradient must meet 1e-4 outright."""
     _check_random_layer(n, nr, d, e, hub, chunk, 1, seed=seed, lay_seed=seed, strict=True)
 
 

@@ -15,6 +15,13 @@ for (n, nr, d, e, hub, chunk) in [(600, 25, 300, 5000, 700, 64), (500, 17, 256, 
         lay = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())
         p = {k: v.detach().clone().double() for k, v in lay.named_parameters()}
         lay = lay.cuda()
-        fl = T._kink_flips(lay, p, X.double(), R.double(), ei, et, X.cuda(), R.cuda())
+        from jmac_amd import encoder
+        cap = {}
+        encoder.CAPTURE = cap                 # the fused layer node reports the tables it gathered
+        with torch.no_grad():
+            lay.train()
+            lay(X.cuda(), R.cuda(), ei.cuda(), et.cuda())
+        encoder.CAPTURE = None
+        fl = T._kink_flips(lay, p, X.double(), R.double(), ei, et, X.cuda(), R.cuda(), cap)
         out.append((seed, fl))
     print("d=%d:" % d, out)
