@@ -1311,8 +1311,10 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
     if (N < 0 || Nsrc < 0 || E < 0 || nrel <= 0) return JMAC_EINVAL;
     if (loop_rel < 0) self_off = 0;
     if (loop_rel >= 0 && (self_off < 0 || self_off + N > Nsrc)) return JMAC_EINVAL;   // the fused self term reads QZ[self_off + i]
-    if (!P || !QZ || !RR || !a_att || !by_dst || !out || !seg_max || !seg_den || !G || !dP || !dQZ || !dRR || !da)
-        return JMAC_EINVAL;
+    // a rank of the destination-sharded layer may own NO row (N == 0): its row-indexed buffers are empty (null), and the
+    // call still has to produce d[Q|Z] (zeros: no edge reads the table from here), dRR and da
+    if (!QZ || !RR || !a_att || !by_dst || !seg_max || !seg_den || !dQZ || !dRR || !da) return JMAC_EINVAL;
+    if (N > 0 && (!P || !out || !G || !dP)) return JMAC_EINVAL;
     if (mode != 0 && (!by_src || !by_rel || !dst_of_slot)) return JMAC_EINVAL;
     if (int rc = check_dims(d, ldp, ldqz, ldrr)) return rc;
     if (ldo % 4 || ldg % 4 || lddp % 4 || lddqz % 4 || lddrr % 4) return JMAC_EDIM;

@@ -32,7 +32,11 @@ def _standin_aggregate(P, QZ, RR, a, sg, slope):
     s = torch.nn.functional.leaky_relu(h, slope) @ a.view(-1, 1)
     alpha = orc.scatter_softmax(s, dst, sg.n_local)
     deg = orc.scatter_sum(torch.ones(dst.shape[0]), dst, sg.n_local)
-    return orc.scatter_sum(alpha * diff[:, d:], dst, sg.n_local) * deg.sqrt().view(-1, 1)
+    nb = orc.scatter_sum(alpha * diff[:, d:], dst, sg.n_local) * deg.sqrt().view(-1, 1)
+    # like the product's op (an autograd node on every rank, edges or not), the result always hangs on its inputs: a rank
+    # without rows must still run the backward collectives its peers wait in (the oracle's scatter helpers return a
+    # constant for empty inputs, which would let autograd prune them on that rank)
+    return nb + 0.0 * (QZ.sum() + P.sum() + RR.sum() + a.sum())
 
 
 class _StandinBN:
@@ -78,6 +82,8 @@ def _worker(rank, world, port, ret):
         from jmac_amd.layer import RelationAwareLayer
         ei, et, X, R, G, n, nr, d = _case()
         bounds = partition_rows(np.bincount(ei[0], minlength=n), world)
+        if os.environ.get("JMAC_TEST_BOUNDS"):          # hand-made ranges: uneven, and a rank that owns no row at all
+            bounds = np.array([int(x) for x in os.environ["JMAC_TEST_BOUNDS"].split(",")], dtype=np.int64)
         sg = ShardedGraph(ei, et, bounds, rank)
         torch.manual_seed(11)
         base = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())
@@ -99,11 +105,17 @@ def _worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("fused_bn", [False, True])
-def test_sharded_layer_equals_single_process_oracle(fused_bn, monkeypatch):
+@pytest.mark.parametrize("fused_bn,world,bounds", [(False, 2, None), (True, 2, None), (True, 4, "0,25,25,60,90"),
+                                                   (False, 4, "0,1,40,41,90")])
+def test_sharded_layer_equals_single_process_oracle(fused_bn, world, bounds, monkeypatch):
     """fused_bn: BatchNorm + tanh through sync_bn_tanh (per-rank moments, all-gather, Chan combination, all-reduced
-    backward sums) with the kernels' torch stand-in; otherwise the plain torch formulation."""
-    world = 2
+    backward sums) with the kernels' torch stand-in; otherwise the plain torch formulation.  world 4 with hand-made row
+    ranges: uneven shards, single-row shards and a rank that owns NO row (its table slab is all padding, its BN moments
+    carry weight zero in the Chan combination, its reduce-scatter slice is empty)."""
+    if bounds:
+        monkeypatch.setenv("JMAC_TEST_BOUNDS", bounds)
+    else:
+        monkeypatch.delenv("JMAC_TEST_BOUNDS", raising=False)
     if fused_bn:
         monkeypatch.setenv("JMAC_TEST_FUSED_BN", "1")
     else:
@@ -121,7 +133,9 @@ def test_sharded_layer_equals_single_process_oracle(fused_bn, monkeypatch):
     ref = orc.layer_forward(p, Xc, Rc, torch.from_numpy(ei), torch.from_numpy(et), 0.05, "sub", "leaky_relu", True, rm, rv)
     (ref * G).sum().backward()
     assert sum(ret[r]["e_local"] for r in range(world)) == ei.shape[1]
-    assert ret[0]["hi"] == ret[1]["lo"] and ret[0]["lo"] == 0 and ret[1]["hi"] == n
+    assert ret[0]["lo"] == 0 and ret[world - 1]["hi"] == n and all(ret[r]["hi"] == ret[r + 1]["lo"] for r in range(world - 1))
+    if bounds:
+        assert [ret[r]["lo"] for r in range(world)] + [n] == [int(x) for x in bounds.split(",")]
     for r in range(world):
         o = ret[r]
         lo, hi = o["lo"], o["hi"]

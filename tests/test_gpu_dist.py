@@ -43,6 +43,8 @@ def _worker(rank, world, port, ret):
         dev = torch.device("cuda", 0)
         ei, et, X, R, G, n, nr, d = _case()
         bounds = partition_rows(np.bincount(ei[0], minlength=n), world)
+        if os.environ.get("JMAC_TEST_BOUNDS"):          # hand-made ranges: uneven, and a rank that owns no row at all
+            bounds = np.array([int(x) for x in os.environ["JMAC_TEST_BOUNDS"].split(",")], dtype=np.int64)
         sg = ShardedGraph(ei, et, bounds, rank)
         torch.manual_seed(11)
         base = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args()).to(dev)
@@ -60,8 +62,14 @@ def _worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(600)
-def test_sharded_hip_layer_two_ranks():
-    world = 2
+@pytest.mark.parametrize("world,bounds", [(2, None), (3, "0,250,250,700")], ids=["two-ranks", "three-ranks-one-empty"])
+def test_sharded_hip_layer_two_ranks(world, bounds, monkeypatch):
+    """``three-ranks-one-empty``: rank 1 owns no row -- its kernels see N = 0, its table slab is padding, and it must still
+    take part in every collective of the forward and the backward."""
+    if bounds:
+        monkeypatch.setenv("JMAC_TEST_BOUNDS", bounds)
+    else:
+        monkeypatch.delenv("JMAC_TEST_BOUNDS", raising=False)
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
