@@ -290,10 +290,21 @@ __global__ __launch_bounds__(kMarginBlock) void margin_loss_fwd_kernel(const flo
     const float gamma = gamma_p[0];
     float acc = 0.f;
     const int64_t total = (int64_t)B * K;
-    for (int64_t i = threadIdx.x; i < total; i += kMarginBlock) {       // i = k*B + b: coalesced over b
-        const int b = (int)(i % B);
-        acc += fmaxf(score[b] - score[B + i], -gamma);
+    // eight independent (positive, negative) pairs in flight per trip: a rolled loop pays the load latency once per element
+    // (25 dependent round trips per thread at the reference's batch: 11 us for 26 000 scores)
+    int64_t i = threadIdx.x;
+    for (; i + 7 * kMarginBlock < total; i += 8 * kMarginBlock) {
+        float p[8], n[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t j = i + (int64_t)u * kMarginBlock;
+            p[u] = score[(int)(j % B)];
+            n[u] = score[B + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += fmaxf(p[u] - n[u], -gamma);      // fixed order per thread: reproducible
     }
+    for (; i < total; i += kMarginBlock) acc += fmaxf(score[(int)(i % B)] - score[B + i], -gamma);
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = kMarginBlock / 2; s > 0; s >>= 1) {
@@ -311,7 +322,20 @@ __global__ __launch_bounds__(kBlock) void margin_loss_bwd_kernel(const float* __
     if (b >= B) return;
     const float gamma = gamma_p[0], c = gloss[0] / ((float)B * (float)K), pos = score[b];
     float sum = 0.f;
-    for (int k = 0; k < K; ++k) {
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {                               // eight negatives in flight per trip
+        float nv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nv[u] = score[(int64_t)B + (int64_t)(k + u) * B + b];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float diff = pos - nv[u];
+            const float w = diff > -gamma ? 1.f : (diff == -gamma ? 0.5f : 0.f);
+            dscore[(int64_t)B + (int64_t)(k + u) * B + b] = -c * w;
+            sum += w;
+        }
+    }
+    for (; k < K; ++k) {
         const int64_t j = (int64_t)B + (int64_t)k * B + b;
         const float diff = pos - score[j];
         const float w = diff > -gamma ? 1.f : (diff == -gamma ? 0.5f : 0.f);

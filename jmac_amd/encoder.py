@@ -165,7 +165,10 @@ def _bn_fwd(x, bn, training, y, y2=None):
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     use_batch = bool(training or not bn.track_running_stats)
     if training and bn.track_running_stats:
-        bn.num_batches_tracked.add_(1)
+        if _TRACKERS is not None:
+            _TRACKERS.append(bn.num_batches_tracked)           # the encoder node bumps its layers' counters in ONE launch
+        else:
+            bn.num_batches_tracked.add_(1)
     check(L.jmac_bn_tanh_fwd2_f32(ptr(x), x.stride(0), N, d, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
                                   ptr(bn.running_var), 1 if use_batch else 0, float(bn.momentum), float(bn.eps), ptr(y),
                                   y.stride(0), ptr(y2), y2.stride(0) if y2 is not None else 0, ptr(mean), ptr(invstd), ptr(ws),
@@ -187,13 +190,17 @@ def _bn_bwd(x, y, gy, gy2, weight, mean, invstd, use_batch):
     return gx, gbw
 
 
-def _norm_drop_fwd(x, p_drop, training, y):
-    """completion_dropout(F.normalize(x)) into y (src/jmac_model.py:179,191): (inv, mask, scale)."""
+def _norm_drop_fwd(x, p_drop, training, y, mask=None):
+    """completion_dropout(F.normalize(x)) into y (src/jmac_model.py:179,191): (inv, mask, scale).  ``mask``: pre-drawn
+    {0,1} tensor (the encoder draws the masks of both dropout sites in one launch)."""
     N, d = x.shape
-    mask, scale = None, 1.0
+    scale = 1.0
     if training and p_drop > 0.0:
-        mask = torch.empty((N, d), dtype=torch.float32, device=x.device).bernoulli_(1.0 - p_drop)
+        if mask is None:
+            mask = torch.empty((N, d), dtype=torch.float32, device=x.device).bernoulli_(1.0 - p_drop)
         scale = 1.0 / (1.0 - p_drop)
+    else:
+        mask = None
     inv = _empty(x.device, max(N, 1))
     check(lib().jmac_row_normalize_drop_fwd_f32(ptr(x), x.stride(0), N, d, 1e-12, ptr(mask), d, scale, ptr(y), y.stride(0),
                                                 ptr(inv), stream()), "jmac_row_normalize_drop_fwd_f32")
@@ -205,6 +212,14 @@ def _norm_drop_bwd(x, inv, mask, scale, g, gx, accumulate):
     check(lib().jmac_row_normalize_drop_bwd_f32(ptr(x), x.stride(0), ptr(inv), ptr(mask), d, scale, ptr(g), g.stride(0), N, d,
                                                 1e-12, ptr(gx), gx.stride(0), 1 if accumulate else 0, stream()),
           "jmac_row_normalize_drop_bwd_f32")
+
+
+_TRACKERS = None      # list while an encoder node's forward runs: the num_batches_tracked buffers to bump at its end
+
+
+def _bump_trackers(trackers) -> None:
+    if trackers:
+        torch._foreach_add_(trackers, 1)
 
 
 # ---- layer pieces -------------------------------------------------------------------------------------------------------
@@ -382,7 +397,18 @@ class _EncoderName(torch.autograd.Function):
     outputs: align_out [N,d], c1 = completion layer 1 [N,d], rel_c1 [nr,d]"""
 
     @staticmethod
-    def forward(ctx, cfg, E, Rc, Ra, info, NL, U11, U21, Wall, L11, L12, L11u, L12u, *lp):
+    def forward(ctx, cfg, *tensors):
+        global _TRACKERS
+        _TRACKERS = []                            # the three layers' num_batches_tracked: bumped by ONE launch at the end
+        try:
+            out = _EncoderName._forward(ctx, cfg, *tensors)
+            _bump_trackers(_TRACKERS)
+            return out
+        finally:
+            _TRACKERS = None
+
+    @staticmethod
+    def _forward(ctx, cfg, E, Rc, Ra, info, NL, U11, U21, Wall, L11, L12, L11u, L12u, *lp):
         require_device(E, Rc, Ra, info)
         ctx.set_materialize_grads(False)          # an unused output's gradient arrives as None (whole branches are skipped)
         la, lc, l2 = cfg.layers
@@ -411,7 +437,9 @@ class _EncoderName(torch.autograd.Function):
                     [f2[2]]])
         # ---- node side.  cat buffers: cat0 = [comp0 | info] (:180), cat1 = [c1n | a1] (:192), catA = [align0 | a1 | a2] (:203)
         t.cat0, t.cat1, t.catA = _empty(dev, N, d + di), _empty(dev, N, 2 * d), _empty(dev, N, 3 * d)
-        t.inv0, t.mask0, t.scale0 = _norm_drop_fwd(E, p_drop, training, t.cat0[:, :d])          # :179
+        masks = (torch.empty((2, N, d), dtype=torch.float32, device=dev).bernoulli_(1.0 - p_drop)
+                 if training and p_drop > 0.0 else (None, None))
+        t.inv0, t.mask0, t.scale0 = _norm_drop_fwd(E, p_drop, training, t.cat0[:, :d], masks[0])          # :179
         t.cat0[:, d:].copy_(info)
         align0 = t.catA[:, :d]
         torch.mm(t.cat0, t.w, out=align0)                                                       # :180
@@ -419,7 +447,7 @@ class _EncoderName(torch.autograd.Function):
         t.sa = _layer_fwd(la, align0, t.wc[0], t.cha.RR, a_att[0], graph, training, t.catA[:, d:2 * d], t.cat1[:, d:])   # :183
         c1 = _empty(dev, N, d)
         t.sc = _layer_fwd(lc, E, t.wc[1], t.chc.RR, a_att[1], graph, training, c1)              # :190
-        t.inv1, t.mask1, t.scale1 = _norm_drop_fwd(c1, p_drop, training, t.cat1[:, :d])         # :191
+        t.inv1, t.mask1, t.scale1 = _norm_drop_fwd(c1, p_drop, training, t.cat1[:, :d], masks[1])         # :191
         t.a_in = torch.mm(t.cat1, U21)                                                          # :192
         t.s2 = _layer_fwd(l2, t.a_in, t.wc[2], t.ch2.RR, a_att[2], graph, training, t.catA[:, 2 * d:])               # :197
         align_out = torch.mm(t.catA, Wall)                                                      # :203
