@@ -338,6 +338,38 @@ __global__ __launch_bounds__(kBlock, 4) void grouped_gemm_kernel(const GTable ta
 #undef JMAC_GG
 }
 
+// ---- [Wt | Wb | Wg] of up to four layers in one launch, and its adjoint ---------------------------------------------------
+// w_att = [Wt; Wb] is stacked by rows (src/jmac_model.py:24,75-76), the projection GEMM wants [Wt|Wb|Wg] [d, 3d] side by
+// side.  torch.cat builds it with one launch per layer (and the backward needs a cat + a strided clone per layer to cut
+// d w_att / d gcn_weight out of d[Wt|Wb|Wg]); here all layers of an encoder call go in one launch each way.
+struct WcatArgs {
+    const float* w_att[JMAC_WCAT_MAX];     // [2d, d]
+    const float* gcn[JMAC_WCAT_MAX];       // [d, d]
+    float* wcat[JMAC_WCAT_MAX];            // [d, 3d]
+    float* d_watt[JMAC_WCAT_MAX];          // adjoint outputs
+    float* d_gcn[JMAC_WCAT_MAX];
+    const float* dwcat[JMAC_WCAT_MAX];
+    int n, d;
+};
+template <bool ADJOINT>
+__global__ __launch_bounds__(256) void wcat_kernel(const WcatArgs a) {
+    const int l = blockIdx.y, d = a.d, D4 = d / 4;
+    const int64_t total = (int64_t)d * 3 * D4;                 // float4s of one [d, 3d] matrix
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / (3 * D4)), c4 = (int)(i % (3 * D4));
+        const int part = c4 / D4, c = (c4 % D4) * 4;           // 0: Wt, 1: Wb, 2: Wg
+        if (!ADJOINT) {
+            const float* src = part == 0 ? a.w_att[l] + (int64_t)r * d + c
+                             : part == 1 ? a.w_att[l] + (int64_t)(d + r) * d + c : a.gcn[l] + (int64_t)r * d + c;
+            st4(a.wcat[l] + (int64_t)r * 3 * d + part * d + c, ld4(src));
+        } else {
+            float* dst = part == 0 ? a.d_watt[l] + (int64_t)r * d + c
+                       : part == 1 ? a.d_watt[l] + (int64_t)(d + r) * d + c : a.d_gcn[l] + (int64_t)r * d + c;
+            st4(dst, ld4(a.dwcat[l] + (int64_t)r * 3 * d + part * d + c));
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -402,6 +434,38 @@ int jmac_gemm_grouped_f32(const jmac_gemm_task_t* tasks, int32_t n_tasks, jmac_s
         lds_ok = true;
     }
     hipLaunchKernelGGL(grouped_gemm_kernel, dim3((unsigned)tiles, (unsigned)n), dim3(kBlock), kGroupedLds, (hipStream_t)stream, tab);
+    return (int)hipGetLastError();
+}
+
+int jmac_wcat_pack_f32(const float* const* w_att, const float* const* gcn, float* const* wcat, int32_t n_layers, int64_t d,
+                       jmac_stream_t stream) {
+    if (n_layers <= 0 || n_layers > JMAC_WCAT_MAX || d <= 0 || !w_att || !gcn || !wcat) return JMAC_EINVAL;
+    if (d % 4) return JMAC_EDIM;
+    WcatArgs a{};
+    a.n = n_layers; a.d = (int)d;
+    for (int i = 0; i < n_layers; ++i) {
+        if (!w_att[i] || !gcn[i] || !wcat[i]) return JMAC_EINVAL;
+        a.w_att[i] = w_att[i]; a.gcn[i] = gcn[i]; a.wcat[i] = wcat[i];
+    }
+    const int64_t total = d * 3 * (d / 4);
+    hipLaunchKernelGGL(wcat_kernel<false>, dim3((unsigned)((total + 255) / 256), (unsigned)n_layers), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+int jmac_wcat_unpack_f32(const float* const* dwcat, float* const* d_watt, float* const* d_gcn, int32_t n_layers, int64_t d,
+                         jmac_stream_t stream) {
+    if (n_layers <= 0 || n_layers > JMAC_WCAT_MAX || d <= 0 || !dwcat || !d_watt || !d_gcn) return JMAC_EINVAL;
+    if (d % 4) return JMAC_EDIM;
+    WcatArgs a{};
+    a.n = n_layers; a.d = (int)d;
+    for (int i = 0; i < n_layers; ++i) {
+        if (!dwcat[i] || !d_watt[i] || !d_gcn[i]) return JMAC_EINVAL;
+        a.dwcat[i] = dwcat[i]; a.d_watt[i] = d_watt[i]; a.d_gcn[i] = d_gcn[i];
+    }
+    const int64_t total = d * 3 * (d / 4);
+    hipLaunchKernelGGL(wcat_kernel<true>, dim3((unsigned)((total + 255) / 256), (unsigned)n_layers), dim3(256), 0,
+                       (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -230,9 +230,27 @@ def _layer_inputs(lay):
     return [getattr(lay, n) for n in LAYER_PARAMS] + [lay.bn.weight, lay.bn.bias]
 
 
-def _wcat(w_att, gcn, d):
-    """[Wt | Wb | Wgcn] [d, 3d] (w_att = [Wt; Wb] stacked by rows, src/jmac_model.py:24,75-76)."""
-    return torch.cat((w_att[:d], w_att[d:], gcn), dim=1)
+def _vp_array(tensors):
+    return (C.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+
+
+def _wcat_pack(w_atts, gcns, d):
+    """[Wt | Wb | Wgcn] [d, 3d] of each layer (w_att = [Wt; Wb] stacked by rows, src/jmac_model.py:24,75-76): ONE launch for
+    all layers of the call (torch.cat: one per layer)."""
+    w_atts, gcns = [w.contiguous() for w in w_atts], [g.contiguous() for g in gcns]
+    out = [_empty(w_atts[0].device, d, 3 * d) for _ in w_atts]
+    check(lib().jmac_wcat_pack_f32(_vp_array(w_atts), _vp_array(gcns), _vp_array(out), len(out), d, stream()), "jmac_wcat_pack_f32")
+    return out
+
+
+def _wcat_unpack(dwcs, d):
+    """(d w_att [2d, d], d gcn_weight [d, d]) of each layer cut out of its d[Wt|Wb|Wg] [d, 3d]: one launch for all layers
+    (instead of a cat and a strided clone per layer)."""
+    dev = dwcs[0].device
+    dw = [_empty(dev, 2 * d, d) for _ in dwcs]
+    dg = [_empty(dev, d, d) for _ in dwcs]
+    check(lib().jmac_wcat_unpack_f32(_vp_array(dwcs), _vp_array(dw), _vp_array(dg), len(dwcs), d, stream()), "jmac_wcat_unpack_f32")
+    return list(zip(dw, dg))
 
 
 class _Chain:
@@ -313,11 +331,11 @@ def _layer_bwd(st, graph, gy, gy2, dX, dX_accumulate):
     return dRR, dwc, da, gbw
 
 
-def _layer_grads(chain_grads, dwc, da, gbw, d):
+def _layer_grads(chain_grads, dwatt_dgcn, da, gbw, d):
     """Gradients of one layer's parameters in LAYER_PARAMS + (bn.weight, bn.bias) order."""
     dW1, dW2, dloop = chain_grads
-    d_watt = torch.cat((dwc[:, :d], dwc[:, d:2 * d]), dim=0)          # back to the [2d, d] stacking of w_att
-    return [dW1, dW2, dloop, d_watt, da.view(d, 1), dwc[:, 2 * d:], gbw[d:], gbw[:d]]
+    d_watt, d_gcn = dwatt_dgcn                                        # _wcat_unpack of the layer's d[Wt|Wb|Wg]
+    return [dW1, dW2, dloop, d_watt, da.view(d, 1), d_gcn, gbw[d:], gbw[:d]]
 
 
 def supported(model, info_dim: Optional[int]) -> bool:
@@ -344,7 +362,7 @@ class _LayerNode(torch.autograd.Function):
         (lay,) = cfg.layers
         N, d = X.shape
         t = SimpleNamespace()
-        t.wc = _wcat(pl[3], pl[5], d)
+        (t.wc,) = _wcat_pack([pl[3]], [pl[5]], d)
         t.ch = _Chain(lay, R, pl[0], pl[1], pl[2], t.wc, d)
         run_levels([[f] for f in t.ch.fwd_tasks()])
         y = _empty(X.device, N, d)
@@ -370,7 +388,7 @@ class _LayerNode(torch.autograd.Function):
         dR = _empty(dev, *t.ch.R.shape)
         lv, cg = t.ch.bwd_tasks(dRR, dwc, dR, False)
         run_levels(lv)
-        return (None, dX, dR, *_layer_grads(cg, dwc, da, gbw, d))
+        return (None, dX, dR, *_layer_grads(cg, _wcat_unpack([dwc], d)[0], da, gbw, d))
 
 
 def layer_supported(lay, X, R) -> bool:
@@ -419,7 +437,7 @@ class _EncoderName(torch.autograd.Function):
         di = info.shape[1]
         t = SimpleNamespace()
         # weights: [Wt|Wb|Wg] per layer
-        t.wc = [_wcat(p[3], p[5], d) for p in (pa, pc, p2)]
+        t.wc = _wcat_pack([p[3] for p in (pa, pc, p2)], [p[5] for p in (pa, pc, p2)], d)
         # ---- relation side: five dependency levels, one launch each
         t.cha = _Chain(la, Ra, pa[0], pa[1], pa[2], t.wc[0], d)
         t.chc = _Chain(lc, Rc, pc[0], pc[1], pc[2], t.wc[1], d)
@@ -540,11 +558,13 @@ class _EncoderName(torch.autograd.Function):
             run_levels(levels, balance=True)
             dRa = dRa_buf if wrote_a else None
             dRc = dRc_buf if wrote_c else None
+        dwcs = ([dwca, dwc2] if have_align else []) + ([dwcc] if have_c else [])
+        cut = _wcat_unpack(dwcs, d) if dwcs else []
         if have_align:
-            ga = _layer_grads(cga, dwca, daa, gbwa, d)
-            g2 = _layer_grads(cg2, dwc2, da2, gbw2, d)
+            ga = _layer_grads(cga, cut[0], daa, gbwa, d)
+            g2 = _layer_grads(cg2, cut[1], da2, gbw2, d)
         if have_c:
-            gc = _layer_grads(cgc, dwcc, dac, gbwc, d)
+            gc = _layer_grads(cgc, cut[-1], dac, gbwc, d)
         return (None, dE, dRc, dRa, None, dNL, dU11, dU21, dWall, gL11, gL12, gL11u, gL12u, *ga, *gc, *g2)
 
 
@@ -561,7 +581,7 @@ class _EncoderNoName(torch.autograd.Function):
         (lc,) = cfg.layers
         N, d = E.shape
         t = SimpleNamespace()
-        t.wc = _wcat(pc[3], pc[5], d)
+        (t.wc,) = _wcat_pack([pc[3]], [pc[5]], d)
         t.chc = _Chain(lc, Rc, pc[0], pc[1], pc[2], t.wc, d)
         t.mlc = _RelMLP(Rc, L11, L12, cfg.mlp_slope)
         fc, mc = t.chc.fwd_tasks(), t.mlc.fwd_tasks()
@@ -604,7 +624,7 @@ class _EncoderNoName(torch.autograd.Function):
             wrote = True
         run_levels(levels)
         if g_c1 is not None:
-            gc = _layer_grads(cgc, dwcc, dac, gbwc, d)
+            gc = _layer_grads(cgc, _wcat_unpack([dwcc], d)[0], dac, gbwc, d)
         dRc = dRc_buf if wrote else None
         return (None, dE, dRc, gL11, gL12, *gc)
 
