@@ -70,6 +70,7 @@ class _PairCosine(torch.autograd.Function):
     @staticmethod
     def forward(ctx, e1, e2, i1, i2):
         require_device(e1, e2, i1, i2)
+        ctx.same_table = e1 is e2                     # pairs inside one table (the caller passed the same tensor twice)
         e1, e2 = _rows(e1), _rows(e2)
         L, d = i1.numel(), e1.shape[1]
         if e2.shape[1] != d or i2.numel() != L:
@@ -86,10 +87,13 @@ class _PairCosine(torch.autograd.Function):
         L, d = i1.numel(), e1.shape[1]
         g = g.contiguous()
         de1 = torch.zeros((e1.shape[0], d), dtype=torch.float32, device=e1.device)
-        de2 = torch.zeros((e2.shape[0], d), dtype=torch.float32, device=e1.device)
+        # both sides gathered from ONE table (pairs inside a KG): the kernel's atomics accumulate both sides' rows into one
+        # gradient buffer -- no second zero-fill, no add of the two halves afterwards
+        same = ctx.same_table and e1.data_ptr() == e2.data_ptr()
+        de2 = de1 if same else torch.zeros((e2.shape[0], d), dtype=torch.float32, device=e1.device)
         check(lib().jmac_pair_cosine_bwd_f32(ptr(e1), e1.stride(0), ptr(e2), e2.stride(0), ptr(i1), ptr(i2), L, d, ptr(g),
                                              ptr(de1), d, ptr(de2), d, stream()), "jmac_pair_cosine_bwd_f32")
-        return de1, de2, None, None
+        return de1, (None if same else de2), None, None
 
 
 def pair_cosine_distance(e1: torch.Tensor, i1: torch.Tensor, e2: torch.Tensor, i2: torch.Tensor) -> torch.Tensor:
