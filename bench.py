@@ -638,7 +638,7 @@ def sim_bench(device, iters=10, cpu=True):
     res = {"workload": "config 5 shape: N=30000 d=300; quality GEMM 12000x12000, get_neg 3000x30000 k=25, CSLS test 10500^2",
            "sim_gemm_ms": gemm_ms, "sim_gemm_tflops": tf, "mfma_frac_of_f32_peak": tf / MFMA_F32_PEAK_TFLOPS,
            "mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS, "mfma_util_pmc_percent": pmc_mfma_util(),
-           "mfma_util_source": "profiles/r1_pmc_simgemm.json (committed rocprofv3 --pmc pass; not collected by this run)",
+           "mfma_util_source": "profiles/r3_pmc_mfma.json (committed rocprofv3 --pmc pass, tools/pmc_mfma_r3.sh; not collected by this run)",
            "get_neg_ms": neg_ms, "get_neg_pairs_per_s": 3000 * 30000 / (neg_ms * 1e-3),
            "alignment_test_ms": test_ms, "align_entropy_12000sq_ms": ent_ms}
     if cpu:
@@ -683,6 +683,22 @@ def union_bench(a, device, cpu=True):
         enc = lambda: m.forward_base(ei_t, et_t, [0, n], [0, nr])
         enc_ms = _median_ms(enc, n=10, warm=3)
         cached = enc()
+        enc_graph_ms = None
+        try:                                               # the same forward as one hipGraph (inference: nothing changes between calls)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                enc()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                enc()
+            torch.cuda.synchronize()
+            enc_graph_ms = _median_ms(gr.replay, n=10, warm=3)
+        except Exception as ex:                            # pragma: no cover
+            sys.stderr.write("union encoder: hipGraph capture failed (%s)\n" % (ex,))
+            torch.cuda.synchronize()
         rank_fn = lambda: scoring.linkpred_ranks(cached[1], cached[2], hb_d, rb_d, gold, fptr, fidx, table_dtype=torch.bfloat16)
         for _ in range(3):
             rank_fn()
@@ -715,6 +731,8 @@ def union_bench(a, device, cpu=True):
     res = {"workload": "config 3: union of the five DBP-5L-shaped KGs, N=%d E=%d nr=%d d=%d, bf16 tables; scoring B=%d x N x 2 layers"
                        % (n, E, nr, d, B),
            "encoder_fwd_ms": enc_ms, "encoder_fwd_edges_per_s": 3 * E / (enc_ms * 1e-3),
+           "encoder_fwd_hipgraph_ms": enc_graph_ms,
+           "encoder_fwd_hipgraph_edges_per_s": (3 * E / (enc_graph_ms * 1e-3)) if enc_graph_ms else None,
            "encoder": "JMAC.forward_base, eval mode, three RelationAwareLayer calls on bf16 tables (wall time, eager)",
            "scored_triples_per_s": B / (rank_ms * 1e-3), "pair_scores_per_s": B * n * 2 / (rank_ms * 1e-3), "rank_ms_per_batch": rank_ms,
            "scoring": "jmac_linkpred_rank_bf16: query rows + gold distances + filter correction + L1 tiles with a "
@@ -871,9 +889,9 @@ def pmc_traffic(key, kernel_prefix, rounds=("r3", "r2")):
 
 
 def pmc_mfma_util():
-    """rocprofv3's MfmaUtil for sim_gemm_kernel from the committed PMC pass (profiles/r1_pmc_simgemm.json), or None."""
+    """rocprofv3's MfmaUtil for sim_gemm_kernel from the committed PMC pass (profiles/r3_pmc_mfma.json), or None."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_simgemm.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_mfma.json")))
         return d["kernels"]["sim_gemm_kernel"]["MfmaUtil_percent_mean"]
     except (OSError, KeyError, ValueError):
         return None
