@@ -217,6 +217,9 @@ class JaWorkload:
         self.r = torch.from_numpy(np.tile(br, K + 1)).to(device)
         self.t = torch.from_numpy(np.concatenate([bt, rng.integers(0, n, B * K)])).to(device)
         self.pairs = torch.from_numpy(rng.integers(0, n, (2264, 2))).to(device)
+        # the link columns as the training loop hands them over: two contiguous index vectors, made once per batch
+        # (a fresh pairs[:, 0] view every step costs a copy, a range check and a host sync each)
+        self.pair_cols = (self.pairs[:, 0].contiguous(), self.pairs[:, 1].contiguous())
         self.state_cpu = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
         self.name_emb = torch.from_numpy(name_emb)
         self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True, capturable=True)
@@ -249,7 +252,8 @@ class JaWorkload:
             pos = score[:B].view(-1, B).permute(1, 0)
             neg = score[B:].view(-1, B).permute(1, 0)
             loss = loss + torch.max(pos - neg, -margin).mean() + margin
-        return loss + cos(align_out, pairs[:, 0], align_out, pairs[:, 1]).mean()          # :271-273
+        p0, p1 = self.pair_cols if pairs is self.pairs else (pairs[:, 0], pairs[:, 1])
+        return loss + cos(align_out, p0, align_out, p1).mean()                           # :271-273
 
     def forward_loss(self):
         """(loss, align_out, comp_layers, rel_layers) of one pass of the hot path (no backward, no update)."""

@@ -137,12 +137,13 @@ def test_fused_encoder_on_a_slice_of_the_tables():
     assert float(ge[:e0].abs().max()) == 0.0 and float(ge[e1:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("shape", [(203, 76, 50), (451, 172, 100)], ids=["203x76x50", "451x172x100"])
 @pytest.mark.parametrize("seed", [0, 1])
-def test_grouped_gemm_forms_and_epilogues(seed):
+def test_grouped_gemm_forms_and_epilogues(seed, shape):
     from jmac_amd.encoder import (ACT_LEAKY, ACT_RELU, DACT_LEAKY, DACT_RELU, gemm_task, grouped_gemm)
     gen = torch.Generator(device=DEV).manual_seed(seed)
     r = lambda *s: torch.randn(s, device=DEV, generator=gen)
-    M, K, N = 203, 76, 50
+    M, K, N = shape
     A, A2, B, Bt, At = r(M - 1, K), r(1, K), r(K, N), r(N, K), r(K, M)
     big = r(M, 3 * N)                                             # strided operands / outputs
     src = r(M, N)

@@ -9,7 +9,8 @@ from util import assert_close
 
 
 @pytest.mark.parametrize("M,N,K", [(962, 300, 300), (962, 600, 300), (300, 300, 962), (300, 600, 962), (33, 65, 7),
-                                   (1, 1, 1), (64, 32, 8), (100, 47, 301), (4806, 300, 300)])
+                                   (1, 1, 1), (64, 32, 8), (100, 47, 301), (4806, 300, 300),
+                                   (962, 300, 600), (300, 962, 84), (257, 66, 12), (260, 68, 5)])
 def test_small_mm_forms(M, N, K):
     from jmac_amd import ops
     gen = torch.Generator().manual_seed(M + N + K)
