@@ -254,35 +254,41 @@ def _wcat_unpack(dwcs, d):
 
 
 class _Chain:
-    """The relation side of one layer: R'' = act(cat(R, loop) W1) W2 (src/jmac_model.py:39-42), RR = R'' [Wb|Wg]."""
+    """The relation side of one layer: RR = R'' [Wb|Wg] with R'' = act(cat(R, loop) W1) W2 (src/jmac_model.py:39-42).
+
+    R'' is used by nothing but that projection (the message is x_j - R''[type], and both of its consumers are linear:
+    src/jmac_model.py:60-66,75-88), so the two weight matrices are multiplied first: W2g = W2 [Wb|Wg] (a [d,d] x [d,2d]
+    product, no relation rows in it) and RR = act(.) W2g.  One dependency level and ~10 % of the relation-side flops less
+    each way than R'' = T W2, RR = R'' [Wb|Wg]; the rounding differs from that order in the last bits only."""
 
     def __init__(self, lay, R, W1, W2, loop, wc, d):
         dev, nr = R.device, R.shape[0]
         self.R, self.W1, self.W2, self.loop, self.wc, self.d, self.nr = R, W1, W2, loop, wc, d, nr
         self.relu = lay.rel_activation == "relu"
         self.slope = float(lay.atv_mlp.negative_slope)
-        self.T, self.R2, self.RR = _empty(dev, nr + 1, d), _empty(dev, nr + 1, d), _empty(dev, nr + 1, 2 * d)
+        self.T, self.W2g, self.RR = _empty(dev, nr + 1, d), _empty(dev, d, 2 * d), _empty(dev, nr + 1, 2 * d)
 
     def fwd_tasks(self):
-        """three dependent products: one task per level"""
-        return [gemm_task(self.R, self.W1, self.T, A2=self.loop, act=ACT_RELU if self.relu else ACT_LEAKY, slope=self.slope),
-                gemm_task(self.T, self.W2, self.R2),
-                gemm_task(self.R2, self.wc[:, self.d:], self.RR)]
+        """(W2g task, T task, RR task): the first two are independent (same level), the third needs both."""
+        return (gemm_task(self.W2, self.wc[:, self.d:], self.W2g),
+                gemm_task(self.R, self.W1, self.T, A2=self.loop, act=ACT_RELU if self.relu else ACT_LEAKY, slope=self.slope),
+                gemm_task(self.T, self.W2g, self.RR))
 
     def bwd_tasks(self, dRR, dwc, dR, dR_accumulate):
-        """three levels; weight gradients ride along.  dwc[:, d:] accumulates (the node side wrote it first); dR receives
+        """two levels; weight gradients ride along.  dwc[:, d:] accumulates (the node side wrote it first); dR receives
         d R (rows < nr).  Returns (levels, (dW1, dW2, dloop)) -- the gradients are NOT kept on self: a second reference
         makes autograd's AccumulateGrad clone every one of them instead of taking the buffer."""
         dev, d, nr = dRR.device, self.d, self.nr
-        dR2, dT = _empty(dev, nr + 1, d), _empty(dev, nr + 1, d)
+        dT, dW2g = _empty(dev, nr + 1, d), _empty(dev, d, 2 * d)
         dW1, dW2, dloop = _empty(dev, d, d), _empty(dev, d, d), _empty(dev, 1, d)
         dact = DACT_RELU if self.relu else DACT_LEAKY
-        return [[gemm_task(dRR, self.wc[:, d:], dR2, tb=True),
-                 gemm_task(self.R2, dRR, dwc[:, d:], ta=True, accumulate=True, defer=True)],
-                [gemm_task(dR2, self.W2, dT, tb=True, act=dact, act_src=self.T, slope=self.slope),
-                 gemm_task(self.T, dR2, dW2, ta=True, defer=True)],
+        wr = self.wc[:, d:]
+        return [[gemm_task(dRR, self.W2g, dT, tb=True, act=dact, act_src=self.T, slope=self.slope),
+                 gemm_task(self.T, dRR, dW2g, ta=True)],
                 [gemm_task(dT, self.W1, dR, tb=True, C2=dloop, accumulate=dR_accumulate),
-                 gemm_task(self.R, dT, dW1, ta=True, A2=self.loop, defer=True)]], (dW1, dW2, dloop)
+                 gemm_task(self.R, dT, dW1, ta=True, A2=self.loop, defer=True),
+                 gemm_task(dW2g, wr, dW2, tb=True, defer=True),                         # d W2 = d W2g [Wb|Wg]^T
+                 gemm_task(self.W2, dW2g, dwc[:, d:], ta=True, accumulate=True, defer=True)]], (dW1, dW2, dloop)
 
 
 class _RelMLP:
@@ -364,7 +370,8 @@ class _LayerNode(torch.autograd.Function):
         t = SimpleNamespace()
         (t.wc,) = _wcat_pack([pl[3]], [pl[5]], d)
         t.ch = _Chain(lay, R, pl[0], pl[1], pl[2], t.wc, d)
-        run_levels([[f] for f in t.ch.fwd_tasks()])
+        w2g, tt, rr = t.ch.fwd_tasks()
+        run_levels([[w2g, tt], [rr]])
         y = _empty(X.device, N, d)
         t.st = _layer_fwd(lay, X, t.wc, t.ch.RR, pl[4].reshape(-1), cfg.graph, cfg.training, y)
         t.st.y = None                                            # the output reaches the backward through save_for_backward
@@ -438,7 +445,7 @@ class _EncoderName(torch.autograd.Function):
         t = SimpleNamespace()
         # weights: [Wt|Wb|Wg] per layer
         t.wc = _wcat_pack([p[3] for p in (pa, pc, p2)], [p[5] for p in (pa, pc, p2)], d)
-        # ---- relation side: five dependency levels, one launch each
+        # ---- relation side: four dependency levels, one launch each
         t.cha = _Chain(la, Ra, pa[0], pa[1], pa[2], t.wc[0], d)
         t.chc = _Chain(lc, Rc, pc[0], pc[1], pc[2], t.wc[1], d)
         t.mlc = _RelMLP(Rc, L11, L12, mslope)                          # rel_c1      (:195)
@@ -448,10 +455,9 @@ class _EncoderName(torch.autograd.Function):
         t.w = _empty(dev, d + di, d)
         t.w[:d].copy_(U11[:d])
         fa, fc, f2, ma, mc = t.cha.fwd_tasks(), t.chc.fwd_tasks(), t.ch2.fwd_tasks(), t.mla.fwd_tasks(), t.mlc.fwd_tasks()
-        run_levels([[fa[0], fc[0], ma[0], mc[0], gemm_task(NL, U11[d:], t.w[d:])],
-                    [fa[1], fc[1], ma[1], mc[1]],
-                    [fa[2], fc[2], f2[0]],
-                    [f2[1]],
+        run_levels([[fa[0], fa[1], fc[0], fc[1], f2[0], ma[0], mc[0], gemm_task(NL, U11[d:], t.w[d:])],
+                    [fa[2], fc[2], ma[1], mc[1]],
+                    [f2[1]],                                  # conv2_alignment's relations are the MLP's output
                     [f2[2]]])
         # ---- node side.  cat buffers: cat0 = [comp0 | info] (:180), cat1 = [c1n | a1] (:192), catA = [align0 | a1 | a2] (:203)
         t.cat0, t.cat1, t.catA = _empty(dev, N, d + di), _empty(dev, N, 2 * d), _empty(dev, N, 3 * d)
@@ -545,15 +551,16 @@ class _EncoderName(torch.autograd.Function):
             wrote_a = wrote_c = False
             if have_align:
                 d_rain = _empty(dev, *t.mla.out.shape)
-                cg2 = add(0, t.ch2.bwd_tasks(dRR2, dwc2, d_rain, False))          # levels 0-2 -> d rel_a_in
-                cga = add(0, t.cha.bwd_tasks(dRRa, dwca, dRa_buf, False))        # levels 0-2 -> d rel_align (first writer)
+                cg2 = add(0, t.ch2.bwd_tasks(dRR2, dwc2, d_rain, False))          # levels 0-1 -> d rel_a_in
+                cga = add(0, t.cha.bwd_tasks(dRRa, dwca, dRa_buf, False))        # levels 0-1 -> d rel_align (first writer)
                 wrote_a = True
-                gL11u, gL12u = add(3, t.mla.bwd_tasks(d_rain, dRa_buf, True))    # levels 3-4 -> d rel_align +=
+                gL11u, gL12u = add(2, t.mla.bwd_tasks(d_rain, dRa_buf, True))    # levels 2-3 -> d rel_align +=
             if g_relc1 is not None:                                               # rel_c1 = MLP(rel_comp) needs only the loss' gradient:
                 gL11, gL12 = add(0, t.mlc.bwd_tasks(g_relc1.contiguous(), dRc_buf, False))   # levels 0-1 -> d rel_comp (first writer)
                 wrote_c = True
             if have_c:
-                cgc = add(0, t.chc.bwd_tasks(dRRc, dwcc, dRc_buf, wrote_c))      # levels 0-2 -> d rel_comp (+)= at level 2
+                # d rel_comp: the MLP writes it at level 1, the chain adds to it one level later (or writes it at level 1)
+                cgc = add(1 if wrote_c else 0, t.chc.bwd_tasks(dRRc, dwcc, dRc_buf, wrote_c))
                 wrote_c = True
             run_levels(levels, balance=True)
             dRa = dRa_buf if wrote_a else None
@@ -585,7 +592,7 @@ class _EncoderNoName(torch.autograd.Function):
         t.chc = _Chain(lc, Rc, pc[0], pc[1], pc[2], t.wc, d)
         t.mlc = _RelMLP(Rc, L11, L12, cfg.mlp_slope)
         fc, mc = t.chc.fwd_tasks(), t.mlc.fwd_tasks()
-        run_levels([[fc[0], mc[0]], [fc[1], mc[1]], [fc[2]]])
+        run_levels([[fc[0], fc[1], mc[0]], [fc[2], mc[1]]])
         c1 = _empty(E.device, N, d)
         t.sc = _layer_fwd(lc, E, t.wc, t.chc.RR, pc[4].reshape(-1), cfg.graph, cfg.training, c1)
         if CAPTURE is not None:
@@ -620,7 +627,7 @@ class _EncoderNoName(torch.autograd.Function):
         if g_relc1 is not None:
             lv, (gL11, gL12) = t.mlc.bwd_tasks(g_relc1.contiguous(), dRc_buf, wrote)
             for i, l in enumerate(lv):
-                levels[3 + i].extend(l)
+                levels[(2 if wrote else 0) + i].extend(l)
             wrote = True
         run_levels(levels)
         if g_c1 is not None:
