@@ -7,9 +7,10 @@ cat copies, the zero-fills / copies / adds autograd generates for slices and fan
 Here the same function is evaluated by one ``torch.autograd.Function`` with a hand-written backward:
 
 * every product on the relation side -- the layers' two relation transforms and the hoisted R''[Wb|Wg]
-  (src/jmac_model.py:39-42), the two relation MLPs (:195-196), the folded name projection -- goes out in
-  dependency LEVELS through ``jmac_gemm_grouped_f32``: 5 launches forward, 5 backward, activations and their
-  derivatives fused into the products, ``cat(rel_emb, loop_rel)`` read in place from two buffers;
+  (src/jmac_model.py:39-42; evaluated as act(.) (W2 [Wb|Wg]): see ``_Chain``), the two relation MLPs (:195-196),
+  the folded name projection -- goes out in dependency LEVELS through ``jmac_gemm_grouped_f32``: 4 launches forward,
+  4 backward, activations and their derivatives fused into the products, ``cat(rel_emb, loop_rel)`` read in place
+  from two buffers;
 * the operands of the three concatenations (:180, :192, :203) are WRITTEN into their cat buffers by the
   kernels that produce them (normalise+dropout, BatchNorm+tanh with two destinations, the library GEMM
   with a strided output), and their gradients are read from the adjoint buffers in place (BatchNorm's
@@ -17,8 +18,9 @@ Here the same function is evaluated by one ``torch.autograd.Function`` with a ha
 * N-row products stay library GEMMs (torch.mm on hipBLASLt / rocBLAS), with ``out=`` views and
   ``addmm_`` accumulation instead of separate adds; the constant name embeddings get no input gradient.
 
-Same arithmetic as the op-by-op path in ``jmac_amd.model`` (which stays as the second implementation and
-serves every configuration this node does not cover); tests/test_gpu_encoder.py holds the two to each other.
+Same function and the same fp32 arithmetic as the op-by-op path in ``jmac_amd.model`` up to the association of the
+relation chain's products (that path stays as the second implementation and serves every configuration this node does
+not cover); tests/test_gpu_encoder.py holds the two to each other.
 """
 from __future__ import annotations
 
@@ -84,6 +86,8 @@ def balance_levels(levels: List[List[GemmTask]]) -> List[List[GemmTask]]:
     backward are lopsided: the first carries ten products, the last two carry two each.  Order of execution per output is
     unchanged (a task only ever moves later; accumulating tasks keep their single predecessor), so results are too."""
     levels = [list(lv) for lv in levels]
+    while levels and not levels[-1]:                     # an empty trailing level is not a launch to fill
+        levels.pop()
     total = sum(t._cost for lv in levels for t in lv)
     if not total or len(levels) < 2:
         return levels
