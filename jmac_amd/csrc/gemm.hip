@@ -161,7 +161,7 @@ __device__ __forceinline__ float4 panel_frag(const float* __restrict__ lds, int 
 // single-chunk products (every forward product at d <= 304) prefetch all of a wave's LDS fragments instead.
 #ifdef JMAC_GG_TRACE
 // debug builds (tools/gg_trace.py): per-block timestamps of the phases, written behind the output of task 0's C2 pointer
-#define GG_STAMP(i) do { if (threadIdx.x == 0) gg_trace_buf[((int64_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define GG_STAMP(i) do { if (threadIdx.x == 0) { gg_trace_buf[((int64_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 8 + (i)] = __builtin_readcyclecounter(); if ((i) == 0 || (i) == 4) gg_trace_buf[((int64_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 8 + ((i) == 0 ? 5 : 6)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 __device__ unsigned long long* gg_trace_buf;
 #else
 #define GG_STAMP(i)
@@ -289,6 +289,113 @@ __device__ __forceinline__ void grouped_tile(const GTask& t, int tile, float* __
     GG_STAMP(4);
 }
 
+// ---- TN products (the weight gradients: C = A^T B, A [K,M], B [K,N], K = the ~10^3 relation rows) without LDS staging ------
+// In this form BOTH operands are stored with the tile's 32 rows / columns contiguous, which is exactly the fragment layout of
+// v_mfma_f32_32x32x2_f32 (lane (r, h) holds the element of row / column r at k0 + h): a wave's fragment load is two fully
+// used 128-byte segments straight from L2 into the register the MFMA reads.  No panel, no barrier, no chunk passes: wave w
+// walks the k pairs w, w + 8, ... with TN_U pairs of loads in flight, and the eight partial tiles meet in the usual LDS
+// reduction.  (Staged through LDS, a K = 962 tile was four dependent chunk passes, ~15 us per block: the products that held
+// every backward level of the step.)  No alignment requirement: the loads are 4 bytes per lane.
+constexpr int TN_U = 8;
+__device__ __forceinline__ void grouped_tile_tn(const GTask& t, int tile, float* __restrict__ lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = (tile / t.tiles_n) * 32, n0 = (tile % t.tiles_n) * 32;
+    const int M = t.M, N = t.N, K = t.K;
+    const int mc = min(m0 + r, M - 1), nc = min(n0 + r, N - 1);     // clamped: rows / columns past the edge are never stored
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    GG_STAMP(1);
+    // Full batches below the A operand's split run on two incremented row pointers (two VALU adds per load: with the
+    // general row() form -- clamp, split select, 64-bit multiply -- per load the loop was bound by its ADDRESS arithmetic,
+    // ~45 VALU instructions per k pair, and two blocks on a CU took twice as long as one).  The last, partial batch (and the
+    // rows of a second buffer) takes the general form once.
+    const int pairs = (K + 1) >> 1;
+    const int pairs_fast = min(K, t.A.split) >> 1;             // pairs whose two rows both lie in A.p (and below K)
+    const int64_t sa = (int64_t)2 * kWaves * t.A.ld, sb = (int64_t)2 * kWaves * t.B.ld;
+    const float* qa = t.A.p + (int64_t)(2 * wave + h) * t.A.ld + mc;
+    const float* qb = t.B.p + (int64_t)(2 * wave + h) * t.B.ld + nc;
+    int p = wave;
+    // software pipeline over the full batches: batch i + 1's loads are issued before batch i's (dependent) MFMA chain
+    float a[TN_U], b[TN_U];
+    bool have = p + (TN_U - 1) * kWaves < pairs_fast;
+    if (have) {
+#pragma unroll
+        for (int u = 0; u < TN_U; ++u) {
+            a[u] = gld(qa + u * sa);
+            b[u] = gld(qb + u * sb);
+        }
+        qa += TN_U * sa;
+        qb += TN_U * sb;
+        p += TN_U * kWaves;
+    }
+    while (have) {
+        float an[TN_U], bn[TN_U];
+        const bool more = p + (TN_U - 1) * kWaves < pairs_fast;            // wave-uniform
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < TN_U; ++u) {
+                an[u] = gld(qa + u * sa);
+                bn[u] = gld(qb + u * sb);
+            }
+            qa += TN_U * sa;
+            qb += TN_U * sb;
+            p += TN_U * kWaves;
+        }
+#pragma unroll
+        for (int u = 0; u < TN_U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < TN_U; ++u) {
+                a[u] = an[u];
+                b[u] = bn[u];
+            }
+        }
+        have = more;
+    }
+    if (p < pairs) {                                           // wave-uniform
+        float a[TN_U], b[TN_U];                                // (the pipeline's registers are dead here)
+#pragma unroll
+        for (int u = 0; u < TN_U; ++u) {
+            const int pu = p + u * kWaves, k = 2 * pu + h, kc = min(k, K - 1);
+            a[u] = gld(t.A.row(kc) + mc);
+            b[u] = gld(t.B.row(kc) + nc);
+            if (pu >= pairs || k >= K) a[u] = 0.f;             // past the end / odd K: the pair contributes nothing
+        }
+#pragma unroll
+        for (int u = 0; u < TN_U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    GG_STAMP(2);
+    GG_STAMP(3);
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(lds);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    const int n = n0 + r;
+    constexpr int kRegs = 16 / kWaves;
+#pragma unroll
+    for (int j = 0; j < kRegs; ++j) {
+        const int i = kRegs * wave + j;
+        float sum = red[0][i][lane];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) sum += red[w][i][lane];
+        const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h, mr = min(m, M - 1);
+        const bool in_c = mr < t.c_split;
+        float* cp = in_c ? t.C + (int64_t)mr * t.ldc + nc : t.C2 + (int64_t)(mr - t.c_split) * t.ldc + nc;
+        float x = sum;
+        if (t.act == JMAC_GEMM_ACT_LEAKY) x = x > 0.f ? x : x * t.slope;
+        else if (t.act == JMAC_GEMM_ACT_RELU) x = x > 0.f ? x : 0.f;
+        else if (t.act == JMAC_GEMM_DACT_LEAKY || t.act == JMAC_GEMM_DACT_RELU) {
+            const float mk = gld(t.mask + (int64_t)mr * t.ldmask + nc);
+            x = mk > 0.f ? x : (t.act == JMAC_GEMM_DACT_LEAKY ? x * t.slope : 0.f);
+        }
+        if (t.accumulate && in_c) x += gld(cp);
+        if (m < M && n < N) gst(cp, x);
+    }
+    GG_STAMP(4);
+}
+
 __global__ __launch_bounds__(kBlock, 4) void grouped_gemm_kernel(const GTable tab) {   // 4 waves per SIMD (two 8-wave blocks per CU)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     GG_STAMP(0);
@@ -316,8 +423,19 @@ __global__ __launch_bounds__(kBlock, 4) void grouped_gemm_kernel(const GTable ta
 #pragma unroll
         for (unsigned i = 0; i < sizeof(GTask) / 4; ++i) dst[i] = (uint32_t)__builtin_amdgcn_readlane((int)w, (int)i);
     }
-    if ((int)blockIdx.x >= t.tile_begin) return;                             // tile_begin holds the task's tile COUNT
-    const int tile = (int)blockIdx.x;
+    // XCD-aware tile order.  Workgroups go to the eight XCDs round-robin by linear id, so block x of a task runs on XCD
+    // (x + const) % 8; each XCD has its own L2.  Tiles that share an operand panel (consecutive tile ids share the A panel of
+    // their row block) are therefore given to ONE XCD: x -> tile (x % 8) * chunk + x / 8, chunk = ceil(tiles / 8).  With the
+    // identity order a panel is fetched by up to eight L2s (a backward level requests ~210 MB of panels for ~15 MB of
+    // operands).  Measured on warm operands it is worth 1 us of a 49 us level: the launches are bound by a block's latency
+    // chain, not by the fabric; kept for the cold operands of the step.
+    const int chunk = (t.tile_begin + 7) >> 3;                               // tile_begin holds the task's tile COUNT
+    const int tile = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+    if ((int)blockIdx.x >= 8 * chunk || tile >= t.tile_begin) return;
+    if (t.ta && !t.tb) {
+        grouped_tile_tn(t, tile, lds);
+        return;
+    }
     // an RC panel (32 tile columns contiguous) takes vector loads only where the whole 32-column tile lies inside the operand
     const int m0t = (tile / t.tiles_n) * 32, n0t = (tile % t.tiles_n) * 32;
     const bool va = (t.vec & 1) != 0 && (!t.ta || m0t + 32 <= t.M), vb = (t.vec & 2) != 0 && (t.tb || n0t + 32 <= t.N);
@@ -331,8 +449,7 @@ __global__ __launch_bounds__(kBlock, 4) void grouped_gemm_kernel(const GTable ta
         else if (vb) grouped_tile<TA, TB, false, true, true>(t, tile, lds);               \
         else grouped_tile<TA, TB, false, false, true>(t, tile, lds);                      \
     } while (0)
-    if (t.ta && t.tb) JMAC_GG(true, true);
-    else if (t.ta) JMAC_GG(true, false);
+    if (t.ta) JMAC_GG(true, true);                       // (TN left above)
     else if (t.tb) JMAC_GG(false, true);
     else JMAC_GG(false, false);
 #undef JMAC_GG
@@ -423,7 +540,8 @@ int jmac_gemm_grouped_f32(const jmac_gemm_task_t* tasks, int32_t n_tasks, jmac_s
         const int64_t nt = (int64_t)((u.M + 31) / 32) * t.tiles_n;
         if (nt >= 65536 * 16) return JMAC_ERANGE;
         t.tile_begin = (int32_t)nt;                    // this launch form: the task's tile count
-        tiles = nt > tiles ? nt : tiles;
+        const int64_t nx = 8 * ((nt + 7) / 8);         // block ids of the XCD-aware order (8 * ceil(tiles / 8))
+        tiles = nx > tiles ? nx : tiles;
     }
     if (tiles == 0) return JMAC_OK;
     static bool lds_ok = false;                       // 77 KB of dynamic LDS per block: above the 64 KB default
