@@ -413,12 +413,16 @@ int jmac_gemm_grouped_f32(const jmac_gemm_task_t* tasks, int32_t n_tasks, jmac_s
 /* [Wt | Wb | Wg] [d, 3d] of up to JMAC_WCAT_MAX layers in one launch (w_att = [Wt; Wb] [2d, d] stacked by rows,
  * src/jmac_model.py:24,75-76; gcn_weight [d, d]) -- the operand of the hoisted node projection X [Wt|Wb|Wg] -- and its adjoint:
  * d w_att [2d, d] and d gcn_weight [d, d] cut out of d[Wt|Wb|Wg].  The pointer arrays are HOST arrays of device pointers
- * (copied into the kernel arguments: capture-safe); all matrices contiguous; d % 4 == 0. */
+ * (copied into the kernel arguments: capture-safe); all matrices contiguous; d % 4 == 0.
+ * extra_src / extra_dst / extra_floats: one more contiguous copy in the same launch (the encoder's U11 block of the folded
+ * name projection, src/jmac_model.py:177,180, and its adjoint), 16-byte aligned, a multiple of 4 floats; 0 floats: none. */
 #define JMAC_WCAT_MAX 4
 int jmac_wcat_pack_f32(const float* const* w_att, const float* const* gcn, float* const* wcat,
-                       int32_t n_layers, int64_t d, jmac_stream_t stream);
+                       int32_t n_layers, int64_t d, const float* extra_src, float* extra_dst,
+                       int64_t extra_floats, jmac_stream_t stream);
 int jmac_wcat_unpack_f32(const float* const* dwcat, float* const* d_watt, float* const* d_gcn,
-                         int32_t n_layers, int64_t d, jmac_stream_t stream);
+                         int32_t n_layers, int64_t d, const float* extra_src, float* extra_dst,
+                         int64_t extra_floats, jmac_stream_t stream);
 
 /* fp32 GEMM on the bf16 matrix cores for the N-row dense products of the encoder and of the factorised layer
  * (replaces torch.mm at src/jmac_model.py:177-203 and the hoisted X [Wt|Wb|Wg] projection / its adjoint):

@@ -1344,7 +1344,7 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
     a.entry_dst = nullptr;
     a.n_items_max = (int32_t)(by_dst->n_items_max > 0 ? by_dst->n_items_max : 1);
 
-    const int T = 256;
+    [[maybe_unused]] const int T = 256;                            // (atomic test mode only)
     const unsigned gridA = fwd_grid(by_dst->n_items_max);          // small graphs: one wave per item, like the forward
     const bool slope01 = slope >= 0.f && slope <= 1.f;
     // column sum of G for the fused self loop (dRz[loop] -= kappa * sum_i G[i]): per-block partials by extra blocks of

@@ -466,11 +466,19 @@ struct WcatArgs {
     float* d_watt[JMAC_WCAT_MAX];          // adjoint outputs
     float* d_gcn[JMAC_WCAT_MAX];
     const float* dwcat[JMAC_WCAT_MAX];
+    const float* extra_src;                // one more contiguous copy riding along (blockIdx.y == n), or NULL
+    float* extra_dst;
+    int64_t extra_n4;                      // float4s
     int n, d;
 };
 template <bool ADJOINT>
 __global__ __launch_bounds__(256) void wcat_kernel(const WcatArgs a) {
     const int l = blockIdx.y, d = a.d, D4 = d / 4;
+    if (l == a.n) {                                            // the extra copy
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.extra_n4; i += (int64_t)gridDim.x * 256)
+            st4(a.extra_dst + 4 * i, ld4(a.extra_src + 4 * i));
+        return;
+    }
     const int64_t total = (int64_t)d * 3 * D4;                 // float4s of one [d, 3d] matrix
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int r = (int)(i / (3 * D4)), c4 = (int)(i % (3 * D4));
@@ -555,8 +563,14 @@ int jmac_gemm_grouped_f32(const jmac_gemm_task_t* tasks, int32_t n_tasks, jmac_s
     return (int)hipGetLastError();
 }
 
+static int wcat_extra(WcatArgs& a, const float* src, float* dst, int64_t n) {
+    if (n < 0 || (n > 0 && (!src || !dst)) || n % 4 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return JMAC_EINVAL;
+    a.extra_src = n ? src : nullptr; a.extra_dst = dst; a.extra_n4 = n / 4;
+    return JMAC_OK;
+}
+
 int jmac_wcat_pack_f32(const float* const* w_att, const float* const* gcn, float* const* wcat, int32_t n_layers, int64_t d,
-                       jmac_stream_t stream) {
+                       const float* extra_src, float* extra_dst, int64_t extra_floats, jmac_stream_t stream) {
     if (n_layers <= 0 || n_layers > JMAC_WCAT_MAX || d <= 0 || !w_att || !gcn || !wcat) return JMAC_EINVAL;
     if (d % 4) return JMAC_EDIM;
     WcatArgs a{};
@@ -566,13 +580,14 @@ int jmac_wcat_pack_f32(const float* const* w_att, const float* const* gcn, float
         a.w_att[i] = w_att[i]; a.gcn[i] = gcn[i]; a.wcat[i] = wcat[i];
     }
     const int64_t total = d * 3 * (d / 4);
-    hipLaunchKernelGGL(wcat_kernel<false>, dim3((unsigned)((total + 255) / 256), (unsigned)n_layers), dim3(256), 0,
-                       (hipStream_t)stream, a);
+    if (int rc = wcat_extra(a, extra_src, extra_dst, extra_floats)) return rc;
+    hipLaunchKernelGGL(wcat_kernel<false>, dim3((unsigned)((total + 255) / 256), (unsigned)(n_layers + (a.extra_src ? 1 : 0))),
+                       dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 
 int jmac_wcat_unpack_f32(const float* const* dwcat, float* const* d_watt, float* const* d_gcn, int32_t n_layers, int64_t d,
-                         jmac_stream_t stream) {
+                         const float* extra_src, float* extra_dst, int64_t extra_floats, jmac_stream_t stream) {
     if (n_layers <= 0 || n_layers > JMAC_WCAT_MAX || d <= 0 || !dwcat || !d_watt || !d_gcn) return JMAC_EINVAL;
     if (d % 4) return JMAC_EDIM;
     WcatArgs a{};
@@ -582,8 +597,9 @@ int jmac_wcat_unpack_f32(const float* const* dwcat, float* const* d_watt, float*
         a.dwcat[i] = dwcat[i]; a.d_watt[i] = d_watt[i]; a.d_gcn[i] = d_gcn[i];
     }
     const int64_t total = d * 3 * (d / 4);
-    hipLaunchKernelGGL(wcat_kernel<true>, dim3((unsigned)((total + 255) / 256), (unsigned)n_layers), dim3(256), 0,
-                       (hipStream_t)stream, a);
+    if (int rc = wcat_extra(a, extra_src, extra_dst, extra_floats)) return rc;
+    hipLaunchKernelGGL(wcat_kernel<true>, dim3((unsigned)((total + 255) / 256), (unsigned)(n_layers + (a.extra_src ? 1 : 0))),
+                       dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -238,22 +238,34 @@ def _vp_array(tensors):
     return (C.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
 
 
-def _wcat_pack(w_atts, gcns, d):
+def _extra_copy(copy):
+    """(src pointer, dst pointer, floats) of an optional contiguous copy that rides along in a pack launch."""
+    if copy is None:
+        return None, None, 0
+    src, dst = copy
+    if not (src.is_contiguous() and dst.is_contiguous()) or src.numel() != dst.numel() or src.numel() % 4:
+        raise ValueError("ride-along copy: contiguous blocks of equal size, a multiple of 4 floats")
+    return ptr(src), ptr(dst), src.numel()
+
+
+def _wcat_pack(w_atts, gcns, d, copy=None):
     """[Wt | Wb | Wgcn] [d, 3d] of each layer (w_att = [Wt; Wb] stacked by rows, src/jmac_model.py:24,75-76): ONE launch for
-    all layers of the call (torch.cat: one per layer)."""
+    all layers of the call (torch.cat: one per layer).  ``copy`` = (src, dst): one more block copied by the same launch."""
     w_atts, gcns = [w.contiguous() for w in w_atts], [g.contiguous() for g in gcns]
     out = [_empty(w_atts[0].device, d, 3 * d) for _ in w_atts]
-    check(lib().jmac_wcat_pack_f32(_vp_array(w_atts), _vp_array(gcns), _vp_array(out), len(out), d, stream()), "jmac_wcat_pack_f32")
+    check(lib().jmac_wcat_pack_f32(_vp_array(w_atts), _vp_array(gcns), _vp_array(out), len(out), d, *_extra_copy(copy), stream()),
+          "jmac_wcat_pack_f32")
     return out
 
 
-def _wcat_unpack(dwcs, d):
+def _wcat_unpack(dwcs, d, copy=None):
     """(d w_att [2d, d], d gcn_weight [d, d]) of each layer cut out of its d[Wt|Wb|Wg] [d, 3d]: one launch for all layers
     (instead of a cat and a strided clone per layer)."""
     dev = dwcs[0].device
     dw = [_empty(dev, 2 * d, d) for _ in dwcs]
     dg = [_empty(dev, d, d) for _ in dwcs]
-    check(lib().jmac_wcat_unpack_f32(_vp_array(dwcs), _vp_array(dw), _vp_array(dg), len(dwcs), d, stream()), "jmac_wcat_unpack_f32")
+    check(lib().jmac_wcat_unpack_f32(_vp_array(dwcs), _vp_array(dw), _vp_array(dg), len(dwcs), d, *_extra_copy(copy), stream()),
+          "jmac_wcat_unpack_f32")
     return list(zip(dw, dg))
 
 
@@ -447,17 +459,17 @@ class _EncoderName(torch.autograd.Function):
         N, d = E.shape
         di = info.shape[1]
         t = SimpleNamespace()
-        # weights: [Wt|Wb|Wg] per layer
-        t.wc = _wcat_pack([p[3] for p in (pa, pc, p2)], [p[5] for p in (pa, pc, p2)], d)
+        # :177 + :180  cat(comp0, info @ name_linear) @ U11  ==  cat(comp0, info) @ [U11_top ; name_linear @ U11_bottom]
+        t.w = _empty(dev, d + di, d)
+        # weights: [Wt|Wb|Wg] per layer; the U11_top block of t.w is copied by the same launch
+        u11 = U11.contiguous()
+        t.wc = _wcat_pack([p[3] for p in (pa, pc, p2)], [p[5] for p in (pa, pc, p2)], d, copy=(u11[:d], t.w[:d]))
         # ---- relation side: four dependency levels, one launch each
         t.cha = _Chain(la, Ra, pa[0], pa[1], pa[2], t.wc[0], d)
         t.chc = _Chain(lc, Rc, pc[0], pc[1], pc[2], t.wc[1], d)
         t.mlc = _RelMLP(Rc, L11, L12, mslope)                          # rel_c1      (:195)
         t.mla = _RelMLP(Ra, L11u, L12u, mslope)                        # rel_a_in    (:196)
         t.ch2 = _Chain(l2, t.mla.out, p2[0], p2[1], p2[2], t.wc[2], d)
-        # :177 + :180  cat(comp0, info @ name_linear) @ U11  ==  cat(comp0, info) @ [U11_top ; name_linear @ U11_bottom]
-        t.w = _empty(dev, d + di, d)
-        t.w[:d].copy_(U11[:d])
         fa, fc, f2, ma, mc = t.cha.fwd_tasks(), t.chc.fwd_tasks(), t.ch2.fwd_tasks(), t.mla.fwd_tasks(), t.mlc.fwd_tasks()
         run_levels([[fa[0], fa[1], fc[0], fc[1], f2[0], ma[0], mc[0], gemm_task(NL, U11[d:], t.w[d:])],
                     [fa[2], fc[2], ma[1], mc[1]],
@@ -545,8 +557,7 @@ class _EncoderName(torch.autograd.Function):
             d_comp0 = torch.mm(d_align0, t.w[:d].t())
             dw = torch.mm(t.cat0.t(), d_align0)                                  # [d+di, d]
             _norm_drop_bwd(E, t.inv0, t.mask0, t.scale0, d_comp0, dE, True)
-            dU11 = _empty(dev, 2 * d, d)
-            dU11[:d].copy_(dw[:d])
+            dU11 = _empty(dev, 2 * d, d)                                         # [:d] <- dw[:d] by the unpack launch below
             dNL = _empty(dev, di, d)
             levels[0].extend([gemm_task(dw[d:], U11[d:], dNL, tb=True, defer=True), gemm_task(NL, dw[d:], dU11[d:], ta=True, defer=True)])
         # ---- relation side
@@ -570,7 +581,7 @@ class _EncoderName(torch.autograd.Function):
             dRa = dRa_buf if wrote_a else None
             dRc = dRc_buf if wrote_c else None
         dwcs = ([dwca, dwc2] if have_align else []) + ([dwcc] if have_c else [])
-        cut = _wcat_unpack(dwcs, d) if dwcs else []
+        cut = _wcat_unpack(dwcs, d, copy=(dw[:d], dU11[:d]) if have_align else None) if dwcs else []
         if have_align:
             ga = _layer_grads(cga, cut[0], daa, gbwa, d)
             g2 = _layer_grads(cg2, cut[1], da2, gbw2, d)
