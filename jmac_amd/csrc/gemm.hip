@@ -354,7 +354,7 @@ __device__ __forceinline__ void grouped_tile_tn(const GTask& t, int tile, float*
         }
         have = more;
     }
-    if (p < pairs) {                                           // wave-uniform
+    for (; p < pairs; p += TN_U * kWaves) {                    // wave-uniform; one pass unless the split leaves a long tail
         float a[TN_U], b[TN_U];                                // (the pipeline's registers are dead here)
 #pragma unroll
         for (int u = 0; u < TN_U; ++u) {

@@ -329,6 +329,55 @@ class _RelMLP:
                  gemm_task(self.R, dM, dW1, ta=True, defer=True)]], (dW1, dW2)
 
 
+class _MlpChain:
+    """conv2_alignment's relation side: its relation input is the output of a relation MLP that nothing else reads
+    (rel_a_in = leaky(Ra L11u) L12u, src/jmac_model.py:196-197), so  cat(rel_a_in, loop) W1  is evaluated as
+    cat(M (L12u W1), loop W1)  with M = leaky(Ra L11u): the [d,d] x [d,d] weight product replaces one nr-row product each way
+    and the MLP's second level disappears from the dependency chain (3 levels instead of 4, forward and backward).
+    RR = act(.) (W2 [Wb|Wg]) as in ``_Chain``."""
+
+    def __init__(self, lay, Ra, L11u, L12u, mlp_slope, W1, W2, loop, wc, d):
+        dev, nr = Ra.device, Ra.shape[0]
+        self.Ra, self.L11u, self.L12u, self.W1, self.W2, self.loop, self.wc, self.d, self.nr = Ra, L11u, L12u, W1, W2, loop, wc, d, nr
+        self.mlp_slope = float(mlp_slope)
+        self.relu = lay.rel_activation == "relu"
+        self.slope = float(lay.atv_mlp.negative_slope)
+        self.M, self.Wp, self.W2g = _empty(dev, nr, L11u.shape[1]), _empty(dev, L12u.shape[0], d), _empty(dev, d, 2 * d)
+        self.T, self.RR = _empty(dev, nr + 1, d), _empty(dev, nr + 1, 2 * d)
+
+    def rel_in(self):
+        """rel_a_in itself (tests only: the product path never forms it)."""
+        return torch.mm(self.M, self.L12u)
+
+    def fwd_tasks(self):
+        act = ACT_RELU if self.relu else ACT_LEAKY
+        return [[gemm_task(self.Ra, self.L11u, self.M, act=ACT_LEAKY, slope=self.mlp_slope),
+                 gemm_task(self.L12u, self.W1, self.Wp), gemm_task(self.W2, self.wc[:, self.d:], self.W2g)],
+                [gemm_task(self.M, self.Wp, self.T[:self.nr], act=act, slope=self.slope),
+                 gemm_task(self.loop, self.W1, self.T[self.nr:], act=act, slope=self.slope)],
+                [gemm_task(self.T, self.W2g, self.RR)]]
+
+    def bwd_tasks(self, dRR, dwc, dRa, dRa_accumulate):
+        """three levels -> (levels, (dW1, dW2, dloop), (dL11u, dL12u))"""
+        dev, d, nr = dRR.device, self.d, self.nr
+        dT, dW2g, dM, dWp = _empty(dev, nr + 1, d), _empty(dev, d, 2 * d), _empty(dev, *self.M.shape), _empty(dev, *self.Wp.shape)
+        dW1, dW2, dloop = _empty(dev, d, d), _empty(dev, d, d), _empty(dev, 1, d)
+        dL11u, dL12u = _empty(dev, *self.L11u.shape), _empty(dev, *self.L12u.shape)
+        dact = DACT_RELU if self.relu else DACT_LEAKY
+        return [[gemm_task(dRR, self.W2g, dT, tb=True, act=dact, act_src=self.T, slope=self.slope),
+                 gemm_task(self.T, dRR, dW2g, ta=True)],
+                [gemm_task(dT[:nr], self.Wp, dM, tb=True, act=DACT_LEAKY, act_src=self.M, slope=self.mlp_slope),
+                 gemm_task(self.M, dT[:nr], dWp, ta=True),
+                 gemm_task(dT[nr:], self.W1, dloop, tb=True),
+                 gemm_task(self.loop, dT[nr:], dW1, ta=True),                          # the loop row's share of d W1 (K = 1)
+                 gemm_task(dW2g, self.wc[:, d:], dW2, tb=True, defer=True),
+                 gemm_task(self.W2, dW2g, dwc[:, d:], ta=True, accumulate=True, defer=True)],
+                [gemm_task(dM, self.L11u, dRa, tb=True, accumulate=dRa_accumulate),
+                 gemm_task(self.Ra, dM, dL11u, ta=True),
+                 gemm_task(dWp, self.W1, dL12u, tb=True),
+                 gemm_task(self.L12u, dWp, dW1, ta=True, accumulate=True)]], (dW1, dW2, dloop), (dL11u, dL12u)
+
+
 def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None):
     """Node side of one RelationAwareLayer (src/jmac_model.py:44-52) given its relation tables: state for the backward."""
     PQZ = torch.mm(X, wc)                                             # [P|Q|Z]: one library GEMM
@@ -464,17 +513,15 @@ class _EncoderName(torch.autograd.Function):
         # weights: [Wt|Wb|Wg] per layer; the U11_top block of t.w is copied by the same launch
         u11 = U11.contiguous()
         t.wc = _wcat_pack([p[3] for p in (pa, pc, p2)], [p[5] for p in (pa, pc, p2)], d, copy=(u11[:d], t.w[:d]))
-        # ---- relation side: four dependency levels, one launch each
+        # ---- relation side: three dependency levels, one launch each
         t.cha = _Chain(la, Ra, pa[0], pa[1], pa[2], t.wc[0], d)
         t.chc = _Chain(lc, Rc, pc[0], pc[1], pc[2], t.wc[1], d)
         t.mlc = _RelMLP(Rc, L11, L12, mslope)                          # rel_c1      (:195)
-        t.mla = _RelMLP(Ra, L11u, L12u, mslope)                        # rel_a_in    (:196)
-        t.ch2 = _Chain(l2, t.mla.out, p2[0], p2[1], p2[2], t.wc[2], d)
-        fa, fc, f2, ma, mc = t.cha.fwd_tasks(), t.chc.fwd_tasks(), t.ch2.fwd_tasks(), t.mla.fwd_tasks(), t.mlc.fwd_tasks()
-        run_levels([[fa[0], fa[1], fc[0], fc[1], f2[0], ma[0], mc[0], gemm_task(NL, U11[d:], t.w[d:])],
-                    [fa[2], fc[2], ma[1], mc[1]],
-                    [f2[1]],                                  # conv2_alignment's relations are the MLP's output
-                    [f2[2]]])
+        t.ch2 = _MlpChain(l2, Ra, L11u, L12u, mslope, p2[0], p2[1], p2[2], t.wc[2], d)   # rel_a_in (:196) + conv2's chain
+        fa, fc, f2, mc = t.cha.fwd_tasks(), t.chc.fwd_tasks(), t.ch2.fwd_tasks(), t.mlc.fwd_tasks()
+        run_levels([[fa[0], fa[1], fc[0], fc[1], *f2[0], mc[0], gemm_task(NL, U11[d:], t.w[d:])],
+                    [fa[2], fc[2], *f2[1], mc[1]],
+                    f2[2]])
         # ---- node side.  cat buffers: cat0 = [comp0 | info] (:180), cat1 = [c1n | a1] (:192), catA = [align0 | a1 | a2] (:203)
         t.cat0, t.cat1, t.catA = _empty(dev, N, d + di), _empty(dev, N, 2 * d), _empty(dev, N, 3 * d)
         masks = (torch.empty((2, N, d), dtype=torch.float32, device=dev).bernoulli_(1.0 - p_drop)
@@ -493,9 +540,11 @@ class _EncoderName(torch.autograd.Function):
         align_out = torch.mm(t.catA, Wall)                                                      # :203
         if CAPTURE is not None:
             CAPTURE.update(conv1_alignment=(align0.clone(), Ra.detach()), conv1_completion=(E.detach(), Rc.detach()),
-                           conv2_alignment=(t.a_in.clone(), t.mla.out.clone()))
-            for name, st in (("conv1_alignment", t.sa), ("conv1_completion", t.sc), ("conv2_alignment", t.s2)):
+                           conv2_alignment=(t.a_in.clone(), t.ch2.rel_in()))
+            for name, st, ch in (("conv1_alignment", t.sa, t.cha), ("conv1_completion", t.sc, t.chc), ("conv2_alignment", t.s2, t.ch2)):
                 CAPTURE[name + ".tables"] = (st.PQZ, st.RR)              # the very tables the aggregation kernel gathered
+                CAPTURE[name + ".rel_act"] = ch.T                        # the relation transform's activation (its sign = the kink side)
+            CAPTURE["rel_linear11.act"], CAPTURE["rel_linear11_uni.act"] = t.mlc.M, t.ch2.M
         # c1 and rel_c1 are OUTPUTS: they reach the backward through save_for_backward / not at all (an attribute on ctx
         # would tie the output to its own grad_fn in a reference cycle)
         rel_c1, t.mlc.out, t.sc.y = t.mlc.out, None, None
@@ -565,11 +614,10 @@ class _EncoderName(torch.autograd.Function):
             dRa_buf, dRc_buf = _empty(dev, *Ra.shape), _empty(dev, *Rc.shape)
             wrote_a = wrote_c = False
             if have_align:
-                d_rain = _empty(dev, *t.mla.out.shape)
-                cg2 = add(0, t.ch2.bwd_tasks(dRR2, dwc2, d_rain, False))          # levels 0-1 -> d rel_a_in
                 cga = add(0, t.cha.bwd_tasks(dRRa, dwca, dRa_buf, False))        # levels 0-1 -> d rel_align (first writer)
                 wrote_a = True
-                gL11u, gL12u = add(2, t.mla.bwd_tasks(d_rain, dRa_buf, True))    # levels 2-3 -> d rel_align +=
+                lv2, cg2, (gL11u, gL12u) = t.ch2.bwd_tasks(dRR2, dwc2, dRa_buf, True)   # levels 0-2; d rel_align += at level 2
+                add(0, (lv2, None))
             if g_relc1 is not None:                                               # rel_c1 = MLP(rel_comp) needs only the loss' gradient:
                 gL11, gL12 = add(0, t.mlc.bwd_tasks(g_relc1.contiguous(), dRc_buf, False))   # levels 0-1 -> d rel_comp (first writer)
                 wrote_c = True

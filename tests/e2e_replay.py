@@ -29,13 +29,16 @@ def metrics(ranks):
     return np.array([(ranks <= 1).mean(), (ranks <= 10).mean(), (1.0 / ranks).mean()])
 
 
-def check_outcome(g, losses, ranks_ckpt, ranks_after, what):
+def check_outcome(g, losses, ranks_ckpt, ranks_after, what, decided_gap=1e-4):
     """Shared acceptance of a replay.
 
     * losses: equal to the reference's at 1e-4 up to the checkpoint (no optimiser drift has accumulated yet), within 2 %
       of the loss scale over the whole run;
-    * checkpoint (30 steps): every rank whose gold tail is separated from its nearest competitor by more than 1e-4 in the
-      reference's own distances must be IDENTICAL, hence identical Hits@1 / Hits@10 / MRR up to the undecided handful;
+    * checkpoint (30 steps): every rank whose gold tail is separated from its nearest competitor by more than ``decided_gap``
+      in the reference's own distances must be IDENTICAL, hence identical Hits@1 / Hits@10 / MRR up to the undecided handful
+      (1e-4 for the deterministic CPU oracle: 4 of 1 156 undecided; the HIP replay passes 5e-4, 19 undecided -- its loss-gather
+      backward sums with float atomics, so gradients differ at rounding level from run to run, and 30 Adam steps carry that
+      into the distances: with 1e-4 one rank in ~10^3 moved by one place in one run out of four);
     * end of the run (120 steps): Adam normalises every gradient by its running magnitude, so rounding-level differences in
       small gradients grow into visible parameter differences over a hundred steps (measured: the fp32 oracle ends 31 %
       rank-identical to the fp32 reference, the float64 oracle 99.7 %, all three at the same metrics) -- the end state is
@@ -48,7 +51,7 @@ def check_outcome(g, losses, ranks_ckpt, ranks_after, what):
     assert np.abs(losses - ref_l).max() <= 2e-2 * np.abs(ref_l).max(), (what, np.abs(losses - ref_l).max())
     # ---- checkpoint
     rk, ref = np.asarray(ranks_ckpt), g["ranks_ckpt"]
-    decided = g["rank_gap_ckpt"] > 1e-4
+    decided = g["rank_gap_ckpt"] > decided_gap
     assert decided.mean() > 0.98
     assert (rk == ref)[decided].all(), (what, int((rk != ref)[decided].sum()), np.abs(rk - ref).max())
     n = len(ref)

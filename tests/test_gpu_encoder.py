@@ -191,6 +191,20 @@ def test_grouped_gemm_forms_and_epilogues(seed, shape):
     assert torch.equal(again, outs["nn"])
 
 
+def test_grouped_gemm_transposed_a_in_two_buffers_any_split():
+    """C = cat(A, A2)^T B with the split anywhere in K (the weight-gradient form reads A's rows straight from memory: rows
+    past the split come from the second buffer through its general path), odd K, ragged tiles."""
+    from jmac_amd.encoder import gemm_task, grouped_gemm
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    K, M, N = 401, 70, 45
+    A, B = torch.randn(K, M, device=DEV, generator=gen), torch.randn(K, N, device=DEV, generator=gen)
+    ref = A.double().t() @ B.double()
+    for split in (1, 7, 200, 399, 400):
+        out = torch.full((M, N), float("nan"), device=DEV)
+        grouped_gemm([gemm_task(A[:split].contiguous(), B, out, ta=True, A2=A[split:].contiguous())])
+        assert_close(out, ref, 1e-5, 1e-5, "split %d" % split)
+
+
 def test_grouped_gemm_many_tasks_and_odd_shapes():
     from jmac_amd.encoder import gemm_task, grouped_gemm
     gen = torch.Generator(device=DEV).manual_seed(7)

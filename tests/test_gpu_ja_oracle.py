@@ -51,10 +51,15 @@ def _gpu_kink_masks(w, captured):
             h = PQZ[ei[0], :d] + (PQZ[ei[1], dp:dp + d] - RR[et, :d])
             masks[name] = (h > 0).cpu()
             # the relation side's own LeakyReLUs: between the two relation transforms of the layer (src/jmac_model.py:41) ...
-            masks[name + ".rel"] = (torch.mm(torch.cat([r, lay.loop_rel], 0), lay.rel_transform_weight1) > 0).cpu()
+            # (the fused node reports the activation it computed: LeakyReLU / ReLU keep the sign of their argument)
+            if name + ".rel_act" in captured:
+                masks[name + ".rel"] = (captured[name + ".rel_act"] > 0).cpu()
+            else:
+                masks[name + ".rel"] = (torch.mm(torch.cat([r, lay.loop_rel], 0), lay.rel_transform_weight1) > 0).cpu()
         m = w.model                               # ... and inside the two relation MLPs (src/jmac_model.py:195-196)
-        masks["rel_linear11"] = (torch.mm(m.rel_init_att_completion, m.rel_linear11) > 0).cpu()
-        masks["rel_linear11_uni"] = (torch.mm(m.rel_init_att_alignment, m.rel_linear11_uni) > 0).cpu()
+        for key, table, weight in (("rel_linear11", m.rel_init_att_completion, m.rel_linear11),
+                                   ("rel_linear11_uni", m.rel_init_att_alignment, m.rel_linear11_uni)):
+            masks[key] = ((captured[key + ".act"] if key + ".act" in captured else torch.mm(table, weight)) > 0).cpu()
     return masks
 
 
