@@ -258,6 +258,19 @@ int jmac_row_normalize_drop_bwd_f32(const float* x, int64_t ldx, const float* in
                                     int64_t d, float eps, float* gx, int64_t ldgx, int32_t accumulate,
                                     jmac_stream_t stream);
 
+/* The same with the Bernoulli draws made INSIDE the kernels (torch's F.dropout draws them with its own Philox stream: the
+ * draws are equally i.i.d. Bernoulli(1 - p_drop) but not the same bits).  seed: ONE device-resident int64 the caller fills from
+ * its generator (a device value, so that a captured step draws a fresh mask on every replay); element (r, c) is kept iff word
+ * c % 4 of Philox4x32-10(key = seed, counter = r * d/4 + c/4) < (1 - p_drop) * 2^32, kept elements are scaled by 1/(1 - p_drop).
+ * The backward regenerates the draws from the same seed: no mask tensor exists.  0 <= p_drop < 1. */
+int jmac_row_normalize_dropseed_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, float eps,
+                                        const int64_t* seed, float p_drop, float* y, int64_t ldy,
+                                        float* inv, jmac_stream_t stream);
+int jmac_row_normalize_dropseed_bwd_f32(const float* x, int64_t ldx, const float* inv, const int64_t* seed,
+                                        float p_drop, const float* g, int64_t ldg, int64_t N, int64_t d,
+                                        float eps, float* gx, int64_t ldgx, int32_t accumulate,
+                                        jmac_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Completion scoring (replaces: torch.cdist(er, all_kg_emb, p=1), src/jmac_model.py:312; the
  * filter/sort/np.where ranking loop of src/validate.py:50-64).

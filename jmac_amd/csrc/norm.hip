@@ -335,12 +335,51 @@ __global__ __launch_bounds__(kBlock) void row_normalize_bwd_kernel(const float* 
 // normalised row from x and inv (nothing but inv [N] is kept from the forward):
 //   gn = g * m;  gx (+)= inv * (gn - xn (gn . xn)),  xn = x * inv   (no radial term on rows whose norm was clamped)
 // one wave per row, 16 bytes per lane (d % 4 == 0, leading dimensions % 4 == 0).
+// Dropout draws made in the kernel (SEED form): Philox4x32-10 keyed by the caller's device-resident seed, counter = index of
+// the float4 (row * d/4 + column quad): its four words decide the four elements.  The backward regenerates the same draws, so
+// no mask tensor is written or read (28 MB each way at DBP-5L size, plus the launch that drew it).
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+struct DropSrc {
+    const float* mask;       // {0,1} draws of the caller, or NULL
+    int64_t ldm;
+    const int64_t* seed;     // SEED form: device int64
+    uint32_t keep_thr;       // keep iff word < keep_thr  (keep probability = keep_thr / 2^32)
+    float scale;
+};
+template <bool SEED>
+__device__ __forceinline__ float4 drop_factors(const DropSrc& s, uint2 key, int64_t r, int c, int D4) {
+    if (SEED) {
+        const uint64_t idx = (uint64_t)r * (uint64_t)D4 + (uint64_t)c;
+        const uint4 w = philox4x32_10(make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), 0u, 0u), key);
+        return make_float4(w.x < s.keep_thr ? s.scale : 0.f, w.y < s.keep_thr ? s.scale : 0.f, w.z < s.keep_thr ? s.scale : 0.f,
+                           w.w < s.keep_thr ? s.scale : 0.f);
+    }
+    const float4 m = ld4(s.mask + r * s.ldm + c * 4);
+    return make_float4(m.x * s.scale, m.y * s.scale, m.z * s.scale, m.w * s.scale);
+}
+
+template <bool SEED>
 __global__ __launch_bounds__(kBlock) void row_normalize_drop_fwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t N, int D4,
-                                                                        float eps, const float* __restrict__ mask, int64_t ldm,
-                                                                        float scale, float* __restrict__ y, int64_t ldy,
+                                                                        float eps, DropSrc ds, float* __restrict__ y, int64_t ldy,
                                                                         float* __restrict__ inv) {
     const int lane = lane_id();
     const int64_t w0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+    uint2 key = make_uint2(0u, 0u);
+    if (SEED) {
+        const uint64_t sd = (uint64_t)ds.seed[0];
+        key = make_uint2((uint32_t)sd, (uint32_t)(sd >> 32));
+    }
+    const bool drop = SEED || ds.mask != nullptr;
     for (int64_t r = w0; r < N; r += nw) {
         const float* xr = x + r * ldx;
         float ss = 0.f;
@@ -353,9 +392,9 @@ __global__ __launch_bounds__(kBlock) void row_normalize_drop_fwd_kernel(const fl
         for (int c = lane; c < D4; c += 64) {
             float4 v = ld4(xr + c * 4);
             v.x *= iv; v.y *= iv; v.z *= iv; v.w *= iv;
-            if (mask) {
-                const float4 m = ld4(mask + r * ldm + c * 4);
-                v.x *= m.x * scale; v.y *= m.y * scale; v.z *= m.z * scale; v.w *= m.w * scale;
+            if (drop) {
+                const float4 m = drop_factors<SEED>(ds, key, r, c, D4);
+                v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
             }
             st4(y + r * ldy + c * 4, v);
         }
@@ -363,14 +402,20 @@ __global__ __launch_bounds__(kBlock) void row_normalize_drop_fwd_kernel(const fl
     }
 }
 
+template <bool SEED>
 __global__ __launch_bounds__(kBlock) void row_normalize_drop_bwd_kernel(const float* __restrict__ x, int64_t ldx,
-                                                                        const float* __restrict__ inv,
-                                                                        const float* __restrict__ mask, int64_t ldm, float scale,
+                                                                        const float* __restrict__ inv, DropSrc ds,
                                                                         const float* __restrict__ g, int64_t ldg, int64_t N, int D4,
                                                                         float eps, float* __restrict__ gx, int64_t ldgx,
                                                                         int accumulate) {
     const int lane = lane_id();
     const int64_t w0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+    uint2 key = make_uint2(0u, 0u);
+    if (SEED) {
+        const uint64_t sd = (uint64_t)ds.seed[0];
+        key = make_uint2((uint32_t)sd, (uint32_t)(sd >> 32));
+    }
+    const bool drop = SEED || ds.mask != nullptr;
     for (int64_t r = w0; r < N; r += nw) {
         const float* xr = x + r * ldx;
         const float* gr = g + r * ldg;
@@ -379,9 +424,9 @@ __global__ __launch_bounds__(kBlock) void row_normalize_drop_bwd_kernel(const fl
         for (int c = lane; c < D4; c += 64) {
             const float4 v = ld4(xr + c * 4);
             float4 q = ld4(gr + c * 4);
-            if (mask) {
-                const float4 m = ld4(mask + r * ldm + c * 4);
-                q.x *= m.x * scale; q.y *= m.y * scale; q.z *= m.z * scale; q.w *= m.w * scale;
+            if (drop) {
+                const float4 m = drop_factors<SEED>(ds, key, r, c, D4);
+                q.x *= m.x; q.y *= m.y; q.z *= m.z; q.w *= m.w;
             }
             dot = fmaf(q.x, v.x * iv, fmaf(q.y, v.y * iv, fmaf(q.z, v.z * iv, fmaf(q.w, v.w * iv, dot))));
         }
@@ -390,9 +435,9 @@ __global__ __launch_bounds__(kBlock) void row_normalize_drop_bwd_kernel(const fl
         for (int c = lane; c < D4; c += 64) {
             const float4 v = ld4(xr + c * 4);
             float4 q = ld4(gr + c * 4);
-            if (mask) {
-                const float4 m = ld4(mask + r * ldm + c * 4);
-                q.x *= m.x * scale; q.y *= m.y * scale; q.z *= m.z * scale; q.w *= m.w * scale;
+            if (drop) {
+                const float4 m = drop_factors<SEED>(ds, key, r, c, D4);
+                q.x *= m.x; q.y *= m.y; q.z *= m.z; q.w *= m.w;
             }
             float4 o;
             o.x = iv * (q.x - v.x * iv * dot); o.y = iv * (q.y - v.y * iv * dot);
@@ -511,33 +556,74 @@ int jmac_row_normalize_bwd_f32(const float* y, int64_t ldy, const float* g, int6
     return (int)hipGetLastError();
 }
 
-int jmac_row_normalize_drop_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, float eps, const float* mask, int64_t ldm,
-                                    float scale, float* y, int64_t ldy, float* inv, jmac_stream_t stream) {
+static int drop_fwd(const float* x, int64_t ldx, int64_t N, int64_t d, float eps, const DropSrc& ds, bool seeded, float* y, int64_t ldy,
+                    float* inv, jmac_stream_t stream) {
     if (N < 0 || d <= 0 || d >= INT32_MAX) return JMAC_EINVAL;
-    if (d % 4 || ldx % 4 || ldy % 4 || (mask && ldm % 4)) return JMAC_EDIM;
+    if (d % 4 || ldx % 4 || ldy % 4 || (ds.mask && ds.ldm % 4)) return JMAC_EDIM;
     if (N == 0) return JMAC_OK;
     if (!x || !y || !inv) return JMAC_EINVAL;
-    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)mask) & 15) != 0) return JMAC_EDIM;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)ds.mask) & 15) != 0) return JMAC_EDIM;
     int64_t blocks = (N + kBlock / 64 - 1) / (kBlock / 64);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(row_normalize_drop_fwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, N,
-                       (int)(d / 4), eps, mask, ldm, scale, y, ldy, inv);
+    if (seeded)
+        hipLaunchKernelGGL(row_normalize_drop_fwd_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, N,
+                           (int)(d / 4), eps, ds, y, ldy, inv);
+    else
+        hipLaunchKernelGGL(row_normalize_drop_fwd_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, N,
+                           (int)(d / 4), eps, ds, y, ldy, inv);
     return (int)hipGetLastError();
+}
+
+static int drop_bwd(const float* x, int64_t ldx, const float* inv, const DropSrc& ds, bool seeded, const float* g, int64_t ldg, int64_t N,
+                    int64_t d, float eps, float* gx, int64_t ldgx, int32_t accumulate, jmac_stream_t stream) {
+    if (N < 0 || d <= 0 || d >= INT32_MAX) return JMAC_EINVAL;
+    if (d % 4 || ldx % 4 || ldg % 4 || ldgx % 4 || (ds.mask && ds.ldm % 4)) return JMAC_EDIM;
+    if (N == 0) return JMAC_OK;
+    if (!x || !inv || !g || !gx) return JMAC_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)g | (uintptr_t)gx | (uintptr_t)ds.mask) & 15) != 0) return JMAC_EDIM;
+    int64_t blocks = (N + kBlock / 64 - 1) / (kBlock / 64);
+    if (blocks > 8192) blocks = 8192;
+    if (seeded)
+        hipLaunchKernelGGL(row_normalize_drop_bwd_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, inv,
+                           ds, g, ldg, N, (int)(d / 4), eps, gx, ldgx, accumulate ? 1 : 0);
+    else
+        hipLaunchKernelGGL(row_normalize_drop_bwd_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, inv,
+                           ds, g, ldg, N, (int)(d / 4), eps, gx, ldgx, accumulate ? 1 : 0);
+    return (int)hipGetLastError();
+}
+
+// keep probability 1 - p as a 32-bit threshold; scale = 1 / (1 - p)
+static int seeded_src(const int64_t* seed, float p_drop, DropSrc& ds) {
+    if (!seed || !(p_drop >= 0.f) || !(p_drop < 1.f)) return JMAC_EINVAL;
+    const double keep = 1.0 - (double)p_drop, t = keep * 4294967296.0;
+    ds = DropSrc{nullptr, 0, seed, t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t, (float)(1.0 / keep)};
+    return JMAC_OK;
+}
+
+int jmac_row_normalize_drop_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, float eps, const float* mask, int64_t ldm,
+                                    float scale, float* y, int64_t ldy, float* inv, jmac_stream_t stream) {
+    return drop_fwd(x, ldx, N, d, eps, DropSrc{mask, ldm, nullptr, 0u, scale}, false, y, ldy, inv, stream);
 }
 
 int jmac_row_normalize_drop_bwd_f32(const float* x, int64_t ldx, const float* inv, const float* mask, int64_t ldm, float scale,
                                     const float* g, int64_t ldg, int64_t N, int64_t d, float eps, float* gx, int64_t ldgx,
                                     int32_t accumulate, jmac_stream_t stream) {
-    if (N < 0 || d <= 0 || d >= INT32_MAX) return JMAC_EINVAL;
-    if (d % 4 || ldx % 4 || ldg % 4 || ldgx % 4 || (mask && ldm % 4)) return JMAC_EDIM;
-    if (N == 0) return JMAC_OK;
-    if (!x || !inv || !g || !gx) return JMAC_EINVAL;
-    if ((((uintptr_t)x | (uintptr_t)g | (uintptr_t)gx | (uintptr_t)mask) & 15) != 0) return JMAC_EDIM;
-    int64_t blocks = (N + kBlock / 64 - 1) / (kBlock / 64);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(row_normalize_drop_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, x, ldx, inv, mask,
-                       ldm, scale, g, ldg, N, (int)(d / 4), eps, gx, ldgx, accumulate ? 1 : 0);
-    return (int)hipGetLastError();
+    return drop_bwd(x, ldx, inv, DropSrc{mask, ldm, nullptr, 0u, scale}, false, g, ldg, N, d, eps, gx, ldgx, accumulate, stream);
+}
+
+int jmac_row_normalize_dropseed_fwd_f32(const float* x, int64_t ldx, int64_t N, int64_t d, float eps, const int64_t* seed,
+                                        float p_drop, float* y, int64_t ldy, float* inv, jmac_stream_t stream) {
+    DropSrc ds;
+    if (int rc = seeded_src(seed, p_drop, ds)) return rc;
+    return drop_fwd(x, ldx, N, d, eps, ds, true, y, ldy, inv, stream);
+}
+
+int jmac_row_normalize_dropseed_bwd_f32(const float* x, int64_t ldx, const float* inv, const int64_t* seed, float p_drop,
+                                        const float* g, int64_t ldg, int64_t N, int64_t d, float eps, float* gx, int64_t ldgx,
+                                        int32_t accumulate, jmac_stream_t stream) {
+    DropSrc ds;
+    if (int rc = seeded_src(seed, p_drop, ds)) return rc;
+    return drop_bwd(x, ldx, inv, ds, true, g, ldg, N, d, eps, gx, ldgx, accumulate, stream);
 }
 
 // ---- phased forms for batch statistics that span several ranks (destination-sharded layer, jmac_amd/dist.py) ---------

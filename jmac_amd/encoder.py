@@ -194,25 +194,36 @@ def _bn_bwd(x, y, gy, gy2, weight, mean, invstd, use_batch):
     return gx, gbw
 
 
-def _norm_drop_fwd(x, p_drop, training, y, mask=None):
-    """completion_dropout(F.normalize(x)) into y (src/jmac_model.py:179,191): (inv, mask, scale).  ``mask``: pre-drawn
-    {0,1} tensor (the encoder draws the masks of both dropout sites in one launch)."""
+def _norm_drop_fwd(x, p_drop, training, y, mask=None, seed=None):
+    """completion_dropout(F.normalize(x)) into y (src/jmac_model.py:179,191): (inv, drop).  ``drop`` is what the backward
+    needs to repeat the draws: None (no dropout), ("mask", tensor, scale) for a pre-drawn {0,1} tensor, or ("seed", tensor,
+    p_drop) -- ``seed``: a one-element device int64; the kernels draw from it themselves, no mask tensor exists."""
     N, d = x.shape
+    inv = _empty(x.device, max(N, 1))
+    if not (training and p_drop > 0.0):
+        mask = seed = None
+    if seed is not None and mask is None:
+        check(lib().jmac_row_normalize_dropseed_fwd_f32(ptr(x), x.stride(0), N, d, 1e-12, ptr(seed), float(p_drop), ptr(y),
+                                                        y.stride(0), ptr(inv), stream()), "jmac_row_normalize_dropseed_fwd_f32")
+        return inv, ("seed", seed, float(p_drop))
     scale = 1.0
     if training and p_drop > 0.0:
         if mask is None:
             mask = torch.empty((N, d), dtype=torch.float32, device=x.device).bernoulli_(1.0 - p_drop)
         scale = 1.0 / (1.0 - p_drop)
-    else:
-        mask = None
-    inv = _empty(x.device, max(N, 1))
     check(lib().jmac_row_normalize_drop_fwd_f32(ptr(x), x.stride(0), N, d, 1e-12, ptr(mask), d, scale, ptr(y), y.stride(0),
                                                 ptr(inv), stream()), "jmac_row_normalize_drop_fwd_f32")
-    return inv, mask, scale
+    return inv, (("mask", mask, scale) if mask is not None else None)
 
 
-def _norm_drop_bwd(x, inv, mask, scale, g, gx, accumulate):
+def _norm_drop_bwd(x, inv, drop, g, gx, accumulate):
     N, d = x.shape
+    if drop is not None and drop[0] == "seed":
+        check(lib().jmac_row_normalize_dropseed_bwd_f32(ptr(x), x.stride(0), ptr(inv), ptr(drop[1]), drop[2], ptr(g), g.stride(0), N,
+                                                        d, 1e-12, ptr(gx), gx.stride(0), 1 if accumulate else 0, stream()),
+              "jmac_row_normalize_dropseed_bwd_f32")
+        return
+    mask, scale = (drop[1], drop[2]) if drop is not None else (None, 1.0)
     check(lib().jmac_row_normalize_drop_bwd_f32(ptr(x), x.stride(0), ptr(inv), ptr(mask), d, scale, ptr(g), g.stride(0), N, d,
                                                 1e-12, ptr(gx), gx.stride(0), 1 if accumulate else 0, stream()),
           "jmac_row_normalize_drop_bwd_f32")
@@ -524,9 +535,11 @@ class _EncoderName(torch.autograd.Function):
                     f2[2]])
         # ---- node side.  cat buffers: cat0 = [comp0 | info] (:180), cat1 = [c1n | a1] (:192), catA = [align0 | a1 | a2] (:203)
         t.cat0, t.cat1, t.catA = _empty(dev, N, d + di), _empty(dev, N, 2 * d), _empty(dev, N, 3 * d)
-        masks = (torch.empty((2, N, d), dtype=torch.float32, device=dev).bernoulli_(1.0 - p_drop)
-                 if training and p_drop > 0.0 else (None, None))
-        t.inv0, t.mask0, t.scale0 = _norm_drop_fwd(E, p_drop, training, t.cat0[:, :d], masks[0])          # :179
+        # dropout draws: two device-resident seeds from torch's generator (one tiny launch, fresh on every replay of a captured
+        # step); the normalise kernels draw from them, forward and backward -- no [N, d] mask is written or read
+        seeds = (torch.empty(2, dtype=torch.int64, device=dev).random_() if training and p_drop > 0.0 else None)
+        sd = (lambda i: seeds[i:i + 1]) if seeds is not None else (lambda i: None)
+        t.inv0, t.drop0 = _norm_drop_fwd(E, p_drop, training, t.cat0[:, :d], seed=sd(0))                  # :179
         t.cat0[:, d:].copy_(info)
         align0 = t.catA[:, :d]
         torch.mm(t.cat0, t.w, out=align0)                                                       # :180
@@ -534,7 +547,7 @@ class _EncoderName(torch.autograd.Function):
         t.sa = _layer_fwd(la, align0, t.wc[0], t.cha.RR, a_att[0], graph, training, t.catA[:, d:2 * d], t.cat1[:, d:])   # :183
         c1 = _empty(dev, N, d)
         t.sc = _layer_fwd(lc, E, t.wc[1], t.chc.RR, a_att[1], graph, training, c1)              # :190
-        t.inv1, t.mask1, t.scale1 = _norm_drop_fwd(c1, p_drop, training, t.cat1[:, :d], masks[1])         # :191
+        t.inv1, t.drop1 = _norm_drop_fwd(c1, p_drop, training, t.cat1[:, :d], seed=sd(1))                 # :191
         t.a_in = torch.mm(t.cat1, U21)                                                          # :192
         t.s2 = _layer_fwd(l2, t.a_in, t.wc[2], t.ch2.RR, a_att[2], graph, training, t.catA[:, 2 * d:])               # :197
         align_out = torch.mm(t.catA, Wall)                                                      # :203
@@ -592,7 +605,7 @@ class _EncoderName(torch.autograd.Function):
             gy, gy2 = None, None
             if have_align:
                 gy = _empty(dev, N, d)
-                _norm_drop_bwd(c1, t.inv1, t.mask1, t.scale1, dcat1[:, :d], gy, False)
+                _norm_drop_bwd(c1, t.inv1, t.drop1, dcat1[:, :d], gy, False)
                 gy2 = g_c1.contiguous() if g_c1 is not None else None
             else:
                 gy = g_c1.contiguous()
@@ -605,7 +618,7 @@ class _EncoderName(torch.autograd.Function):
             # align0 = cat0 @ w: only comp0 needs an input gradient (the name embeddings are constants)
             d_comp0 = torch.mm(d_align0, t.w[:d].t())
             dw = torch.mm(t.cat0.t(), d_align0)                                  # [d+di, d]
-            _norm_drop_bwd(E, t.inv0, t.mask0, t.scale0, d_comp0, dE, True)
+            _norm_drop_bwd(E, t.inv0, t.drop0, d_comp0, dE, True)
             dU11 = _empty(dev, 2 * d, d)                                         # [:d] <- dw[:d] by the unpack launch below
             dNL = _empty(dev, di, d)
             levels[0].extend([gemm_task(dw[d:], U11[d:], dNL, tb=True, defer=True), gemm_task(NL, dw[d:], dU11[d:], ta=True, defer=True)])

@@ -255,6 +255,49 @@ def test_normalize_dropout_kernels(with_mask):
     assert_close(gacc[torch.arange(N) != 5], (base.double() + want)[torch.arange(N) != 5], 1e-5, 1e-6)
 
 
+@pytest.mark.parametrize("p_drop", [0.4, 0.05])
+def test_normalize_dropout_seeded_draws(p_drop):
+    """The in-kernel Bernoulli draws: (1) the forward equals the mask form run with the mask read back from its own zeros,
+    bit for bit; (2) the backward regenerates exactly those draws; (3) the keep rate is 1 - p within sampling error, draws
+    of different seeds / rows / columns are uncorrelated; (4) the same seed gives the same draws (a captured step replays
+    the kernel, the seed tensor's CONTENT is what changes)."""
+    from jmac_amd._lib import check, lib, ptr, stream
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    N, d = 2000, 300
+    x = torch.randn(N, d, device=DEV, generator=gen) + 3.0        # no exact zeros among the normalised values
+    seed = torch.tensor([0x1234_5678_9ABC_DEF0 >> 1, 77], dtype=torch.int64, device=DEV)
+    L = lib()
+
+    def fwd(sd):
+        y, inv = torch.empty(N, d, device=DEV), torch.empty(N, device=DEV)
+        check(L.jmac_row_normalize_dropseed_fwd_f32(ptr(x), d, N, d, 1e-12, ptr(sd), p_drop, ptr(y), d, ptr(inv), stream()))
+        return y, inv
+    y, inv = fwd(seed[0:1])
+    mask = (y != 0).float()
+    keep = float(mask.mean())
+    assert abs(keep - (1 - p_drop)) < 4 * (p_drop * (1 - p_drop) / (N * d)) ** 0.5 + 1e-4, keep
+    scale = 1.0 / (1.0 - p_drop)
+    y2, inv2 = torch.empty(N, d, device=DEV), torch.empty(N, device=DEV)
+    check(L.jmac_row_normalize_drop_fwd_f32(ptr(x), d, N, d, 1e-12, ptr(mask), d, scale, ptr(y2), d, ptr(inv2), stream()))
+    assert torch.equal(y, y2) and torch.equal(inv, inv2)
+    assert torch.equal(fwd(seed[0:1])[0], y)                      # same seed, same draws
+    other = (fwd(seed[1:2])[0] != 0).float()
+    assert abs(float((mask * other).mean()) - (1 - p_drop) ** 2) < 5e-3          # another seed: independent draws
+    assert abs(float((mask[1:] * mask[:-1]).mean()) - (1 - p_drop) ** 2) < 5e-3  # neighbouring rows
+    assert abs(float((mask[:, 1:] * mask[:, :-1]).mean()) - (1 - p_drop) ** 2) < 5e-3
+    g = torch.randn(N, d, device=DEV, generator=gen)
+    base = torch.randn(N, d, device=DEV, generator=gen)
+    for acc in (0, 1):
+        ga, gb = base.clone(), base.clone()
+        check(L.jmac_row_normalize_dropseed_bwd_f32(ptr(x), d, ptr(inv), ptr(seed[0:1]), p_drop, ptr(g), d, N, d, 1e-12, ptr(ga), d,
+                                                    acc, stream()))
+        check(L.jmac_row_normalize_drop_bwd_f32(ptr(x), d, ptr(inv), ptr(mask), d, scale, ptr(g), d, N, d, 1e-12, ptr(gb), d, acc,
+                                                stream()))
+        assert_close(ga, gb.double(), 1e-6, 1e-7)               # same draws (the two kernels contract their FMAs differently)
+    bad = torch.empty(N, d, device=DEV)
+    assert L.jmac_row_normalize_dropseed_fwd_f32(ptr(x), d, N, d, 1e-12, ptr(seed), 1.0, ptr(bad), d, ptr(inv), stream()) != 0
+
+
 def test_bn_tanh_two_destinations_two_gradients():
     from jmac_amd import ops
     from jmac_amd.encoder import _bn_bwd, _bn_fwd
