@@ -489,6 +489,52 @@ def layer_forward(lay, X, R, graph: RelGraph):
 
 
 # ---- forward_name ---------------------------------------------------------------------------------------------------------
+class _Cat0Slot:
+    """``cat(comp0, info)`` (src/jmac_model.py:180) whose right block -- the constant name embeddings -- is written ONCE: the
+    buffer lives with the model, a forward takes it (rewriting only the left block) and its backward gives it back.  A forward
+    that finds it taken (two forwards before a backward), or another ``info``, gets a buffer of its own, as before.  ``lease``
+    counts the takers: a backward that runs after a later forward has re-used the buffer (retain_graph + an interleaved
+    forward) fails loudly instead of reading the other forward's rows."""
+
+    def __init__(self):
+        self.buf, self.key, self.busy, self.lease = None, None, False, 0
+
+
+class _Cat0Lease:
+    def __init__(self, slot, buf, owns):
+        self.slot, self.buf, self.owns, self.released = slot, buf, owns, False
+        self.lease = slot.lease if owns else -1
+
+    def check(self):
+        if self.owns and self.slot.lease != self.lease:
+            raise RuntimeError("jmac encoder: the cat(comp0, info) buffer of this forward was re-used by a later forward "
+                               "(a second backward after retain_graph with a forward in between?)")
+
+    def release(self):
+        if self.owns and not self.released and self.slot.lease == self.lease:
+            self.slot.busy = False
+        self.released = True
+
+    def __del__(self):
+        self.release()
+
+
+def _cat0_take(cache, info, N, d, dev) -> _Cat0Lease:
+    di = info.shape[1]
+    key = (info.data_ptr(), tuple(info.shape), tuple(info.stride()), info._version, N, d, str(dev))
+    slot = cache.setdefault("cat0", _Cat0Slot()) if cache is not None else None
+    if slot is not None and slot.key == key and not slot.busy:
+        slot.busy, slot.lease = True, slot.lease + 1
+        return _Cat0Lease(slot, slot.buf, True)
+    buf = _empty(dev, N, d + di)
+    buf[:, d:].copy_(info)
+    # (never adopt a buffer allocated during a stream capture: it belongs to that graph's memory pool)
+    if slot is not None and not slot.busy and not torch.cuda.is_current_stream_capturing():   # first use / another info
+        slot.buf, slot.key, slot.busy, slot.lease = buf, key, True, slot.lease + 1
+        return _Cat0Lease(slot, buf, True)
+    return _Cat0Lease(slot if slot is not None else _Cat0Slot(), buf, False)
+
+
 class _EncoderName(torch.autograd.Function):
     """JMAC.forward_name (src/jmac_model.py:172-204), num_gcn_layer = 2.
 
@@ -534,13 +580,13 @@ class _EncoderName(torch.autograd.Function):
                     [fa[2], fc[2], *f2[1], mc[1]],
                     f2[2]])
         # ---- node side.  cat buffers: cat0 = [comp0 | info] (:180), cat1 = [c1n | a1] (:192), catA = [align0 | a1 | a2] (:203)
-        t.cat0, t.cat1, t.catA = _empty(dev, N, d + di), _empty(dev, N, 2 * d), _empty(dev, N, 3 * d)
+        t.cat0_lease = _cat0_take(getattr(cfg, "cache", None), info, N, d, dev)       # right block = info, already in place
+        t.cat0, t.cat1, t.catA = t.cat0_lease.buf, _empty(dev, N, 2 * d), _empty(dev, N, 3 * d)
         # dropout draws: two device-resident seeds from torch's generator (one tiny launch, fresh on every replay of a captured
         # step); the normalise kernels draw from them, forward and backward -- no [N, d] mask is written or read
         seeds = (torch.empty(2, dtype=torch.int64, device=dev).random_() if training and p_drop > 0.0 else None)
         sd = (lambda i: seeds[i:i + 1]) if seeds is not None else (lambda i: None)
         t.inv0, t.drop0 = _norm_drop_fwd(E, p_drop, training, t.cat0[:, :d], seed=sd(0))                  # :179
-        t.cat0[:, d:].copy_(info)
         align0 = t.catA[:, :d]
         torch.mm(t.cat0, t.w, out=align0)                                                       # :180
         a_att = [p[4].reshape(-1) for p in (pa, pc, p2)]
@@ -617,7 +663,9 @@ class _EncoderName(torch.autograd.Function):
             dRRa, dwca, daa, gbwa = _layer_bwd(t.sa, graph, dcatA[:, d:2 * d], dcat1[:, d:], d_align0, True)
             # align0 = cat0 @ w: only comp0 needs an input gradient (the name embeddings are constants)
             d_comp0 = torch.mm(d_align0, t.w[:d].t())
+            t.cat0_lease.check()
             dw = torch.mm(t.cat0.t(), d_align0)                                  # [d+di, d]
+            t.cat0_lease.release()                                               # last reader of cat0
             _norm_drop_bwd(E, t.inv0, t.drop0, d_comp0, dE, True)
             dU11 = _empty(dev, 2 * d, d)                                         # [:d] <- dw[:d] by the unpack launch below
             dNL = _empty(dev, di, d)
@@ -648,6 +696,7 @@ class _EncoderName(torch.autograd.Function):
             g2 = _layer_grads(cg2, cut[1], da2, gbw2, d)
         if have_c:
             gc = _layer_grads(cgc, cut[-1], dac, gbwc, d)
+        t.cat0_lease.release()
         return (None, dE, dRc, dRa, None, dNL, dU11, dU21, dWall, gL11, gL12, gL11u, gL12u, *ga, *gc, *g2)
 
 
@@ -724,6 +773,7 @@ def forward_name(model, comp_att, rel_comp, rel_align, info, graph: RelGraph):
     la, lc, l2 = model.conv1_alignment, model.conv1_completion, model.conv2_alignment
     cfg = _cfg(model, (la, lc, l2), graph)
     cfg.training = la.training                                           # BatchNorm follows the layers' own mode
+    cfg.cache = model.__dict__.setdefault("_encoder_cache", {})          # buffers that outlive a step (see _Cat0Slot)
     return _EncoderName.apply(cfg, comp_att, rel_comp, rel_align, info, model.name_linear, model.uni_linear1_1,
                               model.uni_linear2_1, model.all_linear_completion, model.rel_linear11, model.rel_linear12,
                               model.rel_linear11_uni, model.rel_linear12_uni, *_layer_inputs(la), *_layer_inputs(lc),

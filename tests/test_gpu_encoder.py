@@ -105,6 +105,46 @@ def test_fused_encoder_equals_op_by_op_path(no_name, use):
     assert_close(r1[1], r2[1], 2e-5, 1e-6, "eval rel_c1")
 
 
+def test_fused_encoder_keeps_its_name_block_buffer_across_steps():
+    """cat(comp0, info) lives with the model (its constant right block is written once): step after step the same buffer;
+    a second forward before the first one's backward gets its own; a backward after the buffer was re-used fails loudly;
+    the results are those of a model without the cache."""
+    n, nr, d, di = 500, 23, 32, 20
+    rng = np.random.default_rng(9)
+    ei, et = random_graph(rng, n, nr, 1900, hub=100)
+    ei, et = torch.from_numpy(ei).to(DEV), torch.from_numpy(et).to(DEV)
+    m = _model(d, n, nr, di, False, 4)
+    m.train()
+    m.fused_encoder = True
+    fwd = lambda: m.forward_base(ei, et, [0, n], [0, nr])
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    first = None
+    for step in range(3):
+        m.load_state_dict(state)                                 # same BN statistics every time: identical outputs
+        m.zero_grad(set_to_none=True)
+        a, comp, _ = fwd()
+        (a.sum() + comp[1].sum()).backward()
+        slot = m._encoder_cache["cat0"]
+        assert not slot.busy and slot.lease == step + 1
+        got = (a.detach().clone(), m.uni_linear1_1.grad.clone())
+        if first is None:
+            first, buf = got, slot.buf
+        else:
+            assert slot.buf is buf and torch.equal(got[0], first[0]) and torch.equal(got[1], first[1])
+    m.load_state_dict(state)
+    a1, comp1, _ = fwd()                                         # holds the model's buffer ...
+    a2, _, _ = fwd()                                             # ... so this one allocates its own
+    assert m._encoder_cache["cat0"].buf is buf and m._encoder_cache["cat0"].busy
+    a2.sum().backward()
+    assert m._encoder_cache["cat0"].busy                         # (not the owner: the first forward still holds it)
+    (a1.sum() + comp1[1].sum()).backward(retain_graph=True)      # the owner's backward releases the buffer
+    assert not m._encoder_cache["cat0"].busy
+    a3, _, _ = fwd()                                             # re-uses (and rewrites) it
+    with pytest.raises(RuntimeError, match="re-used by a later forward"):
+        a1.sum().backward()
+    del a3
+
+
 def test_fused_encoder_on_a_slice_of_the_tables():
     """ent_bases / rel_bases select one KG of a multi-KG model (src/jmac_model.py:173-176): the node sees row slices of the
     parameters and autograd scatters its gradients back."""
