@@ -428,11 +428,14 @@ int jmac_gemm_grouped_f32(const jmac_gemm_task_t* tasks, int32_t n_tasks, jmac_s
  * d w_att [2d, d] and d gcn_weight [d, d] cut out of d[Wt|Wb|Wg].  The pointer arrays are HOST arrays of device pointers
  * (copied into the kernel arguments: capture-safe); all matrices contiguous; d % 4 == 0.
  * extra_src / extra_dst / extra_floats: one more contiguous copy in the same launch (the encoder's U11 block of the folded
- * name projection, src/jmac_model.py:177,180, and its adjoint), 16-byte aligned, a multiple of 4 floats; 0 floats: none. */
+ * name projection, src/jmac_model.py:177,180, and its adjoint), 16-byte aligned, a multiple of 4 floats; 0 floats: none.
+ * counters (pack only): up to JMAC_WCAT_MAX device int64 incremented by one in the same launch -- nn.BatchNorm1d's
+ * num_batches_tracked of the layers a training-mode encoder call is about to run (src/jmac_model.py:52). */
 #define JMAC_WCAT_MAX 4
 int jmac_wcat_pack_f32(const float* const* w_att, const float* const* gcn, float* const* wcat,
                        int32_t n_layers, int64_t d, const float* extra_src, float* extra_dst,
-                       int64_t extra_floats, jmac_stream_t stream);
+                       int64_t extra_floats, int64_t* const* counters, int32_t n_counters,
+                       jmac_stream_t stream);
 int jmac_wcat_unpack_f32(const float* const* dwcat, float* const* d_watt, float* const* d_gcn,
                          int32_t n_layers, int64_t d, const float* extra_src, float* extra_dst,
                          int64_t extra_floats, jmac_stream_t stream);

@@ -469,11 +469,14 @@ struct WcatArgs {
     const float* extra_src;                // one more contiguous copy riding along (blockIdx.y == n), or NULL
     float* extra_dst;
     int64_t extra_n4;                      // float4s
+    int64_t* counters[JMAC_WCAT_MAX];      // incremented by one (BatchNorm's num_batches_tracked of the layers), pack only
+    int n_counters;
     int n, d;
 };
 template <bool ADJOINT>
 __global__ __launch_bounds__(256) void wcat_kernel(const WcatArgs a) {
     const int l = blockIdx.y, d = a.d, D4 = d / 4;
+    if (!ADJOINT && blockIdx.x == 0 && l == 0 && threadIdx.x < (unsigned)a.n_counters) a.counters[threadIdx.x][0] += 1;
     if (l == a.n) {                                            // the extra copy
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.extra_n4; i += (int64_t)gridDim.x * 256)
             st4(a.extra_dst + 4 * i, ld4(a.extra_src + 4 * i));
@@ -570,7 +573,8 @@ static int wcat_extra(WcatArgs& a, const float* src, float* dst, int64_t n) {
 }
 
 int jmac_wcat_pack_f32(const float* const* w_att, const float* const* gcn, float* const* wcat, int32_t n_layers, int64_t d,
-                       const float* extra_src, float* extra_dst, int64_t extra_floats, jmac_stream_t stream) {
+                       const float* extra_src, float* extra_dst, int64_t extra_floats, int64_t* const* counters,
+                       int32_t n_counters, jmac_stream_t stream) {
     if (n_layers <= 0 || n_layers > JMAC_WCAT_MAX || d <= 0 || !w_att || !gcn || !wcat) return JMAC_EINVAL;
     if (d % 4) return JMAC_EDIM;
     WcatArgs a{};
@@ -581,6 +585,12 @@ int jmac_wcat_pack_f32(const float* const* w_att, const float* const* gcn, float
     }
     const int64_t total = d * 3 * (d / 4);
     if (int rc = wcat_extra(a, extra_src, extra_dst, extra_floats)) return rc;
+    if (n_counters < 0 || n_counters > JMAC_WCAT_MAX || (n_counters > 0 && !counters)) return JMAC_EINVAL;
+    a.n_counters = n_counters;
+    for (int i = 0; i < n_counters; ++i) {
+        if (!counters[i]) return JMAC_EINVAL;
+        a.counters[i] = counters[i];
+    }
     hipLaunchKernelGGL(wcat_kernel<false>, dim3((unsigned)((total + 255) / 256), (unsigned)(n_layers + (a.extra_src ? 1 : 0))),
                        dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();

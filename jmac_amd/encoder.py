@@ -259,13 +259,15 @@ def _extra_copy(copy):
     return ptr(src), ptr(dst), src.numel()
 
 
-def _wcat_pack(w_atts, gcns, d, copy=None):
+def _wcat_pack(w_atts, gcns, d, copy=None, counters=()):
     """[Wt | Wb | Wgcn] [d, 3d] of each layer (w_att = [Wt; Wb] stacked by rows, src/jmac_model.py:24,75-76): ONE launch for
-    all layers of the call (torch.cat: one per layer).  ``copy`` = (src, dst): one more block copied by the same launch."""
+    all layers of the call (torch.cat: one per layer).  ``copy`` = (src, dst): one more block copied by the same launch;
+    ``counters``: int64 device scalars it increments (the layers' num_batches_tracked)."""
     w_atts, gcns = [w.contiguous() for w in w_atts], [g.contiguous() for g in gcns]
     out = [_empty(w_atts[0].device, d, 3 * d) for _ in w_atts]
-    check(lib().jmac_wcat_pack_f32(_vp_array(w_atts), _vp_array(gcns), _vp_array(out), len(out), d, *_extra_copy(copy), stream()),
-          "jmac_wcat_pack_f32")
+    counters = list(counters)
+    check(lib().jmac_wcat_pack_f32(_vp_array(w_atts), _vp_array(gcns), _vp_array(out), len(out), d, *_extra_copy(copy),
+                                   _vp_array(counters) if counters else None, len(counters), stream()), "jmac_wcat_pack_f32")
     return out
 
 
@@ -546,10 +548,11 @@ class _EncoderName(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, *tensors):
         global _TRACKERS
-        _TRACKERS = []                            # the three layers' num_batches_tracked: bumped by ONE launch at the end
+        _TRACKERS = []                            # the layers' num_batches_tracked: bumped by the weight-pack launch (below)
         try:
             out = _EncoderName._forward(ctx, cfg, *tensors)
-            _bump_trackers(_TRACKERS)
+            done = {id(c) for c in ctx.t.bumped}
+            _bump_trackers([c for c in _TRACKERS if id(c) not in done])       # (none left in practice)
             return out
         finally:
             _TRACKERS = None
@@ -569,7 +572,10 @@ class _EncoderName(torch.autograd.Function):
         t.w = _empty(dev, d + di, d)
         # weights: [Wt|Wb|Wg] per layer; the U11_top block of t.w is copied by the same launch
         u11 = U11.contiguous()
-        t.wc = _wcat_pack([p[3] for p in (pa, pc, p2)], [p[5] for p in (pa, pc, p2)], d, copy=(u11[:d], t.w[:d]))
+        # ... and so are the layers' num_batches_tracked counters (nn.BatchNorm1d bumps them in train mode)
+        t.bumped = [lay.bn.num_batches_tracked for lay in (la, lc, l2) if training and lay.bn.track_running_stats]
+        t.wc = _wcat_pack([p[3] for p in (pa, pc, p2)], [p[5] for p in (pa, pc, p2)], d, copy=(u11[:d], t.w[:d]),
+                          counters=t.bumped)
         # ---- relation side: three dependency levels, one launch each
         t.cha = _Chain(la, Ra, pa[0], pa[1], pa[2], t.wc[0], d)
         t.chc = _Chain(lc, Rc, pc[0], pc[1], pc[2], t.wc[1], d)
