@@ -244,11 +244,11 @@ class JaWorkload:
         B = self.a.batch
         loss = 0
         for ent, rl in zip(comp, rel):                                   # src/jmac_model.py:331-378
-            score = l1(ent, rl, h, r, t)
-            if on_device:
+            if on_device:                                                # as JMAC.completion_loss composes it
                 from jmac_amd import losses
-                loss = loss + losses.margin_loss(score, B, margin)
+                loss = loss + losses.triple_l1_margin_loss(ent, rl, h, r, t, B, margin)
                 continue
+            score = l1(ent, rl, h, r, t)
             pos = score[:B].view(-1, B).permute(1, 0)
             neg = score[B:].view(-1, B).permute(1, 0)
             loss = loss + torch.max(pos - neg, -margin).mean() + margin

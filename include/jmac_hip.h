@@ -472,6 +472,14 @@ int jmac_triple_l1_bwd_f32(const float* ent, int64_t lde, const float* rel, int6
                            const int64_t* h, const int64_t* r, const int64_t* t, int64_t T,
                            int64_t period, int64_t d, const float* gscore, float* dent, int64_t ldde, float* drel, int64_t lddr,
                            jmac_stream_t stream);
+/* The same adjoint for a score vector that fed the margin ranking loss of completion_loss directly (T = B (K + 1) triples, the
+ * batch layout of train.py:347-352, src/jmac_model.py:351-378): the score gradient is derived inside the kernel from the
+ * scores, gamma (device scalar) and gloss (device scalar, the loss' incoming gradient) by jmac_margin_loss_bwd_f32's rule --
+ * no dscore vector, no launch for it.  dent / drel zeroed by the caller as above. */
+int jmac_triple_l1_margin_bwd_f32(const float* ent, int64_t lde, const float* rel, int64_t ldr,
+                                  const int64_t* h, const int64_t* r, const int64_t* t, int64_t B, int64_t K,
+                                  int64_t d, const float* score, const float* gamma, const float* gloss,
+                                  float* dent, int64_t ldde, float* drel, int64_t lddr, jmac_stream_t stream);
 
 /* dist[x] = 1 - <u, v>, u = e1[i1[x]] / max(||.||, 1e-12), v = e2[i2[x]] / max(||.||, 1e-12)
  * (replaces F.normalize(E[idx]) x2 + sum of alignment_loss / alignment_loss_simple,

@@ -113,6 +113,7 @@ _SIGS = {
     "jmac_gemm_f32": (C.c_int, [vp, i64, i32, vp, i64, i32, i64, i64, i64, vp, i64, vp]),
     "jmac_triple_l1_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp]),
     "jmac_triple_l1_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp, i64, vp, i64, vp]),
+    "jmac_triple_l1_margin_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, i64, vp, i64, vp]),
     "jmac_pair_cosine_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp]),
     "jmac_pair_cosine_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp]),
     "jmac_margin_loss_fwd_f32": (C.c_int, [vp, i64, i64, vp, vp, vp]),

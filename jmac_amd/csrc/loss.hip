@@ -92,13 +92,35 @@ __global__ __launch_bounds__(kBlock) void triple_l1_fwd_kernel(const float* __re
     }
 }
 
-template <int NK>
+// MARGIN: the score gradient is not read but derived on the spot from the margin ranking loss that consumed the scores
+// (completion_loss, src/jmac_model.py:351-378: dscore[b] = c sum_k w_{b,k}, dscore[B + kB + b] = -c w_{b,k}, c = gloss/(BK),
+// w = 1 (pos - neg > -gamma), 1/2 (tie), 0) -- `gscore` then holds the SCORES, and no dscore vector / launch exists.
+struct MarginArgs {
+    const float* gamma;
+    const float* gloss;
+    int64_t B, K;
+};
+template <int NK, bool MARGIN>
 __global__ __launch_bounds__(kBlock) void triple_l1_bwd_kernel(const float* __restrict__ ent, int64_t lde,
                                                                const float* __restrict__ rel, int64_t ldr,
                                                                const int64_t* __restrict__ h, const int64_t* __restrict__ r,
                                                                const int64_t* __restrict__ t, int64_t T, int64_t period, int parts,
                                                                int d, const float* __restrict__ gscore, float* __restrict__ dent,
-                                                               int64_t ldde, float* __restrict__ drel, int64_t lddr) {
+                                                               int64_t ldde, float* __restrict__ drel, int64_t lddr, MarginArgs ma) {
+    float mg_c = 0.f, mg_gamma = 0.f;
+    if (MARGIN) {
+        mg_gamma = ma.gamma[0];
+        mg_c = ma.gloss[0] / ((float)ma.B * (float)ma.K);
+    }
+    auto gof = [&](int64_t x) -> float {                       // x is wave-uniform
+        if (!MARGIN) return gscore[x];
+        auto w = [&](float diff) { return diff > -mg_gamma ? 1.f : (diff == -mg_gamma ? 0.5f : 0.f); };
+        if (x >= ma.B) return -mg_c * w(gscore[(x - ma.B) % ma.B] - gscore[x]);
+        const float pos = gscore[x];
+        float sum = 0.f;
+        for (int64_t k = 0; k < ma.K; ++k) sum += w(pos - gscore[ma.B + k * ma.B + x]);     // same order as margin_loss_bwd_kernel
+        return mg_c * sum;
+    };
     const int lane = lane_id();
     const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * kWavesPerBlock;
@@ -141,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void triple_l1_bwd_kernel(const float* __re
                     acc[k] = 0.f;
                 }
             }
-            const float g = gscore[x], g2 = pair ? gscore[x2] : 0.f;
+            const float g = gof(x), g2 = pair ? gof(x2) : 0.f;
             const float* pt = ent + it * lde;
             const float* pt2 = ent + (pair ? it2 : it) * lde;
             float* qt = dent + it * ldde;
@@ -387,8 +409,25 @@ int jmac_triple_l1_bwd_f32(const float* ent, int64_t lde, const float* rel, int6
     hipStream_t st = (hipStream_t)stream;
     const int nk = (int)((d + 63) / 64);
     const int parts = run_parts(T, period);
-    JMAC_DISPATCH_NK(nk, hipLaunchKernelGGL((triple_l1_bwd_kernel<NK>), dim3(wave_grid(period * parts)), dim3(kBlock), 0, st, ent, lde,
-                                            rel, ldr, h, r, t, T, period, parts, (int)d, gscore, dent, ldde, drel, lddr));
+    JMAC_DISPATCH_NK(nk, hipLaunchKernelGGL((triple_l1_bwd_kernel<NK, false>), dim3(wave_grid(period * parts)), dim3(kBlock), 0, st,
+                                            ent, lde, rel, ldr, h, r, t, T, period, parts, (int)d, gscore, dent, ldde, drel, lddr,
+                                            MarginArgs{}));
+    return (int)hipGetLastError();
+}
+
+int jmac_triple_l1_margin_bwd_f32(const float* ent, int64_t lde, const float* rel, int64_t ldr, const int64_t* h, const int64_t* r,
+                                  const int64_t* t, int64_t B, int64_t K, int64_t d, const float* score, const float* gamma,
+                                  const float* gloss, float* dent, int64_t ldde, float* drel, int64_t lddr, jmac_stream_t stream) {
+    if (B <= 0 || K <= 0 || d <= 0 || B >= INT32_MAX || K >= INT32_MAX) return JMAC_EINVAL;
+    if (d > 512) return JMAC_EDIM;
+    if (!ent || !rel || !h || !r || !t || !score || !gamma || !gloss || !dent || !drel) return JMAC_EINVAL;
+    const int64_t T = B * (K + 1), period = B;
+    hipStream_t st = (hipStream_t)stream;
+    const int nk = (int)((d + 63) / 64);
+    const int parts = run_parts(T, period);
+    JMAC_DISPATCH_NK(nk, hipLaunchKernelGGL((triple_l1_bwd_kernel<NK, true>), dim3(wave_grid(period * parts)), dim3(kBlock), 0, st,
+                                            ent, lde, rel, ldr, h, r, t, T, period, parts, (int)d, score, dent, ldde, drel, lddr,
+                                            MarginArgs{gamma, gloss, B, K}));
     return (int)hipGetLastError();
 }
 

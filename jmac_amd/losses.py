@@ -123,6 +123,53 @@ class _MarginLoss(torch.autograd.Function):
         return dscore, None, None, None
 
 
+class _TripleL1Margin(torch.autograd.Function):
+    """score = triple L1 distances, loss = margin ranking loss of the score vector, as ONE node: the backward derives the score
+    gradient inside the L1 adjoint kernel (no dscore vector, no launch for it)."""
+
+    @staticmethod
+    def forward(ctx, ent, rel, h, r, t, margin, B, K):
+        require_device(ent, rel, h, r, t, margin)
+        ent, rel = _rows(ent), _rows(rel)
+        T, d = h.numel(), ent.shape[1]
+        if rel.shape[1] != d or r.numel() != T or t.numel() != T or T != B * (K + 1):
+            raise ValueError("triple_l1_margin_loss: shapes disagree")
+        score = torch.empty(T, dtype=torch.float32, device=ent.device)
+        loss = torch.empty(1, dtype=torch.float32, device=ent.device)
+        check(lib().jmac_triple_l1_fwd_f32(ptr(ent), ent.stride(0), ptr(rel), rel.stride(0), ptr(h), ptr(r), ptr(t), T, B, d,
+                                           ptr(score), stream()), "jmac_triple_l1_fwd_f32")
+        check(lib().jmac_margin_loss_fwd_f32(ptr(score), B, K, ptr(margin), ptr(loss), stream()), "jmac_margin_loss_fwd_f32")
+        ctx.save_for_backward(ent, rel, h, r, t, score, margin)
+        ctx.bk = (B, K)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        ent, rel, h, r, t, score, margin = ctx.saved_tensors
+        B, K = ctx.bk
+        d = ent.shape[1]
+        g = g.contiguous()
+        dent = torch.zeros((ent.shape[0], d), dtype=torch.float32, device=ent.device)
+        drel = torch.zeros((rel.shape[0], d), dtype=torch.float32, device=ent.device)
+        check(lib().jmac_triple_l1_margin_bwd_f32(ptr(ent), ent.stride(0), ptr(rel), rel.stride(0), ptr(h), ptr(r), ptr(t), B, K, d,
+                                                  ptr(score), ptr(margin), ptr(g), ptr(dent), d, ptr(drel), d, stream()),
+              "jmac_triple_l1_margin_bwd_f32")
+        return dent, drel, None, None, None, None, None, None
+
+
+def triple_l1_margin_loss(ent: torch.Tensor, rel: torch.Tensor, h: torch.Tensor, r: torch.Tensor, t: torch.Tensor,
+                          batch_size: int, margin: torch.Tensor) -> torch.Tensor:
+    """``margin_loss(triple_l1_score(ent, rel, h, r, t, period=batch_size), batch_size, margin)`` (src/jmac_model.py:345-378)
+    as one autograd node; batches that are not ``B (K + 1)`` triples long, or a margin that wants a gradient, take the two
+    ops."""
+    dev = ent.device
+    T, B = int(h.numel()), int(batch_size)
+    if B <= 0 or T <= B or (T - B) % B != 0 or margin.numel() != 1 or margin.requires_grad:
+        return margin_loss(triple_l1_score(ent, rel, h, r, t, period=B), B, margin)
+    return _TripleL1Margin.apply(ent, rel, _index(h, ent.shape[0], dev, "batch_h"), _index(r, rel.shape[0], dev, "batch_r"),
+                                 _index(t, ent.shape[0], dev, "batch_t"), margin.reshape(1).to(torch.float32), B, (T - B) // B)
+
+
 def margin_loss(score: torch.Tensor, batch_size: int, margin: torch.Tensor) -> torch.Tensor:
     """``torch.max(pos - neg, -margin).mean() + margin`` of completion_loss (src/jmac_model.py:351-378) on one batch's score
     vector [B + B*K]: ``pos = score[:B].view(-1, B).permute(1, 0)``, ``neg = score[B:].view(-1, B).permute(1, 0)`` -- the

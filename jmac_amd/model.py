@@ -242,9 +242,8 @@ class JMAC(nn.Module):
         loss = 0
         for layer in range(self.args.num_gcn_layer):
             ent, rel = (comp1[layer], rel1[layer]) if source else (comp2[layer], rel2[layer])
-            score = losses.triple_l1_score(ent, rel, h, r, t, period=bs)    # src/jmac_model.py:345-350
-            # pos / neg views + max + mean (:351-378); the reference consumes the b-major negative block as n-major
-            # (view(-1, B).permute): kept as is inside the fused op
-            loss_res = losses.margin_loss(score, bs, self.margin_completion)
+            # the L1 scores (src/jmac_model.py:345-350) and pos / neg views + max + mean (:351-378) as one node; the reference
+            # consumes the b-major negative block as n-major (view(-1, B).permute): kept as is inside the fused op
+            loss_res = losses.triple_l1_margin_loss(ent, rel, h, r, t, bs, self.margin_completion)
             loss = loss + loss_res + self.alignment_loss_simple(feeddict["links"], comp1[layer], comp2[layer])
         return loss

@@ -167,3 +167,38 @@ def test_margin_loss_matches_reference_expression(B, K):
     if (3 % B) != 0:
         with pytest.raises(RuntimeError):
             losses.margin_loss(rag, B, margin)
+
+
+@pytest.mark.parametrize("B,K,d", [(64, 5, 40), (250, 25, 300), (7, 1, 12)])
+def test_triple_l1_margin_loss_is_the_two_ops_in_one_node(B, K, d):
+    """losses.triple_l1_margin_loss == margin_loss(triple_l1_score(...)): same loss (bitwise: the same two forward kernels),
+    same gradients for both tables (the score gradient is derived inside the L1 adjoint; float atomics: tolerance), on the
+    reference's batch layout (sub.repeat(K+1), rel.repeat(K+1), cat(obj, negatives); train.py:347-352)."""
+    from jmac_amd import losses
+    gen = torch.Generator(device="cuda").manual_seed(B * K + d)
+    n, nr = 5 * B, 17
+    ent0 = torch.randn(n, d, device="cuda", generator=gen)
+    rel0 = torch.randn(nr, d, device="cuda", generator=gen)
+    bh = torch.randint(0, n, (B,), device="cuda", generator=gen)
+    br = torch.randint(0, nr, (B,), device="cuda", generator=gen)
+    h, r = bh.repeat(K + 1), br.repeat(K + 1)
+    t = torch.randint(0, n, (B * (K + 1),), device="cuda", generator=gen)
+    margin = torch.nn.Parameter(torch.tensor([float(d) * 0.2], device="cuda"), requires_grad=False)
+    res = []
+    for fused in (True, False):
+        ent, rel = ent0.clone().requires_grad_(True), rel0.clone().requires_grad_(True)
+        if fused:
+            loss = losses.triple_l1_margin_loss(ent, rel, h, r, t, B, margin)
+        else:
+            loss = losses.margin_loss(losses.triple_l1_score(ent, rel, h, r, t, period=B), B, margin)
+        (loss * 1.7).sum().backward()
+        res.append((loss.detach(), ent.grad, rel.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    scale = float(res[1][1].abs().max())
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-6 * scale)
+    # (17 relation rows take ~B / 17 float-atomic contributions each, in an order that differs from run to run)
+    assert torch.allclose(res[0][2], res[1][2], rtol=1e-5, atol=2e-5 * float(res[1][2].abs().max()))
+    assert float(res[0][1].abs().max()) > 0
+    # a batch that is not B (K + 1) long takes the two ops (and the reference's own expression behind them)
+    with pytest.raises(RuntimeError):
+        losses.triple_l1_margin_loss(ent0, rel0, h[:-1], r[:-1], t[:-1], B, margin)
