@@ -493,6 +493,26 @@ def layer_bench(w, device, cpu=True):
         torch.autograd.grad(out, [X] + [p for p in lay.parameters() if p.requires_grad], G, allow_unused=True)
 
     f_ms, fb_ms = _median_ms(fwd), _median_ms(fwdbwd)
+    # the same two as hipGraph replays: the eager figures above are bound by the host (python + ~25 launches), these by the GPU
+    gf_ms = gfb_ms = None
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fwd()
+            fwdbwd()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            fwd()
+        with torch.cuda.graph(g2):
+            fwdbwd()
+        gf_ms, gfb_ms = _median_ms(g1.replay), _median_ms(g2.replay)
+        del g1, g2
+    except Exception as ex:                                # pragma: no cover
+        sys.stderr.write("layer_bench: hipGraph capture failed (%s)\n" % (ex,))
+        torch.cuda.synchronize()
 
     def build():
         g = RelGraph(w.ei, w.et, w.N, w.nr + 1)
@@ -500,6 +520,8 @@ def layer_bench(w, device, cpu=True):
     csr_ms = _median_ms(build, n=5, warm=1)
     res = {"what": "one RelationAwareLayer call on the ja graph (projection GEMMs + aggregation + BN + tanh), eager",
            "fwd_ms": f_ms, "fwd_edges_per_s": w.E / (f_ms * 1e-3), "fwdbwd_ms": fb_ms, "fwdbwd_edges_per_s": w.E / (fb_ms * 1e-3),
+           "fwd_hipgraph_ms": gf_ms, "fwd_hipgraph_edges_per_s": (w.E / (gf_ms * 1e-3)) if gf_ms else None,
+           "fwdbwd_hipgraph_ms": gfb_ms, "fwdbwd_hipgraph_edges_per_s": (w.E / (gfb_ms * 1e-3)) if gfb_ms else None,
            "csr_build_ms": csr_ms, "csr_build": "COO -> CSR + by-source / by-relation views + schedules (cached per edge list)"}
     if cpu:
         import oracle.jmac_oracle as orc
