@@ -116,22 +116,25 @@ def _empty(dev, *shape):
 
 
 def _agg_fwd(PQZ, RR, a, graph: RelGraph, slope, out_scale=0.5):
-    """jmac_rel_attn_aggregate_fwd_f32 on the [P|Q|Z] table; the self loop is the last relation row."""
+    """jmac_rel_attn_aggregate_fwd_{f32,bf16} on the [P|Q|Z] table (fp32, or bf16 for the inference form: sums, softmax and
+    the output stay fp32); the self loop is the last relation row."""
     L = lib()
     N, d3 = PQZ.shape
     d = d3 // 3
     dev = PQZ.device
+    bf16 = PQZ.dtype == torch.bfloat16
     out, smax, sden = _empty(dev, N, d), _empty(dev, max(N, 1)), _empty(dev, max(N, 1))
     s = graph.by_dst
     wsb = int(L.jmac_rel_attn_fwd_workspace_bytes(s.n_parts_max, d))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     ev0 = ops._ev() if ops.PROFILE is not None else None
-    check(L.jmac_rel_attn_aggregate_fwd_f32(
-        ptr(PQZ), d3, PQZ.data_ptr() + d * 4, d3, ptr(RR), RR.stride(0), ptr(a), ptr(graph.col), ptr(graph.etype),
+    fwd = L.jmac_rel_attn_aggregate_fwd_bf16 if bf16 else L.jmac_rel_attn_aggregate_fwd_f32
+    check(fwd(
+        ptr(PQZ), d3, PQZ.data_ptr() + d * PQZ.element_size(), d3, ptr(RR), RR.stride(0), ptr(a), ptr(graph.col), ptr(graph.etype),
         C.byref(s.view()), N, d, float(slope), RR.shape[0] - 1, 0, float(out_scale), ptr(out), d, ptr(smax), ptr(sden),
-        ptr(ws), wsb, stream()), "jmac_rel_attn_aggregate_fwd_f32")
+        ptr(ws), wsb, stream()), "jmac_rel_attn_aggregate_fwd_%s" % ("bf16" if bf16 else "f32"))
     if ev0 is not None:
-        ops.PROFILE.append(("rel_attn_fwd", ev0, ops._ev()))
+        ops.PROFILE.append(("rel_attn_fwd_bf16" if bf16 else "rel_attn_fwd", ev0, ops._ev()))
     return out, smax, sden
 
 
@@ -391,9 +394,15 @@ class _MlpChain:
                  gemm_task(self.L12u, dWp, dW1, ta=True, accumulate=True)]], (dW1, dW2, dloop), (dL11u, dL12u)
 
 
-def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None):
-    """Node side of one RelationAwareLayer (src/jmac_model.py:44-52) given its relation tables: state for the backward."""
-    PQZ = torch.mm(X, wc)                                             # [P|Q|Z]: one library GEMM
+def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch.float32):
+    """Node side of one RelationAwareLayer (src/jmac_model.py:44-52) given its relation tables: state for the backward.
+    ``table_dtype`` bf16 (inference form, no backward: BASELINE config 3): the [P|Q|Z] table comes out of a bf16 GEMM and the
+    relation table is rounded to bf16; the aggregation gathers half the bytes, its arithmetic and everything after it is fp32."""
+    if table_dtype == torch.bfloat16:
+        PQZ = torch.mm(X.to(torch.bfloat16), wc.to(torch.bfloat16))
+        RR = RR.to(torch.bfloat16)
+    else:
+        PQZ = torch.mm(X, wc)                                         # [P|Q|Z]: one library GEMM
     slope = float(lay.atv_mlp.negative_slope)
     pre, smax, sden = _agg_fwd(PQZ, RR, a, graph, slope)
     mean, invstd, use_batch = _bn_fwd(pre, lay.bn, training, y, y2)
@@ -423,15 +432,21 @@ def _layer_grads(chain_grads, dwatt_dgcn, da, gbw, d):
 
 
 def supported(model, info_dim: Optional[int]) -> bool:
-    """What the fused nodes cover: comp_op 'sub', fp32 tables, d % 4 == 0 (16-byte rows), tanh layers with an ordinary
-    BatchNorm momentum, two GNN layers.  Everything else runs op by op (jmac_amd.model)."""
+    """What the fused nodes cover: comp_op 'sub', fp32 tables (bf16 tables under no_grad: the inference form), d % 4 == 0
+    (16-byte rows), tanh layers with an ordinary BatchNorm momentum, two GNN layers.  Everything else runs op by op
+    (jmac_amd.model)."""
     a = model.args
     d = model.entity_dim
     lays = (model.conv1_alignment, model.conv2_alignment, model.conv1_completion)
     return (getattr(a, "num_gcn_layer", 2) == 2 and d % 4 == 0 and (info_dim is None or info_dim % 4 == 0)
-            and getattr(model, "table_dtype", torch.float32) == torch.float32
+            and _tables_ok(getattr(model, "table_dtype", torch.float32))
             and all(l.comp_op == "sub" and l.layer_act is torch.tanh and l.bn.momentum is not None and l.bn.affine
-                    and l.table_dtype == torch.float32 and l.in_channels == d and l.out_channels == d for l in lays))
+                    and _tables_ok(l.table_dtype) and l.in_channels == d and l.out_channels == d for l in lays))
+
+
+def _tables_ok(dtype) -> bool:
+    """fp32 tables always; bf16 tables are the inference form (no backward exists for them): only without grad mode."""
+    return dtype == torch.float32 or (dtype == torch.bfloat16 and not torch.is_grad_enabled())
 
 
 # ---- one RelationAwareLayer ---------------------------------------------------------------------------------------------------
@@ -596,12 +611,14 @@ class _EncoderName(torch.autograd.Function):
         align0 = t.catA[:, :d]
         torch.mm(t.cat0, t.w, out=align0)                                                       # :180
         a_att = [p[4].reshape(-1) for p in (pa, pc, p2)]
-        t.sa = _layer_fwd(la, align0, t.wc[0], t.cha.RR, a_att[0], graph, training, t.catA[:, d:2 * d], t.cat1[:, d:])   # :183
+        t.sa = _layer_fwd(la, align0, t.wc[0], t.cha.RR, a_att[0], graph, training, t.catA[:, d:2 * d], t.cat1[:, d:],
+                          table_dtype=cfg.table_dtype)                                        # :183
         c1 = _empty(dev, N, d)
-        t.sc = _layer_fwd(lc, E, t.wc[1], t.chc.RR, a_att[1], graph, training, c1)              # :190
+        t.sc = _layer_fwd(lc, E, t.wc[1], t.chc.RR, a_att[1], graph, training, c1, table_dtype=cfg.table_dtype)   # :190
         t.inv1, t.drop1 = _norm_drop_fwd(c1, p_drop, training, t.cat1[:, :d], seed=sd(1))                 # :191
         t.a_in = torch.mm(t.cat1, U21)                                                          # :192
-        t.s2 = _layer_fwd(l2, t.a_in, t.wc[2], t.ch2.RR, a_att[2], graph, training, t.catA[:, 2 * d:])               # :197
+        t.s2 = _layer_fwd(l2, t.a_in, t.wc[2], t.ch2.RR, a_att[2], graph, training, t.catA[:, 2 * d:],
+                          table_dtype=cfg.table_dtype)                                        # :197
         align_out = torch.mm(t.catA, Wall)                                                      # :203
         if CAPTURE is not None:
             CAPTURE.update(conv1_alignment=(align0.clone(), Ra.detach()), conv1_completion=(E.detach(), Rc.detach()),
@@ -725,7 +742,7 @@ class _EncoderNoName(torch.autograd.Function):
         fc, mc = t.chc.fwd_tasks(), t.mlc.fwd_tasks()
         run_levels([[fc[0], fc[1], mc[0]], [fc[2], mc[1]]])
         c1 = _empty(E.device, N, d)
-        t.sc = _layer_fwd(lc, E, t.wc, t.chc.RR, pc[4].reshape(-1), cfg.graph, cfg.training, c1)
+        t.sc = _layer_fwd(lc, E, t.wc, t.chc.RR, pc[4].reshape(-1), cfg.graph, cfg.training, c1, table_dtype=cfg.table_dtype)
         if CAPTURE is not None:
             CAPTURE.update(conv1_completion=(E.detach(), Rc.detach()))
             CAPTURE["conv1_completion.tables"] = (t.sc.PQZ, t.sc.RR)
@@ -771,7 +788,8 @@ def _cfg(model, layers, graph):
     training = model.training
     return SimpleNamespace(layers=layers, graph=graph, training=training,
                            p_drop=float(model.completion_dropout.p) if model.completion_dropout.training else 0.0,
-                           mlp_slope=float(model.atv_mlp.negative_slope))
+                           mlp_slope=float(model.atv_mlp.negative_slope),
+                           table_dtype=getattr(model, "table_dtype", torch.float32))
 
 
 def forward_name(model, comp_att, rel_comp, rel_align, info, graph: RelGraph):

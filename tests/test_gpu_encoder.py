@@ -145,6 +145,35 @@ def test_fused_encoder_keeps_its_name_block_buffer_across_steps():
     del a3
 
 
+def test_fused_encoder_inference_form_with_bf16_tables():
+    """BASELINE config 3's table form through the fused node (no_grad only): bf16 [P|Q|Z] / [Rq|Rz] tables, fp32 arithmetic --
+    equal to the op-by-op bf16 path up to the rounding of the relation table (fp32 product rounded once here, a bf16 GEMM
+    there), and close to the fp32 tables; with grad mode on the node declines (there is no backward for bf16 tables)."""
+    from jmac_amd import encoder
+    n, nr, d, di = 700, 37, 32, 20
+    rng = np.random.default_rng(5)
+    ei, et = random_graph(rng, n, nr, 2600, hub=300)
+    ei, et = torch.from_numpy(ei).to(DEV), torch.from_numpy(et).to(DEV)
+    m = _model(d, n, nr, di, False, 11)
+    m.eval()
+    with torch.no_grad():
+        m.fused_encoder = True
+        a32, c32, _ = m.forward_base(ei, et, [0, n], [0, nr])
+        m.set_table_dtype(torch.bfloat16)
+        assert encoder.supported(m, di)
+        a_f, c_f, r_f = m.forward_base(ei, et, [0, n], [0, nr])
+        m.fused_encoder = False
+        for lay in (m.conv1_alignment, m.conv2_alignment, m.conv1_completion):
+            lay.fused = False
+        a_o, c_o, r_o = m.forward_base(ei, et, [0, n], [0, nr])
+    with torch.enable_grad():
+        assert not encoder.supported(m, di)
+    scale = float(a_o.abs().max())
+    assert float((a_f - a_o).abs().max()) <= 2e-2 * scale and float((c_f[1] - c_o[1]).abs().max()) <= 2e-2 * float(c_o[1].abs().max())
+    assert float((a_f - a32).abs().max()) <= 5e-2 * scale
+    assert_close(r_f[1], r_o[1], 2e-5, 1e-6, "rel_c1 (fp32 either way)")
+
+
 def test_fused_encoder_on_a_slice_of_the_tables():
     """ent_bases / rel_bases select one KG of a multi-KG model (src/jmac_model.py:173-176): the node sees row slices of the
     parameters and autograd scatters its gradients back."""
