@@ -59,7 +59,7 @@ struct GTask {
     const float* mask;     // act' source (same shape as C)
     int64_t ldc, ldmask;
     int32_t M, N, K, c_split;
-    int32_t ta, tb, vec, act, accumulate;
+    int32_t ta, tb, vec, act, accumulate, big;     // big: 64x64 tiles (grouped_tile64)
     float slope;
     int32_t tiles_n, tile_begin;       // tile_begin: the task's tile count (grid.x bound)
 };
@@ -289,6 +289,150 @@ __device__ __forceinline__ void grouped_tile(const GTask& t, int tile, float* __
     GG_STAMP(4);
 }
 
+// ---- one 64x64 output tile per 8-wave block: the products on LONG relation tables (the 5-KG union: ~4 800 rows) -------------
+// A launch's time is rounds of resident blocks x a block's life.  At ~10^3 rows a level's 32x32 tiles are a few rounds and the
+// form below changes nothing (measured: forward levels 26.6 / 24.4 / 25.2 -> 23.4 / 22.8 / 23.4 us, single products 10.4 ->
+// 13.6 us); at ~5 000 rows they are 17 rounds, and a 64x64 tile feeds four times the MFMAs from the same panel bytes per K
+// chunk.  Waves: q = wave & 3 picks the 32x32 quadrant, kh = wave >> 2 the K steps of the chunk (even / odd); K chunks of 80
+// (2 x 64 x 84 floats = 43 KB), the next chunk's global loads in flight across the MFMAs; the two K halves are summed through
+// LDS, half 0 first.  A is not transposed here (KC panel); B either way; vector loads only.
+constexpr int kKc2 = 80;
+constexpr int kLdk2 = kKc2 + 4;                 // 84 = 4 * 21
+constexpr int kPanel2 = 64 * kLdk2;             // floats per panel (the RC form needs kKc2 * 64 <= this)
+constexpr int kStage2 = (64 * (kKc2 / 4) + kBlock - 1) / kBlock;    // float4s per thread per panel = 3
+constexpr size_t kGroupedLds2 = (size_t)2 * kPanel2 * sizeof(float);
+static_assert(kWaves == 8, "the 64x64 form is laid out for eight waves");
+static_assert(kKc2 * 64 <= kPanel2 && kGroupedLds2 <= kGroupedLds, "64x64 panels fit the launch's LDS");
+
+template <bool KC>
+__device__ __forceinline__ void panel2_load(const GOperand& o, int r0, int R, int k0, int K, float4 (&v)[kStage2]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < kStage2; ++i) {
+        const int f = tid + i * kBlock;
+        if (KC) {                                              // f -> (row r, quad q): 20 quads per row
+            const int r = min(f / (kKc2 / 4), 63), q = f % (kKc2 / 4);
+            const int k = k0 + 4 * q;
+            v[i] = gld4(o.row(min(r0 + r, R - 1)) + max(min(k, K - 4), 0));
+            if (k >= K) v[i] = f4zero();
+        } else {                                               // f -> (k row kk, quad q of the 64 columns); R % 4 == 0
+            const int kk = min(f >> 4, kKc2 - 1), q = f & 15;
+            const int k = k0 + kk;
+            v[i] = gld4(o.row(min(k, K - 1)) + min(r0 + 4 * q, R - 4));
+            if (k >= K) v[i] = f4zero();
+        }
+    }
+}
+template <bool KC>
+__device__ __forceinline__ void panel2_store(float* __restrict__ lds, const float4 (&v)[kStage2]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < kStage2; ++i) {
+        const int f = tid + i * kBlock;
+        if (KC) {
+            if (f < 64 * (kKc2 / 4)) st4(lds + (f / (kKc2 / 4)) * kLdk2 + 4 * (f % (kKc2 / 4)), v[i]);
+        } else {
+            if (f < kKc2 * 16) st4(lds + (f >> 4) * 64 + 4 * (f & 15), v[i]);
+        }
+    }
+}
+template <bool KC>
+__device__ __forceinline__ float4 panel2_frag(const float* __restrict__ lds, int r, int kk) {
+    if (KC) return ld4(lds + r * kLdk2 + kk);
+    return make_float4(lds[(kk + 0) * 64 + r], lds[(kk + 1) * 64 + r], lds[(kk + 2) * 64 + r], lds[(kk + 3) * 64 + r]);
+}
+
+template <bool TB>
+__device__ __forceinline__ void grouped_tile64(const GTask& t, int tile, float* __restrict__ lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int q = wave & 3, kh = wave >> 2;
+    const int m0 = (tile / t.tiles_n) * 64, n0 = (tile % t.tiles_n) * 64;
+    const int ra = (q >> 1) * 32 + r, rb = (q & 1) * 32 + r;       // this lane's panel row (A) / column (B)
+    const int M = t.M, N = t.N, K = t.K;
+    float* la = lds;
+    float* lb = lds + kPanel2;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    GG_STAMP(1);
+    float4 va[kStage2], vb[kStage2];
+    panel2_load<true>(t.A, m0, M, 0, K, va);
+    panel2_load<TB>(t.B, n0, N, 0, K, vb);
+    constexpr int kHalf = (kKc2 / 8 + 1) / 2;                      // K steps per wave per chunk = 5
+    for (int k0 = 0; k0 < K; k0 += kKc2) {
+        if (k0 > 0) __syncthreads();
+        panel2_store<true>(la, va);
+        panel2_store<TB>(lb, vb);
+        panel2_load<true>(t.A, m0, M, k0 + kKc2, K, va);           // unconditional: see grouped_tile
+        panel2_load<TB>(t.B, n0, N, k0 + kKc2, K, vb);
+        __syncthreads();
+        GG_STAMP(2);
+        const int steps = (min(K - k0, kKc2) + 7) / 8;             // <= 10
+        float4 a = panel2_frag<true>(la, ra, kh * 8 + 4 * h), b = panel2_frag<TB>(lb, rb, kh * 8 + 4 * h);
+#pragma unroll
+        for (int j = 0; j < kHalf; ++j) {
+            const int kn = min(kh + 2 * (j + 1), kKc2 / 8 - 1) * 8 + 4 * h;
+            const float4 an = panel2_frag<true>(la, ra, kn), bn = panel2_frag<TB>(lb, rb, kn);     // one step ahead
+            if (kh + 2 * j < steps) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            }
+            a = an;
+            b = bn;
+        }
+    }
+    GG_STAMP(3);
+    __syncthreads();
+    // wave (q, kh) finishes accumulator registers 8 kh .. 8 kh + 7 of its quadrant: it leaves the other eight in LDS for its
+    // partner and reads the partner's; the sum is always (half 0) + (half 1)
+    float (*red)[2][8][64] = reinterpret_cast<float (*)[2][8][64]>(lds);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[q][kh][i][lane] = kh ? acc[i] : acc[8 + i];
+    __syncthreads();
+    const int n = n0 + rb, nc = min(n, N - 1);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float mine = kh ? acc[8 + j] : acc[j], other = red[q][1 - kh][j][lane];
+        v[j] = kh ? other + mine : mine + other;
+    }
+    // register j of this wave's eight: output row mb + (j & 3) + 8 (j >> 2); two groups of four, one after the other
+    const int mb = m0 + (q >> 1) * 32 + 16 * kh + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float msk[4], old[4];
+        float* cp[4];
+        bool ok[4], acc_ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            msk[j] = old[j] = 0.f;
+            const int m = mb + j + 8 * g, mc = min(m, M - 1);
+            ok[j] = m < M && n < N;
+            cp[j] = mc < t.c_split ? t.C + (int64_t)mc * t.ldc + nc : t.C2 + (int64_t)(mc - t.c_split) * t.ldc + nc;
+            acc_ok[j] = mc < t.c_split;
+            if (t.act == JMAC_GEMM_DACT_LEAKY || t.act == JMAC_GEMM_DACT_RELU) msk[j] = gld(t.mask + (int64_t)mc * t.ldmask + nc);
+        }
+        if (t.accumulate) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) old[j] = gld(cp[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = v[4 * g + j];
+            if (t.act == JMAC_GEMM_ACT_LEAKY) x = x > 0.f ? x : x * t.slope;
+            else if (t.act == JMAC_GEMM_ACT_RELU) x = x > 0.f ? x : 0.f;
+            else if (t.act == JMAC_GEMM_DACT_LEAKY) x = msk[j] > 0.f ? x : x * t.slope;
+            else if (t.act == JMAC_GEMM_DACT_RELU) x = msk[j] > 0.f ? x : 0.f;
+            if (t.accumulate && acc_ok[j]) x += old[j];
+            if (ok[j]) gst(cp[j], x);
+        }
+    }
+    GG_STAMP(4);
+}
+
 // ---- TN products (the weight gradients: C = A^T B, A [K,M], B [K,N], K = the ~10^3 relation rows) without LDS staging ------
 // In this form BOTH operands are stored with the tile's 32 rows / columns contiguous, which is exactly the fragment layout of
 // v_mfma_f32_32x32x2_f32 (lane (r, h) holds the element of row / column r at k0 + h): a wave's fragment load is two fully
@@ -436,6 +580,11 @@ __global__ __launch_bounds__(kBlock, 4) void grouped_gemm_kernel(const GTable ta
         grouped_tile_tn(t, tile, lds);
         return;
     }
+    if (t.big) {
+        if (t.tb) grouped_tile64<true>(t, tile, lds);
+        else grouped_tile64<false>(t, tile, lds);
+        return;
+    }
     // an RC panel (32 tile columns contiguous) takes vector loads only where the whole 32-column tile lies inside the operand
     const int m0t = (tile / t.tiles_n) * 32, n0t = (tile % t.tiles_n) * 32;
     const bool va = (t.vec & 1) != 0 && (!t.ta || m0t + 32 <= t.M), vb = (t.vec & 2) != 0 && (t.tb || n0t + 32 <= t.N);
@@ -516,6 +665,11 @@ int jmac_gemm_trace_buffer(unsigned long long* buf) {
 }
 #endif
 
+static int64_t big_rows() {                          // rows from which a product takes 64x64 tiles (JMAC_GG_TILE64_ROWS: A/B switch)
+    static const int64_t rows = [] { const char* e = getenv("JMAC_GG_TILE64_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)2048; }();
+    return rows;
+}
+
 int jmac_gemm_grouped_f32(const jmac_gemm_task_t* tasks, int32_t n_tasks, jmac_stream_t stream) {
     if (n_tasks < 0 || n_tasks > kMaxTasks || (n_tasks > 0 && !tasks)) return JMAC_EINVAL;
     GTable tab{};
@@ -547,8 +701,12 @@ int jmac_gemm_grouped_f32(const jmac_gemm_task_t* tasks, int32_t n_tasks, jmac_s
         const bool b_al = u.ldb % 4 == 0 && aligned16(u.B);
         const bool k4 = u.K >= 4 && u.K % 4 == 0;
         t.vec = ((a_al && (!a_kc || k4)) ? 1 : 0) | ((b_al && (!b_kc || k4)) ? 2 : 0);
-        t.tiles_n = (int32_t)((u.N + 31) / 32);
-        const int64_t nt = (int64_t)((u.M + 31) / 32) * t.tiles_n;
+        // 64x64 tiles for long tables: A row-major with vector loads, B either K-contiguous (vector loads) or N-contiguous with
+        // N % 4 == 0 (ragged column tiles then end on a quad boundary)
+        t.big = (!u.transA && (t.vec & 1) && (t.vec & 2) && (u.transB || u.N % 4 == 0) && u.M >= big_rows() && u.N >= 64) ? 1 : 0;
+        const int ts = t.big ? 64 : 32;
+        t.tiles_n = (int32_t)((u.N + ts - 1) / ts);
+        const int64_t nt = (int64_t)((u.M + ts - 1) / ts) * t.tiles_n;
         if (nt >= 65536 * 16) return JMAC_ERANGE;
         t.tile_begin = (int32_t)nt;                    // this launch form: the task's tile count
         const int64_t nx = 8 * ((nt + 7) / 8);         // block ids of the XCD-aware order (8 * ceil(tiles / 8))

@@ -206,7 +206,8 @@ def test_fused_encoder_on_a_slice_of_the_tables():
     assert float(ge[:e0].abs().max()) == 0.0 and float(ge[e1:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("shape", [(203, 76, 50), (451, 172, 100)], ids=["203x76x50", "451x172x100"])
+@pytest.mark.parametrize("shape", [(203, 76, 50), (451, 172, 100), (2100, 172, 100)],
+                         ids=["203x76x50", "451x172x100", "2100x172x100-tiles64"])
 @pytest.mark.parametrize("seed", [0, 1])
 def test_grouped_gemm_forms_and_epilogues(seed, shape):
     from jmac_amd.encoder import (ACT_LEAKY, ACT_RELU, DACT_LEAKY, DACT_RELU, gemm_task, grouped_gemm)
