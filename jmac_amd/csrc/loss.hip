@@ -118,7 +118,15 @@ __global__ __launch_bounds__(kBlock) void triple_l1_bwd_kernel(const float* __re
         if (x >= ma.B) return -mg_c * w(gscore[(x - ma.B) % ma.B] - gscore[x]);
         const float pos = gscore[x];
         float sum = 0.f;
-        for (int64_t k = 0; k < ma.K; ++k) sum += w(pos - gscore[ma.B + k * ma.B + x]);     // same order as margin_loss_bwd_kernel
+        int64_t k = 0;
+        for (; k + 8 <= ma.K; k += 8) {                        // eight negatives in flight per trip (the loop is a latency chain
+            float nv[8];                                       // otherwise); same summation order as margin_loss_bwd_kernel
+#pragma unroll
+            for (int u = 0; u < 8; ++u) nv[u] = gscore[ma.B + (k + u) * ma.B + x];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += w(pos - nv[u]);
+        }
+        for (; k < ma.K; ++k) sum += w(pos - gscore[ma.B + k * ma.B + x]);
         return mg_c * sum;
     };
     const int lane = lane_id();
