@@ -1065,6 +1065,10 @@ def main():
                 "frac": bbytes / (prof["rel_attn_bwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "avg_launch_ms": prof["rel_attn_bwd"][0], "back_to_back_ms": raw["bwd_ms"],
                 "implementation_bytes": synth.bwd_implementation_bytes(w.N, w.E, w.d)}
+    if a.data == "real" and a.dim == 300:             # the three launches' HBM-side bytes from the committed PMC passes
+        parts = [pmc_traffic("ja", k, ("r3",)) for k in ("rel_attn_bwd_dst_kernel", "rel_attn_bwd_gather_kernel", "bwd_finalize_kernel")]
+        roof_bwd["traffic"] = float(sum(parts)) if all(p is not None for p in parts) else None
+        roof_bwd["traffic_source"] = roof_src
 
     line = {"metric": "gnn_layer_edges_per_s", "value": value, "unit": "edges/s", "n_gpus": 1, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
