@@ -16,6 +16,7 @@ Extra objects on the same line:
   scoring       scored triples/s: B=1000 queries x all N candidates x 2 layers + filtered rank
   sim           config-5 shape: fp32 MFMA similarity GEMM (TFLOP/s, fraction of the f32 matrix peak), get_neg, CSLS test
   union         config 3 (union of the five KGs, bf16 tables): encoder forward + fused scoring vs all 56 589 entities
+  pair          the reference's real training step: completion_loss on the real el + ja KG pair, both encoders as one launch set
   synth         config 4 (1M entities / 20M triples / 1k relations): aggregation kernel GB/s at HBM scale
 """
 import argparse
@@ -344,6 +345,144 @@ class JaWorkload:
             loss = self.loss_fn(align_out, comp, rel, h, r, t, pairs, margin, orc.triple_l1_score, orc.pair_cosine_distance)
             loss.backward()
             return loss
+        return step
+
+
+class PairWorkload:
+    """The reference's training step on a KG PAIR (train.py:338-359 -> JMAC.completion_loss, src/jmac_model.py:316-380): the REAL
+    DBP-5L el (supporter: train + val triples, src/knowledgegraph.py:18-19) and ja (target: train triples) KGs, both encoded
+    per batch with the SAME layer weights (:325-326), the L1 margin loss on a batch of the target's triples and
+    alignment_loss_simple on the pair's seed links (both layers), backward, Adam.  ``batched``: JMAC.batched_pairs -- the two
+    encoders as ONE launch set on the block-diagonal union of the two graphs (per-KG BatchNorm statistics) or two
+    forward_base calls."""
+
+    def __init__(self, a, device, seed=1234, batched=True):
+        from jmac_amd.data import edges_from_triples, load_dbp5l_arrays
+        from jmac_amd.model import JMAC
+        self.a = a
+        z = load_dbp5l_arrays(REAL_DATA)
+        nr = int(z["n_relation_lines"]) + 1
+        tri1 = np.concatenate((z["el.train"], z["el.val"])).astype(np.int64)      # supporter: train + val
+        tri2 = z["ja.train"].astype(np.int64)
+        n1, n2 = int(z["el.num_entity"]), int(z["ja.num_entity"])
+        ei1, et1 = edges_from_triples(tri1, False)                                 # train-mode graphs (train.py:130-132)
+        ei2, et2 = edges_from_triples(tri2, False)
+        self.n, self.nr, self.d = (n1, n2), nr, a.dim
+        self.E = (ei1.shape[1], ei2.shape[1])
+        rng = np.random.default_rng(seed + 1)
+        torch.manual_seed(seed)
+        self.margs = make_args(a.dim, a.batch, a.negatives, device)
+        name_emb = rng.standard_normal((n1 + n2, 300)).astype(np.float32)
+        self.model = JMAC(self.margs, name_emb, 2 * nr, n1 + n2).to(device)
+        self.model.ent_info_att = self.model.ent_info_att.to(device)
+        self.model.batched_pairs = bool(batched)
+        self.g1 = (torch.from_numpy(ei1).to(device), torch.from_numpy(et1).to(device))
+        self.g2 = (torch.from_numpy(ei2).to(device), torch.from_numpy(et2).to(device))
+        B, K = a.batch, a.negatives
+        trip = rng.integers(0, len(tri2), B)                                       # a batch of the TARGET's triples: source=False
+        bh, br, bt = (tri2[trip, c] for c in range(3))
+        self.data = {"batch_h": torch.from_numpy(np.tile(bh, K + 1)).to(device),
+                     "batch_r": torch.from_numpy(np.tile(br, K + 1)).to(device),
+                     "batch_t": torch.from_numpy(np.concatenate([bt, rng.integers(0, n2, B * K)])).to(device)}
+        self.links = torch.from_numpy(z["seed_train_pairs"].astype(np.int64)).to(device)     # (el id, ja id)
+        self.feed = {"links": self.links, "ent_bases1": [0, n1], "rel_bases1": [0, nr], "ent_bases2": [n1, n1 + n2],
+                     "rel_bases2": [nr, 2 * nr]}
+        self.state_cpu = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
+        self.name_emb = torch.from_numpy(name_emb)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True, capturable=True)
+        self.model.train()
+
+    def blocks(self):
+        f = self.feed
+        return [(self.g1[0], self.g1[1], f["ent_bases1"], f["rel_bases1"]), (self.g2[0], self.g2[1], f["ent_bases2"], f["rel_bases2"])]
+
+    def loss(self):
+        return self.model.completion_loss(self.data, self.g1[0], self.g1[1], self.g2[0], self.g2[1], self.feed, source=False)
+
+    def step(self):
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.loss()
+        loss.backward()
+        self.opt.step()
+        return loss
+
+    # ---- the oracle on this very step: two forward_name calls one after the other on the SAME parameters and BatchNorm
+    # ---- buffers, then completion_loss (checker only: parity below, tests/test_gpu_pair.py; CPU baseline leg) -------------
+    def oracle_pass(self, dtype=torch.float32, kink_masks=None, backward=False, l1_sign_masks=None):
+        """(loss, [forward_name outputs of KG 1, of KG 2], {param: grad}, BatchNorm buffers after the two calls).
+        ``kink_masks``: per KG a dict as orc.forward_name takes it; ``l1_sign_masks``: per completion layer a bool [T, d]
+        pattern for the L1 score terms (see JaWorkload.oracle_pass)."""
+        import oracle.jmac_oracle as orc
+        skip = ("running", "num_batches", "margin_completion")
+        st = {k: v.clone().to(dtype if v.dtype.is_floating_point else v.dtype) for k, v in self.state_cpu.items()}
+        for k, v in st.items():
+            if backward and v.dtype.is_floating_point and not any(s_ in k for s_ in skip):
+                v.requires_grad_(True)
+        bn = {k: v.clone() for k, v in st.items() if "running" in k}
+        f = self.feed
+        outs = []
+        for gi, (g, eb, rb) in enumerate(((self.g1, f["ent_bases1"], f["rel_bases1"]), (self.g2, f["ent_bases2"], f["rel_bases2"]))):
+            outs.append(orc.forward_name(st, self.name_emb.to(dtype), g[0].cpu(), g[1].cpu(), eb, rb, 2, 0.05, "sub", True, bn,
+                                         kink_masks=kink_masks[gi] if kink_masks is not None else None))
+        h, r, t = (self.data[k].cpu() for k in ("batch_h", "batch_r", "batch_t"))
+        links = self.links.cpu()
+        margin = st["margin_completion"].detach()
+        B = self.a.batch
+        self.l1_flips = 0
+        loss = 0
+        for layer in range(2):
+            ent, rel = outs[1][1][layer], outs[1][2][layer]                    # source=False: the batch is the second KG's
+            v = (ent[h] + rel[r]) - ent[t]
+            if l1_sign_masks is not None:
+                m = l1_sign_masks[layer]
+                self.l1_flips += int((((v > 0) != m) & (v != 0)).sum())
+                score = torch.where(m, v, -v).sum(-1).flatten()
+            else:
+                score = torch.norm(v, 1, -1).flatten()
+            pos = score[:B].view(-1, B).permute(1, 0)
+            neg = score[B:].view(-1, B).permute(1, 0)
+            loss = loss + torch.max(pos - neg, -margin).mean() + margin
+            loss = loss + orc.pair_cosine_distance(outs[0][1][layer], links[:, 0], outs[1][1][layer], links[:, 1]).mean()
+        grads = {}
+        if backward:
+            loss.backward()
+            grads = {k: v.grad for k, v in st.items() if v.requires_grad}
+        return loss.detach(), outs, grads, bn
+
+    def check_against_oracle(self, tol=1e-4):
+        """The step about to be timed against the oracle's two separate forward_name calls (dropout off): loss, both KGs'
+        completion layer, and the BatchNorm running estimates after the step's two (reference) / one stacked (here) pass."""
+        m = self.model
+        p_drop = m.completion_dropout.p
+        m.completion_dropout.p = 0.0
+        try:
+            with torch.no_grad():
+                loss = self.loss()
+            rm = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if "running" in k}
+            m.load_state_dict({k: v.to(self.links.device) for k, v in self.state_cpu.items()}, strict=True)
+            with torch.no_grad():
+                got = m.forward_blocks(self.blocks())
+            torch.cuda.synchronize()
+        finally:
+            m.completion_dropout.p = p_drop
+        m.load_state_dict({k: v.to(self.links.device) for k, v in self.state_cpu.items()}, strict=True)
+        o_loss, outs, _, bn = self.oracle_pass(torch.float32)
+
+        def rel(a, b):
+            a, b = a.detach().double().cpu(), b.detach().double()
+            return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        res = {"loss_gpu": float(loss), "loss_oracle": float(o_loss), "loss_rel_err": abs(float(loss) - float(o_loss)) / abs(float(o_loss)),
+               "comp_layer1_rel_err": [rel(got[k][1][1], outs[k][1][1]) for k in range(2)],
+               "align_out_rel_err": [rel(got[k][0], outs[k][0]) for k in range(2)],
+               "bn_running_rel_err": max(rel(rm[k], bn[k]) for k in bn), "tol": tol,
+               "what": "completion_loss on the real el + ja pair (dropout off) vs the oracle's two forward_name calls + loss, fp32"}
+        res["ok"] = bool(res["loss_rel_err"] <= tol and max(res["comp_layer1_rel_err"]) <= tol and max(res["align_out_rel_err"]) <= tol
+                         and res["bn_running_rel_err"] <= tol)
+        return res
+
+    def cpu_step_fn(self):
+        def step():
+            return self.oracle_pass(torch.float32, backward=True)[0]
         return step
 
 
@@ -800,6 +939,63 @@ def union_bench(a, device, cpu=True):
     return res
 
 
+def pair_bench(a, device, rank, ms_single, cpu=True):
+    """The reference's real training step: JMAC.completion_loss on a KG PAIR (real el + ja), both encoders + backward + Adam as
+    one hipGraph.  Timed twice: the two KGs as ONE launch set (JMAC.batched_pairs, the product's default) and as two
+    forward_base calls; the oracle's step on the host cores beside it."""
+    def timed(batched):
+        if not a.no_gemm_tuning:
+            enable_gemm_tuning(rank)                       # the stacked row counts are new GEMM shapes
+        w = PairWorkload(a, device, seed=1234, batched=batched)
+        parity = w.check_against_oracle() if (batched and not a.no_parity_check) else None
+        for _ in range(2):
+            w.step()
+        torch.cuda.synchronize()
+        if not a.no_gemm_tuning:
+            freeze_gemm_tuning()
+        fn, mode = w.step, "eager"
+        if not a.no_graph:
+            try:
+                g = try_capture(w)
+                fn, mode = g.replay, "hipgraph"
+            except Exception as ex:                         # pragma: no cover
+                sys.stderr.write("pair step: hipGraph capture failed (%s); running eager\n" % (ex,))
+                torch.cuda.synchronize()
+        n = max(20, a.steps)
+        el = time_steps(fn, n, a.warmup, False)
+        return w, el / n * 1e3, mode, parity
+    w, ms, mode, parity = timed(True)
+    if parity is not None and not parity["ok"]:
+        raise SystemExit("bench.py: the pair step does not match the oracle: %s" % json.dumps(parity))
+    e_all = 3 * (w.E[0] + w.E[1])
+    res = {"workload": "JMAC.completion_loss on the REAL DBP-5L el (supporter, train+val) + ja (target) pair: N=%d+%d E=%d+%d nr=2x%d "
+                       "d=%d; both KGs encoded per batch (3 RelationAwareLayer calls each), L1 margin loss on %dx(1+%d) ja triples + "
+                       "alignment_loss_simple on %d seed links, backward, Adam"
+                       % (w.n[0], w.n[1], w.E[0], w.E[1], w.nr, w.d, a.batch, a.negatives, int(w.links.shape[0])),
+           "exec": mode, "ms_per_step": ms, "edges_per_s": e_all / (ms * 1e-3), "edges_counted_per_step": e_all,
+           "batched": "one launch set on the block-diagonal union of the two graphs, per-KG BatchNorm statistics "
+                      "(JMAC.forward_stacked)",
+           "ms_single_kg_step": ms_single, "ratio_to_single_kg_step": ms / ms_single if ms_single else None,
+           "parity": parity}
+    del w
+    try:
+        w2, ms2, mode2, _ = timed(False)
+        res["separate_calls_ms_per_step"] = ms2
+        res["separate_calls_exec"] = mode2
+        res["speedup_over_separate_calls"] = ms2 / ms
+        if cpu:
+            cstep = w2.cpu_step_fn()
+            cs, n = _cpu_median_s(cstep, n=3, warm=1, budget_s=12.0)
+            res["cpu"] = {"kind": "port", "cores": torch.get_num_threads(), "s_per_step": cs, "edges_per_s": e_all / cs,
+                          "sample": "median of %d steps of the oracle (two forward_name calls + completion_loss + backward, "
+                                    "un-factorised reference formulation, PyTorch CPU) on the same pair and batch" % n}
+            res["gpu_over_cpu"] = cs / (ms * 1e-3)
+        del w2
+    except Exception as ex:                                 # pragma: no cover
+        res["separate_calls_error"] = str(ex)
+    return res
+
+
 def synth_cpu_layer(scale, d):
     """config 4 down-scaled (E = 20M x scale) through the oracle's layer on the host cores, fwd and
     fwd+bwd, one call each; the full-size figure is the linear extrapolation in E (stated in the output)."""
@@ -1096,6 +1292,13 @@ def main():
         line["union"] = union_bench(a, device, cpu=cpu_on)
     except Exception as ex:                          # pragma: no cover
         line["union"] = {"error": str(ex)}
+    if a.data == "real":
+        try:
+            line["pair"] = pair_bench(a, device, rank, ms, cpu=cpu_on)
+        except SystemExit:
+            raise
+        except Exception as ex:                      # pragma: no cover
+            line["pair"] = {"error": str(ex)}
 
     if cpu_on:
         # PyTorch-CPU scales poorly past one socket's worth of cores on these small ops (256 threads ran 30x

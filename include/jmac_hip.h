@@ -215,6 +215,28 @@ int jmac_bn_tanh_bwd2_f32(const float* x, int64_t ldx, const float* y, int64_t l
                           int32_t training, float* gx, int64_t ldgx, float* gweight, float* gbias,
                           void* ws, size_t ws_bytes, jmac_stream_t stream);
 
+/* Segmented form (train mode): the N rows are a STACK of `nblocks` row blocks, h_blk_ptr [nblocks+1] (HOST array, h_blk_ptr[0] = 0)
+ * -- the KGs of one launch set.  The reference's training step encodes two KGs per batch with one set of layer weights
+ * (src/jmac_model.py:325-326, 263-264: forward_base(graph1), forward_base(graph2)); each of those calls normalises with the
+ * batch statistics of ITS rows and moves the layer's running estimates once.  Here every block gets its own statistics
+ * (save_mean / save_invstd [nblocks, d]); weight / bias / running_mean / running_var are the layer's; the running estimates
+ * are updated block after block in the order h_order [nblocks] (HOST; NULL = 0,1,2,...; a permutation: the reference's
+ * call order), i.e. r <- (1-m)((1-m) r + m b_first) + m b_second ...; the caller bumps num_batches_tracked by nblocks.
+ * The backward sums grad weight / grad bias over the blocks (shared parameters) and applies every block's own sums and
+ * row count.  nblocks <= JMAC_BN_MAX_BLOCKS; blocks must be non-empty. */
+#define JMAC_BN_MAX_BLOCKS 16
+size_t jmac_bn_tanh_seg_workspace_bytes(int32_t nblocks, int64_t d);
+int jmac_bn_tanh_seg_fwd2_f32(const float* x, int64_t ldx, int64_t d, int32_t nblocks, const int64_t* h_blk_ptr,
+                              const int32_t* h_order, const float* weight, const float* bias,
+                              float* running_mean, float* running_var, float momentum, float eps, float* y,
+                              int64_t ldy, float* y2, int64_t ldy2, float* save_mean, float* save_invstd,
+                              void* ws, size_t ws_bytes, jmac_stream_t stream);
+int jmac_bn_tanh_seg_bwd2_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy,
+                              int64_t ldgy, const float* gy2, int64_t ldgy2, int64_t d, int32_t nblocks,
+                              const int64_t* h_blk_ptr, const float* weight, const float* save_mean,
+                              const float* save_invstd, float* gx, int64_t ldgx, float* gweight, float* gbias,
+                              void* ws, size_t ws_bytes, jmac_stream_t stream);
+
 /* Phased forms of the same BatchNorm + tanh for batch statistics that span several ranks (destination-sharded
  * layer): the caller combines the per-rank moments / sums between the phases (torch.distributed over RCCL).
  *   forward : jmac_col_moments_f32 -> mean[d], m2[d] = sum (x - mean)^2 of THIS rank's N rows

@@ -76,6 +76,11 @@ _SIGS = {
                                         vp, sz, vp]),
     "jmac_bn_tanh_bwd2_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, vp, vp, vp, i32, vp, i64, vp, vp,
                                         vp, sz, vp]),
+    "jmac_bn_tanh_seg_workspace_bytes": (sz, [i32, i64]),
+    "jmac_bn_tanh_seg_fwd2_f32": (C.c_int, [vp, i64, i64, i32, C.POINTER(i64), C.POINTER(i32), vp, vp, vp, vp, f32, f32, vp, i64,
+                                            vp, i64, vp, vp, vp, sz, vp]),
+    "jmac_bn_tanh_seg_bwd2_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.POINTER(i64), vp, vp, vp, vp, i64,
+                                            vp, vp, vp, sz, vp]),
     "jmac_row_normalize_drop_fwd_f32": (C.c_int, [vp, i64, i64, i64, f32, vp, i64, f32, vp, i64, vp, vp]),
     "jmac_row_normalize_drop_bwd_f32": (C.c_int, [vp, i64, vp, vp, i64, f32, vp, i64, i64, i64, f32, vp, i64, i32, vp]),
     "jmac_row_normalize_dropseed_fwd_f32": (C.c_int, [vp, i64, i64, i64, f32, vp, f32, vp, i64, vp, vp]),

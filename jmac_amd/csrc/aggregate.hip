@@ -1233,9 +1233,10 @@ static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t l
     if (grid_env > 0) grid = (unsigned)(need < grid_env ? need : grid_env);
     else grid = (unsigned)(need <= 2 * kPersistBlocks ? need : kPersistBlocks);
     // small graphs (one wave per item) are bound by round trips, not by gathers in flight: the 2-edge group
-    // is the faster form there (DBP-5L ja: 20.4 us against 22.6 us)
+    // is the faster form there (DBP-5L ja: 20.4 us against 22.6 us).  "Small" is the host's call (jmac_amd/graph.py:
+    // schedules that carry their items' first entries inline, the real el + ja pair step: 1.571 -> 1.527 ms)
     static const int fwd_u_env = env_int("JMAC_FWD_U", 0);         // tuning knob (debug)
-    const int fwd_u = fwd_u_env ? fwd_u_env : (n_items_max <= 8 * kPersistBlocks ? 2 : 4);
+    const int fwd_u = fwd_u_env ? fwd_u_env : ((v->item_edges || n_items_max <= 8 * kPersistBlocks) ? 2 : 4);
     const bool slope01 = slope >= 0.f && slope <= 1.f;
     if (fwd_u == 2) {
         JMAC_DISPATCH_D(a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 2, D4T, TT>), dim3(grid), dim3(kBlock), 0, st, a));

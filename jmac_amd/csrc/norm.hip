@@ -277,6 +277,298 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
     }
 }
 
+
+// ---- segmented forms: the rows are a stack of `nb` blocks (KGs of one launch set: the reference's training step encodes
+// ---- two KGs per batch, src/jmac_model.py:325-326,263-264, each forward_base call with batch statistics of ITS rows) ----
+// Every block has its own batch statistics (mean / invstd [nb, d]); weight, bias and the running estimates are the layer's
+// (shared), and the running estimates are updated once per block in the callers' CALL order (seg.order), exactly what nb
+// separate forward_base calls leave behind:  r <- (1-m)((1-m) r + m b_1) + m b_2 ...
+constexpr int kMaxSeg = JMAC_BN_MAX_BLOCKS;
+struct SegTab {
+    int nb;
+    int order[kMaxSeg];        // block processed k-th by the running-statistics update
+    int gofs[kMaxSeg + 1];     // first statistics workgroup (= partial row) of each block
+    int64_t ptr[kMaxSeg + 1];  // first row of each block; ptr[nb] = rows in all
+};
+__device__ __forceinline__ int seg_of_row(const SegTab& s, int64_t r) {
+    int b = 0;
+    for (int k = 1; k < s.nb; ++k) b += r >= s.ptr[k] ? 1 : 0;
+    return b;
+}
+__device__ __forceinline__ int seg_of_group(const SegTab& s, int wg) {
+    int b = 0;
+    for (int k = 1; k < s.nb; ++k) b += wg >= s.gofs[k] ? 1 : 0;
+    return b;
+}
+
+// col_stats_partial_kernel per block: workgroup wg works on block b = seg_of_group(wg); partial row index = wg
+__global__ __launch_bounds__(kBlock) void col_stats_partial_seg_kernel(const float* __restrict__ x, int64_t ldx, SegTab seg, int D4,
+                                                                       float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* red = reinterpret_cast<float4*>(smem);   // [2][rpb][D4]
+    const int b = seg_of_group(seg, (int)blockIdx.x);
+    const int lb = (int)blockIdx.x - seg.gofs[b], gb = seg.gofs[b + 1] - seg.gofs[b];
+    const int64_t r0 = seg.ptr[b], r1 = seg.ptr[b + 1];
+    const int rpb = kBlock / D4 > 0 ? kBlock / D4 : 1;
+    const int tid = threadIdx.x;
+    for (int cbase = 0; cbase < D4; cbase += kBlock) {
+        const int rsub = D4 >= kBlock ? 0 : tid / D4;
+        const int c4 = D4 >= kBlock ? cbase + tid : tid % D4;
+        const bool active = (D4 >= kBlock ? c4 < D4 : tid < rpb * D4);
+        float4 s1 = f4zero(), s2 = f4zero();
+        if (active) {
+            const float4 K = ld4(x + r0 * ldx + c4 * 4);
+            for (int64_t r = r0 + (int64_t)lb * rpb + rsub; r < r1; r += (int64_t)gb * rpb) {
+                float4 v = ld4(x + r * ldx + c4 * 4);
+                v.x -= K.x; v.y -= K.y; v.z -= K.z; v.w -= K.w;
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+            }
+        }
+        if (D4 >= kBlock) {
+            if (active) {
+                st4(partial + ((int64_t)blockIdx.x * 2 + 0) * D4 * 4 + c4 * 4, s1);
+                st4(partial + ((int64_t)blockIdx.x * 2 + 1) * D4 * 4 + c4 * 4, s2);
+            }
+        } else {
+            if (active) {
+                red[(0 * rpb + rsub) * D4 + c4] = s1;
+                red[(1 * rpb + rsub) * D4 + c4] = s2;
+            }
+            __syncthreads();
+            if (tid < D4) {
+                float4 a1 = red[tid], a2 = red[rpb * D4 + tid];
+                for (int q = 1; q < rpb; ++q) {
+                    float4 b1 = red[q * D4 + tid], b2 = red[(rpb + q) * D4 + tid];
+                    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+                    a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
+                }
+                st4(partial + ((int64_t)blockIdx.x * 2 + 0) * D4 * 4 + tid * 4, a1);
+                st4(partial + ((int64_t)blockIdx.x * 2 + 1) * D4 * 4 + tid * 4, a2);
+            }
+            break;
+        }
+    }
+}
+
+// bn_reduce_finalize_kernel over the blocks in CALL order: a workgroup owns 16 features, reduces block after block and
+// carries the running estimates of its features through the blocks in registers
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_seg_kernel(const float* __restrict__ partial, SegTab seg,
+                                                                      const float* __restrict__ x, int64_t ldx, int d, float eps,
+                                                                      float momentum, float* __restrict__ running_mean,
+                                                                      float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                                      float* __restrict__ save_invstd) {
+    __shared__ float red1[RF_LANES][RF_COLS], red2[RF_LANES][RF_COLS];
+    const int cl = threadIdx.x % RF_COLS, rl = threadIdx.x / RF_COLS;
+    const int c = blockIdx.x * RF_COLS + cl;
+    float rm = 0.f, rv = 0.f;
+    if (rl == 0 && c < d) {
+        if (running_mean) rm = running_mean[c];
+        if (running_var) rv = running_var[c];
+    }
+    for (int k = 0; k < seg.nb; ++k) {
+        const int b = seg.order[k];
+        const int p0 = seg.gofs[b], p1 = seg.gofs[b + 1];
+        float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+        if (c < d) {
+            int p = p0 + rl;
+            for (; p + RF_LANES < p1; p += 2 * RF_LANES) {
+                a1 += partial[(int64_t)p * 2 * d + c];
+                a2 += partial[(int64_t)p * 2 * d + d + c];
+                b1 += partial[(int64_t)(p + RF_LANES) * 2 * d + c];
+                b2 += partial[(int64_t)(p + RF_LANES) * 2 * d + d + c];
+            }
+            if (p < p1) {
+                a1 += partial[(int64_t)p * 2 * d + c];
+                a2 += partial[(int64_t)p * 2 * d + d + c];
+            }
+        }
+        red1[rl][cl] = a1 + b1;
+        red2[rl][cl] = a2 + b2;
+        __syncthreads();
+        if (rl == 0 && c < d) {
+            float s1 = red1[0][cl], s2 = red2[0][cl];
+#pragma unroll 8
+            for (int r = 1; r < RF_LANES; ++r) {
+                s1 += red1[r][cl];
+                s2 += red2[r][cl];
+            }
+            const int64_t nrow = seg.ptr[b + 1] - seg.ptr[b];
+            const float n = (float)nrow;
+            const float mshift = s1 / n;
+            const float mean = x[seg.ptr[b] * ldx + c] + mshift;
+            float var = s2 / n - mshift * mshift;
+            var = var > 0.f ? var : 0.f;
+            save_mean[(int64_t)b * d + c] = mean;
+            save_invstd[(int64_t)b * d + c] = rsqrtf(var + eps);
+            rm = (1.f - momentum) * rm + momentum * mean;
+            const float unbiased = nrow > 1 ? var * n / (n - 1.f) : var;
+            rv = (1.f - momentum) * rv + momentum * unbiased;
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && c < d) {
+        if (running_mean) running_mean[c] = rm;
+        if (running_var) running_var[c] = rv;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bn_tanh_apply_seg_kernel(const float* __restrict__ x, int64_t ldx, SegTab seg, int D4,
+                                                                   const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   float* __restrict__ y, int64_t ldy, float* __restrict__ y2,
+                                                                   int64_t ldy2) {
+    const int64_t total = seg.ptr[seg.nb] * D4;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / D4;
+        const int c4 = (int)(i % D4);
+        const int64_t so = (int64_t)seg_of_row(seg, r) * D4 * 4;
+        const float4 v = ld4(x + r * ldx + c4 * 4);
+        const float4 mu = ld4(mean + so + c4 * 4), is = ld4(invstd + so + c4 * 4), w = ld4(weight + c4 * 4), b = ld4(bias + c4 * 4);
+        float4 o;
+        o.x = tanhf(fmaf((v.x - mu.x) * is.x, w.x, b.x));
+        o.y = tanhf(fmaf((v.y - mu.y) * is.y, w.y, b.y));
+        o.z = tanhf(fmaf((v.z - mu.z) * is.z, w.z, b.z));
+        o.w = tanhf(fmaf((v.w - mu.w) * is.w, w.w, b.w));
+        st4(y + r * ldy + c4 * 4, o);
+        if (y2) st4(y2 + r * ldy2 + c4 * 4, o);
+    }
+}
+
+// bn_bwd_partial_kernel per block (mean / invstd of the workgroup's block)
+__global__ __launch_bounds__(kBlock) void bn_bwd_partial_seg_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                    const float* __restrict__ y, int64_t ldy,
+                                                                    const float* __restrict__ gy, int64_t ldgy,
+                                                                    const float* __restrict__ gy2, int64_t ldgy2, SegTab seg, int D4,
+                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                    float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* red = reinterpret_cast<float4*>(smem);
+    const int b = seg_of_group(seg, (int)blockIdx.x);
+    const int lb = (int)blockIdx.x - seg.gofs[b], gb = seg.gofs[b + 1] - seg.gofs[b];
+    const int64_t r0 = seg.ptr[b], r1 = seg.ptr[b + 1];
+    const int64_t so = (int64_t)b * D4 * 4;
+    const int rpb = kBlock / D4 > 0 ? kBlock / D4 : 1;
+    const int tid = threadIdx.x;
+    for (int cbase = 0; cbase < D4; cbase += kBlock) {
+        const int rsub = D4 >= kBlock ? 0 : tid / D4;
+        const int c4 = D4 >= kBlock ? cbase + tid : tid % D4;
+        const bool active = (D4 >= kBlock ? c4 < D4 : tid < rpb * D4);
+        float4 s1 = f4zero(), s2 = f4zero();
+        if (active) {
+            const float4 mu = ld4(mean + so + c4 * 4), is = ld4(invstd + so + c4 * 4);
+            for (int64_t r = r0 + (int64_t)lb * rpb + rsub; r < r1; r += (int64_t)gb * rpb) {
+                const float4 xv = ld4(x + r * ldx + c4 * 4), yv = ld4(y + r * ldy + c4 * 4);
+                float4 g = ld4(gy + r * ldgy + c4 * 4);
+                if (gy2) {
+                    const float4 g2 = ld4(gy2 + r * ldgy2 + c4 * 4);
+                    g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+                }
+                const float gz0 = g.x * (1.f - yv.x * yv.x), gz1 = g.y * (1.f - yv.y * yv.y);
+                const float gz2 = g.z * (1.f - yv.z * yv.z), gz3 = g.w * (1.f - yv.w * yv.w);
+                s1.x += gz0; s1.y += gz1; s1.z += gz2; s1.w += gz3;
+                s2.x = fmaf(gz0, (xv.x - mu.x) * is.x, s2.x); s2.y = fmaf(gz1, (xv.y - mu.y) * is.y, s2.y);
+                s2.z = fmaf(gz2, (xv.z - mu.z) * is.z, s2.z); s2.w = fmaf(gz3, (xv.w - mu.w) * is.w, s2.w);
+            }
+        }
+        if (D4 >= kBlock) {
+            if (active) {
+                st4(partial + ((int64_t)blockIdx.x * 2 + 0) * D4 * 4 + c4 * 4, s1);
+                st4(partial + ((int64_t)blockIdx.x * 2 + 1) * D4 * 4 + c4 * 4, s2);
+            }
+        } else {
+            if (active) {
+                red[(0 * rpb + rsub) * D4 + c4] = s1;
+                red[(1 * rpb + rsub) * D4 + c4] = s2;
+            }
+            __syncthreads();
+            if (tid < D4) {
+                float4 a1 = red[tid], a2 = red[rpb * D4 + tid];
+                for (int q = 1; q < rpb; ++q) {
+                    float4 b1 = red[q * D4 + tid], b2 = red[(rpb + q) * D4 + tid];
+                    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+                    a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
+                }
+                st4(partial + ((int64_t)blockIdx.x * 2 + 0) * D4 * 4 + tid * 4, a1);
+                st4(partial + ((int64_t)blockIdx.x * 2 + 1) * D4 * 4 + tid * 4, a2);
+            }
+            break;
+        }
+    }
+}
+
+// per-block sums of the backward partial rows -> bsums [nb, 2d] (sum gz | sum gz*xhat of each block) and their totals over
+// the blocks in block order -> gbw [2d] = [grad bias | grad weight] (the parameters are shared by the blocks)
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_seg_kernel(const float* __restrict__ partial, SegTab seg, int W,
+                                                                 float* __restrict__ bsums, float* __restrict__ gbias,
+                                                                 float* __restrict__ gweight, int d) {
+    __shared__ float red[RF_LANES][RF_COLS];
+    const int cl = threadIdx.x % RF_COLS, rl = threadIdx.x / RF_COLS;
+    const int c = blockIdx.x * RF_COLS + cl;
+    float total = 0.f;
+    for (int b = 0; b < seg.nb; ++b) {
+        const int p0 = seg.gofs[b], p1 = seg.gofs[b + 1];
+        float a0 = 0.f, a1 = 0.f;
+        if (c < W) {
+            int p = p0 + rl;
+            for (; p + RF_LANES < p1; p += 2 * RF_LANES) {
+                a0 += partial[(int64_t)p * W + c];
+                a1 += partial[(int64_t)(p + RF_LANES) * W + c];
+            }
+            if (p < p1) a0 += partial[(int64_t)p * W + c];
+        }
+        red[rl][cl] = a0 + a1;
+        __syncthreads();
+        if (rl == 0 && c < W) {
+            float s = red[0][cl];
+#pragma unroll 8
+            for (int r = 1; r < RF_LANES; ++r) s += red[r][cl];
+            bsums[(int64_t)b * W + c] = s;
+            total += s;
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && c < W) {
+        if (c < d) gbias[c] = total;
+        else gweight[c - d] = total;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply_seg_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                  const float* __restrict__ y, int64_t ldy,
+                                                                  const float* __restrict__ gy, int64_t ldgy,
+                                                                  const float* __restrict__ gy2, int64_t ldgy2, SegTab seg, int D4,
+                                                                  const float* __restrict__ weight, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, const float* __restrict__ bsums,
+                                                                  float* __restrict__ gx, int64_t ldgx) {
+    const int64_t total = seg.ptr[seg.nb] * D4;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / D4;
+        const int c4 = (int)(i % D4);
+        const int b = seg_of_row(seg, r);
+        const int64_t so = (int64_t)b * D4 * 4;
+        const float invn = 1.f / (float)(seg.ptr[b + 1] - seg.ptr[b]);
+        const float4 xv = ld4(x + r * ldx + c4 * 4), yv = ld4(y + r * ldy + c4 * 4);
+        float4 g = ld4(gy + r * ldgy + c4 * 4);
+        if (gy2) {
+            const float4 g2 = ld4(gy2 + r * ldgy2 + c4 * 4);
+            g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+        }
+        const float4 mu = ld4(mean + so + c4 * 4), is = ld4(invstd + so + c4 * 4), w = ld4(weight + c4 * 4);
+        const float4 gb = ld4(bsums + 2 * so + c4 * 4), gw = ld4(bsums + 2 * so + D4 * 4 + c4 * 4);
+        float4 o;
+#define JMAC_BN_BWD(comp)                                                                 \
+        {                                                                                 \
+            const float gz = g.comp * (1.f - yv.comp * yv.comp);                          \
+            const float xh = (xv.comp - mu.comp) * is.comp;                               \
+            o.comp = w.comp * is.comp * (gz - invn * (gb.comp + xh * gw.comp));           \
+        }
+        JMAC_BN_BWD(x) JMAC_BN_BWD(y) JMAC_BN_BWD(z) JMAC_BN_BWD(w)
+#undef JMAC_BN_BWD
+        st4(gx + r * ldgx + c4 * 4, o);
+    }
+}
+
 inline unsigned stat_grid(int64_t N, int D4) {
     const int rpb = kBlock / D4 > 0 ? kBlock / D4 : 1;
     int64_t need = (N + rpb - 1) / rpb;
@@ -624,6 +916,78 @@ int jmac_row_normalize_dropseed_bwd_f32(const float* x, int64_t ldx, const float
     DropSrc ds;
     if (int rc = seeded_src(seed, p_drop, ds)) return rc;
     return drop_bwd(x, ldx, inv, ds, true, g, ldg, N, d, eps, gx, ldgx, accumulate, stream);
+}
+
+// ---- segmented BatchNorm + tanh (block-batched encoder: several KGs in one launch set) ------------------------------
+static int make_seg(int32_t nblocks, const int64_t* blk_ptr, const int32_t* order, int D4, SegTab& s) {
+    if (nblocks < 1 || nblocks > kMaxSeg || !blk_ptr || blk_ptr[0] != 0) return JMAC_EINVAL;
+    s.nb = nblocks;
+    unsigned seen = 0;
+    s.gofs[0] = 0;
+    for (int b = 0; b < kMaxSeg; ++b) s.order[b] = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        const int64_t n = blk_ptr[b + 1] - blk_ptr[b];
+        if (n <= 0) return JMAC_EINVAL;
+        s.ptr[b] = blk_ptr[b];
+        s.gofs[b + 1] = s.gofs[b] + (int)stat_grid(n, D4);
+        const int o = order ? order[b] : b;
+        if (o < 0 || o >= nblocks || (seen >> o & 1u)) return JMAC_EINVAL;    // a permutation of the blocks
+        seen |= 1u << o;
+        s.order[b] = o;
+    }
+    for (int b = nblocks; b <= kMaxSeg; ++b) s.ptr[b] = blk_ptr[nblocks];
+    for (int b = nblocks + 1; b <= kMaxSeg; ++b) s.gofs[b] = s.gofs[nblocks];
+    return JMAC_OK;
+}
+
+size_t jmac_bn_tanh_seg_workspace_bytes(int32_t nblocks, int64_t d) {
+    if (nblocks < 1) nblocks = 1;
+    if (d < 0) d = 0;
+    // partial rows of every block (<= kStatBlocks each) + the per-block backward sums [nb, 2d]
+    return align_up((size_t)nblocks * kStatBlocks * 2 * d * 4) + align_up((size_t)nblocks * 2 * d * 4) + 256;
+}
+
+int jmac_bn_tanh_seg_fwd2_f32(const float* x, int64_t ldx, int64_t d, int32_t nblocks, const int64_t* blk_ptr,
+                              const int32_t* order, const float* weight, const float* bias, float* running_mean,
+                              float* running_var, float momentum, float eps, float* y, int64_t ldy, float* y2, int64_t ldy2,
+                              float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    if (!x || !y || !weight || !bias || !save_mean || !save_invstd) return JMAC_EINVAL;
+    if (d <= 0 || d % 4 || ldx % 4 || ldy % 4 || (y2 && ldy2 % 4)) return JMAC_EDIM;
+    const int D4 = (int)(d / 4);
+    SegTab seg;
+    if (int rc = make_seg(nblocks, blk_ptr, order, D4, seg)) return rc;
+    if (!ws || ws_bytes < jmac_bn_tanh_seg_workspace_bytes(nblocks, d)) return JMAC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)ws;
+    hipLaunchKernelGGL(col_stats_partial_seg_kernel, dim3((unsigned)seg.gofs[nblocks]), dim3(kBlock), stat_smem(D4), st, x, ldx, seg,
+                       D4, partial);
+    hipLaunchKernelGGL(bn_reduce_finalize_seg_kernel, dim3((unsigned)((d + RF_COLS - 1) / RF_COLS)), dim3(1024), 0, st, partial, seg,
+                       x, ldx, (int)d, eps, momentum, running_mean, running_var, save_mean, save_invstd);
+    hipLaunchKernelGGL(bn_tanh_apply_seg_kernel, dim3(stream_grid(seg.ptr[nblocks] * D4)), dim3(kBlock), 0, st, x, ldx, seg, D4,
+                       weight, bias, save_mean, save_invstd, y, ldy, y2, ldy2);
+    return (int)hipGetLastError();
+}
+
+int jmac_bn_tanh_seg_bwd2_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
+                              const float* gy2, int64_t ldgy2, int64_t d, int32_t nblocks, const int64_t* blk_ptr,
+                              const float* weight, const float* save_mean, const float* save_invstd, float* gx, int64_t ldgx,
+                              float* gweight, float* gbias, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    if (!x || !y || !gy || !gx || !weight || !save_mean || !save_invstd || !gweight || !gbias) return JMAC_EINVAL;
+    if (d <= 0 || d % 4 || ldx % 4 || ldy % 4 || ldgy % 4 || ldgx % 4 || (gy2 && ldgy2 % 4)) return JMAC_EDIM;
+    const int D4 = (int)(d / 4);
+    SegTab seg;
+    if (int rc = make_seg(nblocks, blk_ptr, nullptr, D4, seg)) return rc;
+    if (!ws || ws_bytes < jmac_bn_tanh_seg_workspace_bytes(nblocks, d)) return JMAC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)ws;
+    float* bsums = (float*)((char*)ws + align_up((size_t)nblocks * kStatBlocks * 2 * d * 4));
+    hipLaunchKernelGGL(bn_bwd_partial_seg_kernel, dim3((unsigned)seg.gofs[nblocks]), dim3(kBlock), stat_smem(D4), st, x, ldx, y, ldy,
+                       gy, ldgy, gy2, ldgy2, seg, D4, save_mean, save_invstd, partial);
+    hipLaunchKernelGGL(bn_bwd_reduce_seg_kernel, dim3((unsigned)((2 * d + RF_COLS - 1) / RF_COLS)), dim3(1024), 0, st, partial, seg,
+                       (int)(2 * d), bsums, gbias, gweight, (int)d);
+    hipLaunchKernelGGL(bn_bwd_apply_seg_kernel, dim3(stream_grid(seg.ptr[nblocks] * D4)), dim3(kBlock), 0, st, x, ldx, y, ldy, gy, ldgy,
+                       gy2, ldgy2, seg, D4, weight, save_mean, save_invstd, bsums, gx, ldgx);
+    return (int)hipGetLastError();
 }
 
 // ---- phased forms for batch statistics that span several ranks (destination-sharded layer, jmac_amd/dist.py) ---------

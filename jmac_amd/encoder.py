@@ -147,8 +147,8 @@ def _agg_bwd(PQZ, RR, a, graph: RelGraph, slope, out, smax, sden, G, out_scale=0
     nrel = RR.shape[0]
     graph.ensure_backward_views()
     dPQZ, dRR, da = _empty(dev, N, d3), _empty(dev, nrel, 2 * d), _empty(dev, d)
-    vd, vs, vr = graph.by_dst.view(), graph.by_src.view(), graph.by_rel.view()
-    wsb = int(L.jmac_rel_attn_bwd_workspace_bytes(N, graph.E, nrel, d, graph.by_dst.n_parts_max, graph.by_src.n_parts_max,
+    vd, vs, vr = graph.by_dst_bwd.view(), graph.by_src.view(), graph.by_rel.view()
+    wsb = int(L.jmac_rel_attn_bwd_workspace_bytes(N, graph.E, nrel, d, graph.by_dst_bwd.n_parts_max, graph.by_src.n_parts_max,
                                                   graph.by_rel.n_parts_max, 1))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     ev0 = ops._ev() if ops.PROFILE is not None else None
@@ -162,20 +162,55 @@ def _agg_bwd(PQZ, RR, a, graph: RelGraph, slope, out, smax, sden, G, out_scale=0
     return dPQZ, dRR, da
 
 
-def _bn_fwd(x, bn, training, y, y2=None):
-    """tanh(BatchNorm1d(x)) into y (and y2), nn.BatchNorm1d bookkeeping included (src/jmac_model.py:52)."""
+class RowBlocks:
+    """Row blocks of a stacked launch set: the KGs that share one pass through the layer kernels (JMAC.forward_stacked).
+    ``sizes``: rows per block in stack order; ``order``: stack position of the block the reference's loop would have
+    encoded k-th (the order in which BatchNorm's running estimates see the blocks' batch statistics)."""
+
+    def __init__(self, sizes, order=None):
+        self.sizes = tuple(int(n) for n in sizes)
+        self.nb = len(self.sizes)
+        if not 1 <= self.nb <= 16 or min(self.sizes) <= 0:
+            raise ValueError("RowBlocks: 1..16 non-empty blocks")
+        off = [0]
+        for n in self.sizes:
+            off.append(off[-1] + n)
+        self.offsets = tuple(off)
+        self.order = tuple(int(o) for o in (order if order is not None else range(self.nb)))
+        if sorted(self.order) != list(range(self.nb)):
+            raise ValueError("RowBlocks: order must be a permutation of the blocks")
+        self.c_ptr = (C.c_int64 * (self.nb + 1))(*off)
+        self.c_order = (C.c_int32 * self.nb)(*self.order)
+
+
+def _bn_fwd(x, bn, training, y, y2=None, seg=None):
+    """tanh(BatchNorm1d(x)) into y (and y2), nn.BatchNorm1d bookkeeping included (src/jmac_model.py:52).  ``seg`` (RowBlocks,
+    more than one block, batch statistics): every block of rows is normalised with ITS statistics and the running estimates
+    move once per block, as one forward_base call per KG leaves them (src/jmac_model.py:325-326)."""
     L = lib()
     N, d = x.shape
     dev = x.device
-    mean, invstd = _empty(dev, d), _empty(dev, d)
-    wsb = int(L.jmac_bn_tanh_workspace_bytes(N, d))
-    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     use_batch = bool(training or not bn.track_running_stats)
+    nb = seg.nb if (seg is not None and use_batch) else 1
+    if nb > 1 and seg.offsets[-1] != N:
+        raise ValueError("RowBlocks cover %d rows, the layer has %d" % (seg.offsets[-1], N))
     if training and bn.track_running_stats:
         if _TRACKERS is not None:
             _TRACKERS.append(bn.num_batches_tracked)           # the encoder node bumps its layers' counters in ONE launch
         else:
-            bn.num_batches_tracked.add_(1)
+            bn.num_batches_tracked.add_(nb)
+    if nb > 1:
+        mean, invstd = _empty(dev, nb, d), _empty(dev, nb, d)
+        wsb = int(L.jmac_bn_tanh_seg_workspace_bytes(nb, d))
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        check(L.jmac_bn_tanh_seg_fwd2_f32(ptr(x), x.stride(0), d, nb, seg.c_ptr, seg.c_order, ptr(bn.weight), ptr(bn.bias),
+                                          ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum), float(bn.eps), ptr(y),
+                                          y.stride(0), ptr(y2), y2.stride(0) if y2 is not None else 0, ptr(mean), ptr(invstd),
+                                          ptr(ws), wsb, stream()), "jmac_bn_tanh_seg_fwd2_f32")
+        return mean, invstd, use_batch
+    mean, invstd = _empty(dev, d), _empty(dev, d)
+    wsb = int(L.jmac_bn_tanh_workspace_bytes(N, d))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     check(L.jmac_bn_tanh_fwd2_f32(ptr(x), x.stride(0), N, d, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
                                   ptr(bn.running_var), 1 if use_batch else 0, float(bn.momentum), float(bn.eps), ptr(y),
                                   y.stride(0), ptr(y2), y2.stride(0) if y2 is not None else 0, ptr(mean), ptr(invstd), ptr(ws),
@@ -183,11 +218,20 @@ def _bn_fwd(x, bn, training, y, y2=None):
     return mean, invstd, use_batch
 
 
-def _bn_bwd(x, y, gy, gy2, weight, mean, invstd, use_batch):
+def _bn_bwd(x, y, gy, gy2, weight, mean, invstd, use_batch, seg=None):
     L = lib()
     N, d = x.shape
     dev = x.device
     gx, gbw = _empty(dev, N, d), _empty(dev, 2 * d)            # gbw = [grad bias | grad weight]
+    if mean.dim() == 2:                                        # per-block statistics (segmented forward)
+        nb = seg.nb
+        wsb = int(L.jmac_bn_tanh_seg_workspace_bytes(nb, d))
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        check(L.jmac_bn_tanh_seg_bwd2_f32(ptr(x), x.stride(0), ptr(y), y.stride(0), ptr(gy), gy.stride(0), ptr(gy2),
+                                          gy2.stride(0) if gy2 is not None else 0, d, nb, seg.c_ptr, ptr(weight), ptr(mean),
+                                          ptr(invstd), ptr(gx), d, gbw.data_ptr() + d * 4, ptr(gbw), ptr(ws), wsb, stream()),
+              "jmac_bn_tanh_seg_bwd2_f32")
+        return gx, gbw
     wsb = int(L.jmac_bn_tanh_workspace_bytes(N, d))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     check(L.jmac_bn_tanh_bwd2_f32(ptr(x), x.stride(0), ptr(y), y.stride(0), ptr(gy), gy.stride(0), ptr(gy2),
@@ -394,7 +438,7 @@ class _MlpChain:
                  gemm_task(self.L12u, dWp, dW1, ta=True, accumulate=True)]], (dW1, dW2, dloop), (dL11u, dL12u)
 
 
-def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch.float32):
+def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch.float32, seg=None):
     """Node side of one RelationAwareLayer (src/jmac_model.py:44-52) given its relation tables: state for the backward.
     ``table_dtype`` bf16 (inference form, no backward: BASELINE config 3): the [P|Q|Z] table comes out of a bf16 GEMM and the
     relation table is rounded to bf16; the aggregation gathers half the bytes, its arithmetic and everything after it is fp32."""
@@ -405,15 +449,15 @@ def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch
         PQZ = torch.mm(X, wc)                                         # [P|Q|Z]: one library GEMM
     slope = float(lay.atv_mlp.negative_slope)
     pre, smax, sden = _agg_fwd(PQZ, RR, a, graph, slope)
-    mean, invstd, use_batch = _bn_fwd(pre, lay.bn, training, y, y2)
+    mean, invstd, use_batch = _bn_fwd(pre, lay.bn, training, y, y2, seg)
     return SimpleNamespace(X=X, wc=wc, RR=RR, a=a, PQZ=PQZ, pre=pre, smax=smax, sden=sden, y=y, mean=mean, invstd=invstd,
-                           use_batch=use_batch, slope=slope, bn_weight=lay.bn.weight)
+                           use_batch=use_batch, slope=slope, bn_weight=lay.bn.weight, seg=seg)
 
 
 def _layer_bwd(st, graph, gy, gy2, dX, dX_accumulate):
     """Backward of _layer_fwd.  dX: destination of the input gradient (None: not needed).  Returns dRR, dwc (node part),
     da, gbw."""
-    gpre, gbw = _bn_bwd(st.pre, st.y, gy, gy2, st.bn_weight, st.mean, st.invstd, st.use_batch)
+    gpre, gbw = _bn_bwd(st.pre, st.y, gy, gy2, st.bn_weight, st.mean, st.invstd, st.use_batch, st.seg)
     dPQZ, dRR, da = _agg_bwd(st.PQZ, st.RR, st.a, graph, st.slope, st.pre, st.smax, st.sden, gpre)
     if dX is not None:
         if dX_accumulate:
@@ -431,17 +475,30 @@ def _layer_grads(chain_grads, dwatt_dgcn, da, gbw, d):
     return [dW1, dW2, dloop, d_watt, da.view(d, 1), d_gcn, gbw[d:], gbw[:d]]
 
 
+def _layer_ok(l, d) -> bool:
+    """One layer's settings the nodes' correctness rests on: comp_op 'sub'; tanh after an affine BatchNorm with an ordinary
+    momentum; d x d weights; attention / relation-transform slopes in [0, 1] (the backward reads act'(z) from the sign of
+    act(z): wrong for a negative slope); the fused deterministic form asked for (``fused`` / ``bwd_mode`` of the layer are
+    honoured, not overridden by the model-level node); no forward hooks (the node never calls the module)."""
+    slope = float(l.atv_mlp.negative_slope)
+    return (l.comp_op == "sub" and l.layer_act is torch.tanh and l.bn.momentum is not None and l.bn.affine
+            and l.in_channels == d and l.out_channels == d and 0.0 <= slope <= 1.0
+            and getattr(l, "fused", True) and getattr(l, "bwd_mode", ops.BWD_MODE_DETERMINISTIC) == ops.BWD_MODE_DETERMINISTIC
+            and not l._forward_hooks and not l._forward_pre_hooks)
+
+
 def supported(model, info_dim: Optional[int]) -> bool:
     """What the fused nodes cover: comp_op 'sub', fp32 tables (bf16 tables under no_grad: the inference form), d % 4 == 0
-    (16-byte rows), tanh layers with an ordinary BatchNorm momentum, two GNN layers.  Everything else runs op by op
-    (jmac_amd.model)."""
+    (16-byte rows), tanh layers with an ordinary BatchNorm momentum, two GNN layers, LeakyReLU slopes in [0, 1], dropout
+    p < 1, one chunk setting for the three layers (they share the graph).  Everything else runs op by op (jmac_amd.model)."""
     a = model.args
     d = model.entity_dim
     lays = (model.conv1_alignment, model.conv2_alignment, model.conv1_completion)
     return (getattr(a, "num_gcn_layer", 2) == 2 and d % 4 == 0 and (info_dim is None or info_dim % 4 == 0)
             and _tables_ok(getattr(model, "table_dtype", torch.float32))
-            and all(l.comp_op == "sub" and l.layer_act is torch.tanh and l.bn.momentum is not None and l.bn.affine
-                    and _tables_ok(l.table_dtype) and l.in_channels == d and l.out_channels == d for l in lays))
+            and 0.0 <= float(model.atv_mlp.negative_slope) <= 1.0 and float(model.completion_dropout.p) < 1.0
+            and len({l.chunk for l in lays}) == 1
+            and all(_layer_ok(l, d) and _tables_ok(l.table_dtype) for l in lays))
 
 
 def _tables_ok(dtype) -> bool:
@@ -466,7 +523,7 @@ class _LayerNode(torch.autograd.Function):
         w2g, tt, rr = t.ch.fwd_tasks()
         run_levels([[w2g, tt], [rr]])
         y = _empty(X.device, N, d)
-        t.st = _layer_fwd(lay, X, t.wc, t.ch.RR, pl[4].reshape(-1), cfg.graph, cfg.training, y)
+        t.st = _layer_fwd(lay, X, t.wc, t.ch.RR, pl[4].reshape(-1), cfg.graph, cfg.training, y, seg=getattr(cfg, "seg", None))
         t.st.y = None                                            # the output reaches the backward through save_for_backward
         if CAPTURE is not None:                                  # tests: the very tables the kernel gathered + the relation
             CAPTURE["layer.tables"] = (t.st.PQZ, t.st.RR)        # transform's activation (its sign is its pre-activation's)
@@ -493,10 +550,9 @@ class _LayerNode(torch.autograd.Function):
 
 def layer_supported(lay, X, R) -> bool:
     d = lay.out_channels
-    return (lay.comp_op == "sub" and lay.layer_act is torch.tanh and lay.bn.momentum is not None and lay.bn.affine
-            and lay.table_dtype == torch.float32 and lay.in_channels == d and d % 4 == 0 and X.is_cuda
+    return (_layer_ok(lay, d) and lay.table_dtype == torch.float32 and d % 4 == 0 and X.is_cuda
             and X.dtype == torch.float32 and R.dtype == torch.float32 and X.dim() == 2 and X.stride(1) == 1
-            and X.stride(0) % 4 == 0 and R.is_contiguous() and R.shape[1] == d)
+            and X.stride(0) % 4 == 0 and R.is_contiguous() and R.shape[1] == d and R.shape[0] > 0)
 
 
 def layer_forward(lay, X, R, graph: RelGraph):
@@ -508,13 +564,15 @@ def layer_forward(lay, X, R, graph: RelGraph):
 # ---- forward_name ---------------------------------------------------------------------------------------------------------
 class _Cat0Slot:
     """``cat(comp0, info)`` (src/jmac_model.py:180) whose right block -- the constant name embeddings -- is written ONCE: the
-    buffer lives with the model, a forward takes it (rewriting only the left block) and its backward gives it back.  A forward
-    that finds it taken (two forwards before a backward), or another ``info``, gets a buffer of its own, as before.  ``lease``
+    buffer lives with the model (one slot per ``info`` tensor, never replaced or freed while the model lives: a captured
+    hipGraph that took it keeps a valid pointer), a forward takes it (rewriting only the left block) and its backward gives
+    it back.  A forward that finds it taken (two forwards before a backward) gets a buffer of its own, as before.  ``lease``
     counts the takers: a backward that runs after a later forward has re-used the buffer (retain_graph + an interleaved
-    forward) fails loudly instead of reading the other forward's rows."""
+    forward) fails loudly instead of reading the other forward's rows.  The slot holds a strong reference to ``info``: its
+    storage cannot be recycled for other rows while the slot's key still names it."""
 
     def __init__(self):
-        self.buf, self.key, self.busy, self.lease = None, None, False, 0
+        self.buf, self.info, self.busy, self.lease = None, None, False, 0
 
 
 class _Cat0Lease:
@@ -536,20 +594,28 @@ class _Cat0Lease:
         self.release()
 
 
-def _cat0_take(cache, info, N, d, dev) -> _Cat0Lease:
+CAT0_MAX_SLOTS = 32      # distinct name-embedding tensors a model keeps a cat buffer for (KGs + KG pairs of DBP-5L: 15)
+
+
+def _cat0_take(cache, info, N, d, dev, persistent=False) -> _Cat0Lease:
+    """``persistent``: the caller vouches that ``info`` is a device tensor it keeps (jmac_amd.model caches the device copies
+    of its name-embedding rows); only such tensors get a slot -- a temporary (a fresh ``.to(dev)`` per call) is never cached:
+    its address can come back with other rows in it."""
     di = info.shape[1]
-    key = (info.data_ptr(), tuple(info.shape), tuple(info.stride()), info._version, N, d, str(dev))
-    slot = cache.setdefault("cat0", _Cat0Slot()) if cache is not None else None
-    if slot is not None and slot.key == key and not slot.busy:
+    slots = cache.setdefault("cat0", {}) if (cache is not None and persistent) else None
+    key = (id(info), info._version, N, d, str(dev))
+    slot = slots.get(key) if slots is not None else None
+    if slot is not None and slot.info is info and not slot.busy:
         slot.busy, slot.lease = True, slot.lease + 1
         return _Cat0Lease(slot, slot.buf, True)
     buf = _empty(dev, N, d + di)
     buf[:, d:].copy_(info)
     # (never adopt a buffer allocated during a stream capture: it belongs to that graph's memory pool)
-    if slot is not None and not slot.busy and not torch.cuda.is_current_stream_capturing():   # first use / another info
-        slot.buf, slot.key, slot.busy, slot.lease = buf, key, True, slot.lease + 1
+    if slots is not None and slot is None and len(slots) < CAT0_MAX_SLOTS and not torch.cuda.is_current_stream_capturing():
+        slot = slots[key] = _Cat0Slot()
+        slot.buf, slot.info, slot.busy, slot.lease = buf, info, True, 1
         return _Cat0Lease(slot, buf, True)
-    return _Cat0Lease(slot if slot is not None else _Cat0Slot(), buf, False)
+    return _Cat0Lease(_Cat0Slot(), buf, False)
 
 
 class _EncoderName(torch.autograd.Function):
@@ -568,6 +634,9 @@ class _EncoderName(torch.autograd.Function):
             out = _EncoderName._forward(ctx, cfg, *tensors)
             done = {id(c) for c in ctx.t.bumped}
             _bump_trackers([c for c in _TRACKERS if id(c) not in done])       # (none left in practice)
+            seg = getattr(cfg, "seg", None)
+            if seg is not None and seg.nb > 1 and ctx.t.bumped:               # one forward_base call per block in the reference:
+                torch._foreach_add_(ctx.t.bumped, seg.nb - 1)                 # num_batches_tracked moves by the block count
             return out
         finally:
             _TRACKERS = None
@@ -601,7 +670,8 @@ class _EncoderName(torch.autograd.Function):
                     [fa[2], fc[2], *f2[1], mc[1]],
                     f2[2]])
         # ---- node side.  cat buffers: cat0 = [comp0 | info] (:180), cat1 = [c1n | a1] (:192), catA = [align0 | a1 | a2] (:203)
-        t.cat0_lease = _cat0_take(getattr(cfg, "cache", None), info, N, d, dev)       # right block = info, already in place
+        t.cat0_lease = _cat0_take(getattr(cfg, "cache", None), info, N, d, dev,
+                                   persistent=getattr(cfg, "info_persistent", False))     # right block = info, already in place
         t.cat0, t.cat1, t.catA = t.cat0_lease.buf, _empty(dev, N, 2 * d), _empty(dev, N, 3 * d)
         # dropout draws: two device-resident seeds from torch's generator (one tiny launch, fresh on every replay of a captured
         # step); the normalise kernels draw from them, forward and backward -- no [N, d] mask is written or read
@@ -611,14 +681,15 @@ class _EncoderName(torch.autograd.Function):
         align0 = t.catA[:, :d]
         torch.mm(t.cat0, t.w, out=align0)                                                       # :180
         a_att = [p[4].reshape(-1) for p in (pa, pc, p2)]
+        seg = getattr(cfg, "seg", None)
         t.sa = _layer_fwd(la, align0, t.wc[0], t.cha.RR, a_att[0], graph, training, t.catA[:, d:2 * d], t.cat1[:, d:],
-                          table_dtype=cfg.table_dtype)                                        # :183
+                          table_dtype=cfg.table_dtype, seg=seg)                                        # :183
         c1 = _empty(dev, N, d)
-        t.sc = _layer_fwd(lc, E, t.wc[1], t.chc.RR, a_att[1], graph, training, c1, table_dtype=cfg.table_dtype)   # :190
+        t.sc = _layer_fwd(lc, E, t.wc[1], t.chc.RR, a_att[1], graph, training, c1, table_dtype=cfg.table_dtype, seg=seg)   # :190
         t.inv1, t.drop1 = _norm_drop_fwd(c1, p_drop, training, t.cat1[:, :d], seed=sd(1))                 # :191
         t.a_in = torch.mm(t.cat1, U21)                                                          # :192
         t.s2 = _layer_fwd(l2, t.a_in, t.wc[2], t.ch2.RR, a_att[2], graph, training, t.catA[:, 2 * d:],
-                          table_dtype=cfg.table_dtype)                                        # :197
+                          table_dtype=cfg.table_dtype, seg=seg)                                        # :197
         align_out = torch.mm(t.catA, Wall)                                                      # :203
         if CAPTURE is not None:
             CAPTURE.update(conv1_alignment=(align0.clone(), Ra.detach()), conv1_completion=(E.detach(), Rc.detach()),
@@ -742,7 +813,8 @@ class _EncoderNoName(torch.autograd.Function):
         fc, mc = t.chc.fwd_tasks(), t.mlc.fwd_tasks()
         run_levels([[fc[0], fc[1], mc[0]], [fc[2], mc[1]]])
         c1 = _empty(E.device, N, d)
-        t.sc = _layer_fwd(lc, E, t.wc, t.chc.RR, pc[4].reshape(-1), cfg.graph, cfg.training, c1, table_dtype=cfg.table_dtype)
+        t.sc = _layer_fwd(lc, E, t.wc, t.chc.RR, pc[4].reshape(-1), cfg.graph, cfg.training, c1, table_dtype=cfg.table_dtype,
+                          seg=getattr(cfg, "seg", None))
         if CAPTURE is not None:
             CAPTURE.update(conv1_completion=(E.detach(), Rc.detach()))
             CAPTURE["conv1_completion.tables"] = (t.sc.PQZ, t.sc.RR)
@@ -792,21 +864,26 @@ def _cfg(model, layers, graph):
                            table_dtype=getattr(model, "table_dtype", torch.float32))
 
 
-def forward_name(model, comp_att, rel_comp, rel_align, info, graph: RelGraph):
-    """(align_out, c1, rel_c1) of JMAC.forward_name on the fused node."""
+def forward_name(model, comp_att, rel_comp, rel_align, info, graph: RelGraph, seg: Optional[RowBlocks] = None,
+                 info_persistent: bool = False):
+    """(align_out, c1, rel_c1) of JMAC.forward_name on the fused node.  ``seg``: the rows are a stack of KGs (``graph`` their
+    block-diagonal union, the relation tables stacked likewise): BatchNorm statistics per block.  ``info_persistent``: the
+    caller keeps ``info`` (a device tensor) alive and unchanged between calls -- its cat buffer may be cached."""
     la, lc, l2 = model.conv1_alignment, model.conv1_completion, model.conv2_alignment
     cfg = _cfg(model, (la, lc, l2), graph)
     cfg.training = la.training                                           # BatchNorm follows the layers' own mode
     cfg.cache = model.__dict__.setdefault("_encoder_cache", {})          # buffers that outlive a step (see _Cat0Slot)
+    cfg.seg, cfg.info_persistent = seg, bool(info_persistent)
     return _EncoderName.apply(cfg, comp_att, rel_comp, rel_align, info, model.name_linear, model.uni_linear1_1,
                               model.uni_linear2_1, model.all_linear_completion, model.rel_linear11, model.rel_linear12,
                               model.rel_linear11_uni, model.rel_linear12_uni, *_layer_inputs(la), *_layer_inputs(lc),
                               *_layer_inputs(l2))
 
 
-def forward_no_name(model, comp_att, rel_comp, graph: RelGraph):
+def forward_no_name(model, comp_att, rel_comp, graph: RelGraph, seg: Optional[RowBlocks] = None):
     """(c1, rel_c1) of JMAC.forward_no_name on the fused node."""
     lc = model.conv1_completion
     cfg = _cfg(model, (lc,), graph)
     cfg.training = lc.training
+    cfg.seg = seg
     return _EncoderNoName.apply(cfg, comp_att, rel_comp, model.rel_linear11, model.rel_linear12, *_layer_inputs(lc))

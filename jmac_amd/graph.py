@@ -8,6 +8,7 @@ is cached per tensor identity, so the drop-in layer can keep the reference's cal
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 from typing import Optional, Tuple
 
@@ -19,7 +20,11 @@ from ._lib import View, check, check_index_range, lib, ptr, require_device, stre
 DEFAULT_CHUNK = None          # None -> auto_chunk()
 # schedules of up to this many items carry the first two entries of each item inline (the forward kernel gives every
 # item its own wave there -- aggregate.hip fwd_grid -- and is bound by dependent round trips, not by bandwidth)
-INLINE_EDGES_MAX_ITEMS = 16384
+INLINE_EDGES_MAX_ITEMS = int(os.environ.get("JMAC_SMALL_ITEMS", "65536"))   # env: tuning knob (debug)
+# the by-source / by-relation views (backward passes B / C) switch to their small-graph form (short items, inline entries) on
+# their own threshold: measured on the 56 589-entity union the forward gains from the small form (136 -> 117 us fp32, 122 -> 86 us
+# bf16) while the backward loses (306 -> 346 us)
+SMALL_BWD_MAX_ITEMS = int(os.environ.get("JMAC_SMALL_BWD_ITEMS", "16384"))
 # order of a destination's edges inside its CSR row: by relation type, then input order (False: input order)
 SORT_ROWS_BY_TYPE = True
 
@@ -141,6 +146,12 @@ class RelGraph:
         self.by_dst = _Schedule(self.rowptr, N, E, chunk_dst, None, coop=small)
         if small:
             self.by_dst.build_item_edges(self.col, self.etype)
+        # pass A of the backward walks a by-destination schedule too.  Past the backward's own small-graph threshold it gets a
+        # plain one (no cooperative quarters: their partial dP rows cost more than the long rows they split; measured on the
+        # 56 589-entity union: 306 us with the plain schedule, 346 us with the forward's)
+        self.by_dst_bwd = self.by_dst
+        self._dst_bwd_plain = small and not (N + E // max(chunk, 1) + 1 <= SMALL_BWD_MAX_ITEMS)
+        self._chunk_dst = chunk_dst
         self._ei = ei
         self._bwd_ready = False
         self.dst_of_slot = None
@@ -153,6 +164,8 @@ class RelGraph:
             return
         L = lib()
         dev, E, N = self.device, self.E, self.N
+        if self._dst_bwd_plain:
+            self.by_dst_bwd = _Schedule(self.rowptr, N, E, self._chunk_dst, None, coop=False)
         if E > 0:
             self.dst_of_slot = self._ei[0].index_select(0, self.perm[:E].long()).to(torch.int32)
         else:
@@ -160,7 +173,7 @@ class RelGraph:
 
         # small graphs: shorter items (a 32-entry item is 8 dependent gather rounds in one wave; the merge pass keeps
         # four partial rows in flight per lane, so the longer partial lists cost less than the rounds they save)
-        small = self.by_dst.item_edges is not None
+        small = self.by_dst.item_edges is not None and N + E // max(self.chunk, 1) + 1 <= SMALL_BWD_MAX_ITEMS
         chunk_bwd = min(self.chunk, SMALL_BWD_CHUNK) if small else self.chunk
 
         def group(keys: torch.Tensor, n_seg: int) -> _Schedule:
@@ -216,3 +229,51 @@ class GraphCache:
 
 
 graph_cache = GraphCache()
+
+
+class UnionGraphCache:
+    """Block-diagonal union of several typed edge lists (one RelGraph over the stacked id spaces), keyed on the identity of
+    the component COO tensors.  The reference's training step encodes two KGs per batch with one set of layer weights
+    (src/jmac_model.py:325-326, 263-264); their union -- entity ids offset by the rows in front of the block, relation ids
+    by the relation rows in front of it, ONE loop relation behind all of them -- goes through the layer kernels as one
+    launch set (jmac_amd.model.JMAC.forward_stacked)."""
+
+    def __init__(self, capacity: int = 32):
+        self.capacity = capacity
+        self._d: "OrderedDict[Tuple, RelGraph]" = OrderedDict()
+
+    def get(self, parts, chunk: Optional[int] = DEFAULT_CHUNK) -> RelGraph:
+        """``parts``: sequence of (edge_index [2,E_k], edge_type [E_k], num_nodes_k, num_rel_k) in stack order."""
+        key = tuple((ei.data_ptr(), et.data_ptr(), tuple(ei.shape), ei._version, et._version, int(n), int(nr), str(ei.device))
+                    for ei, et, n, nr in parts) + (-1 if chunk is None else int(chunk),)
+        g = self._d.get(key)
+        if g is not None:
+            self._d.move_to_end(key)
+            return g
+        eis, ets = [], []
+        row0 = rel0 = 0
+        for ei, et, n, nr in parts:
+            require_device(ei, et)
+            if ei.shape[1] > 0:                     # per block: an id past its own block must not land in a neighbour's rows
+                check_index_range(ei, int(n), "edge_index (block of %d entities)" % int(n))
+                check_index_range(et, int(nr), "edge_type (block of %d relations)" % int(nr))
+            eis.append(ei.to(torch.int64) + row0)
+            ets.append(et.to(torch.int64) + rel0)
+            row0 += int(n)
+            rel0 += int(nr)
+        ei_u, et_u = torch.cat(eis, dim=1).contiguous(), torch.cat(ets).contiguous()
+        _lib.mark_index_range(ei_u, row0)
+        _lib.mark_index_range(et_u, rel0 + 1)
+        g = RelGraph(ei_u, et_u, row0, rel0 + 1, chunk)
+        # the component tensors stay alive with the entry, so that a recycled data_ptr can never alias it
+        g._key_refs = tuple((ei, et) for ei, et, _, _ in parts)
+        self._d[key] = g
+        while len(self._d) > self.capacity:
+            self._d.popitem(last=False)
+        return g
+
+    def clear(self) -> None:
+        self._d.clear()
+
+
+union_cache = UnionGraphCache()

@@ -68,7 +68,7 @@ def triple_l1_score(ent: torch.Tensor, rel: torch.Tensor, h: torch.Tensor, r: to
 
 class _PairCosine(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, e1, e2, i1, i2):
+    def forward(ctx, e1, e2, i1, i2, off1, off2):
         require_device(e1, e2, i1, i2)
         ctx.same_table = e1 is e2                     # pairs inside one table (the caller passed the same tensor twice)
         e1, e2 = _rows(e1), _rows(e2)
@@ -76,30 +76,36 @@ class _PairCosine(torch.autograd.Function):
         if e2.shape[1] != d or i2.numel() != L:
             raise ValueError("pair_cosine_distance: shapes disagree")
         dist = torch.empty(L, dtype=torch.float32, device=e1.device)
-        check(lib().jmac_pair_cosine_fwd_f32(ptr(e1), e1.stride(0), ptr(e2), e2.stride(0), ptr(i1), ptr(i2), L, d, ptr(dist),
-                                             stream()), "jmac_pair_cosine_fwd_f32")
+        check(lib().jmac_pair_cosine_fwd_f32(_wptr(e1, off1), e1.stride(0), _wptr(e2, off2), e2.stride(0), ptr(i1), ptr(i2), L, d,
+                                             ptr(dist), stream()), "jmac_pair_cosine_fwd_f32")
         ctx.save_for_backward(e1, e2, i1, i2)
+        ctx.offs = (off1, off2)
         return dist
 
     @staticmethod
     def backward(ctx, g):
         e1, e2, i1, i2 = ctx.saved_tensors
+        off1, off2 = ctx.offs
         L, d = i1.numel(), e1.shape[1]
         g = g.contiguous()
         de1 = torch.zeros((e1.shape[0], d), dtype=torch.float32, device=e1.device)
-        # both sides gathered from ONE table (pairs inside a KG): the kernel's atomics accumulate both sides' rows into one
-        # gradient buffer -- no second zero-fill, no add of the two halves afterwards
+        # both sides gathered from ONE table (pairs inside a KG, or two blocks of one stacked table): the kernel's atomics
+        # accumulate both sides' rows into one gradient buffer -- no second zero-fill, no add of the two halves afterwards
         same = ctx.same_table and e1.data_ptr() == e2.data_ptr()
         de2 = de1 if same else torch.zeros((e2.shape[0], d), dtype=torch.float32, device=e1.device)
-        check(lib().jmac_pair_cosine_bwd_f32(ptr(e1), e1.stride(0), ptr(e2), e2.stride(0), ptr(i1), ptr(i2), L, d, ptr(g),
-                                             ptr(de1), d, ptr(de2), d, stream()), "jmac_pair_cosine_bwd_f32")
-        return de1, (None if same else de2), None, None
+        check(lib().jmac_pair_cosine_bwd_f32(_wptr(e1, off1), e1.stride(0), _wptr(e2, off2), e2.stride(0), ptr(i1), ptr(i2), L, d,
+                                             ptr(g), _wptr(de1, off1), d, _wptr(de2, off2), d, stream()), "jmac_pair_cosine_bwd_f32")
+        return de1, (None if same else de2), None, None, None, None
 
 
-def pair_cosine_distance(e1: torch.Tensor, i1: torch.Tensor, e2: torch.Tensor, i2: torch.Tensor) -> torch.Tensor:
-    """``1 - sum(F.normalize(e1[i1], 2, -1) * F.normalize(e2[i2], 2, -1), 1)`` -> [L]."""
+def pair_cosine_distance(e1: torch.Tensor, i1: torch.Tensor, e2: torch.Tensor, i2: torch.Tensor, win1=None,
+                         win2=None) -> torch.Tensor:
+    """``1 - sum(F.normalize(e1[i1], 2, -1) * F.normalize(e2[i2], 2, -1), 1)`` -> [L].  ``win1`` / ``win2`` = (first row,
+    rows): the ids are local to that window of the table."""
     dev = e1.device
-    return _PairCosine.apply(e1, e2, _index(i1, e1.shape[0], dev), _index(i2, e2.shape[0], dev))
+    off1, n1 = _win(e1, win1)
+    off2, n2 = _win(e2, win2)
+    return _PairCosine.apply(e1, e2, _index(i1, n1, dev), _index(i2, n2, dev), off1, off2)
 
 
 class _MarginLoss(torch.autograd.Function):
@@ -123,12 +129,29 @@ class _MarginLoss(torch.autograd.Function):
         return dscore, None, None, None
 
 
+def _win(table: torch.Tensor, win):
+    """(row offset, rows) of the window of ``table`` the indices address: all of it, or the block of a stacked launch set
+    (JMAC.forward_stacked) the caller names -- the kernels then see the block's first row as row 0, so the reference's
+    block-local ids are used as they are and no sliced view (with its zero-fill + copy + add in the backward) exists."""
+    if win is None:
+        return 0, int(table.shape[0])
+    off, n = int(win[0]), int(win[1])
+    if off < 0 or n < 0 or off + n > table.shape[0]:
+        raise ValueError("row window [%d, %d) outside a table of %d rows" % (off, off + n, table.shape[0]))
+    return off, n
+
+
+def _wptr(t: torch.Tensor, off: int) -> int:
+    return t.data_ptr() + off * t.stride(0) * t.element_size()
+
+
 class _TripleL1Margin(torch.autograd.Function):
     """score = triple L1 distances, loss = margin ranking loss of the score vector, as ONE node: the backward derives the score
-    gradient inside the L1 adjoint kernel (no dscore vector, no launch for it)."""
+    gradient inside the L1 adjoint kernel (no dscore vector, no launch for it).  ``eoff`` / ``roff``: first row of the entity /
+    relation window the indices are local to."""
 
     @staticmethod
-    def forward(ctx, ent, rel, h, r, t, margin, B, K):
+    def forward(ctx, ent, rel, h, r, t, margin, B, K, eoff, roff):
         require_device(ent, rel, h, r, t, margin)
         ent, rel = _rows(ent), _rows(rel)
         T, d = h.numel(), ent.shape[1]
@@ -136,38 +159,42 @@ class _TripleL1Margin(torch.autograd.Function):
             raise ValueError("triple_l1_margin_loss: shapes disagree")
         score = torch.empty(T, dtype=torch.float32, device=ent.device)
         loss = torch.empty(1, dtype=torch.float32, device=ent.device)
-        check(lib().jmac_triple_l1_fwd_f32(ptr(ent), ent.stride(0), ptr(rel), rel.stride(0), ptr(h), ptr(r), ptr(t), T, B, d,
-                                           ptr(score), stream()), "jmac_triple_l1_fwd_f32")
+        check(lib().jmac_triple_l1_fwd_f32(_wptr(ent, eoff), ent.stride(0), _wptr(rel, roff), rel.stride(0), ptr(h), ptr(r), ptr(t),
+                                           T, B, d, ptr(score), stream()), "jmac_triple_l1_fwd_f32")
         check(lib().jmac_margin_loss_fwd_f32(ptr(score), B, K, ptr(margin), ptr(loss), stream()), "jmac_margin_loss_fwd_f32")
         ctx.save_for_backward(ent, rel, h, r, t, score, margin)
-        ctx.bk = (B, K)
+        ctx.bk = (B, K, eoff, roff)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         ent, rel, h, r, t, score, margin = ctx.saved_tensors
-        B, K = ctx.bk
+        B, K, eoff, roff = ctx.bk
         d = ent.shape[1]
         g = g.contiguous()
         dent = torch.zeros((ent.shape[0], d), dtype=torch.float32, device=ent.device)
         drel = torch.zeros((rel.shape[0], d), dtype=torch.float32, device=ent.device)
-        check(lib().jmac_triple_l1_margin_bwd_f32(ptr(ent), ent.stride(0), ptr(rel), rel.stride(0), ptr(h), ptr(r), ptr(t), B, K, d,
-                                                  ptr(score), ptr(margin), ptr(g), ptr(dent), d, ptr(drel), d, stream()),
+        check(lib().jmac_triple_l1_margin_bwd_f32(_wptr(ent, eoff), ent.stride(0), _wptr(rel, roff), rel.stride(0), ptr(h), ptr(r),
+                                                  ptr(t), B, K, d, ptr(score), ptr(margin), ptr(g), _wptr(dent, eoff), d,
+                                                  _wptr(drel, roff), d, stream()),
               "jmac_triple_l1_margin_bwd_f32")
-        return dent, drel, None, None, None, None, None, None
+        return dent, drel, None, None, None, None, None, None, None, None
 
 
 def triple_l1_margin_loss(ent: torch.Tensor, rel: torch.Tensor, h: torch.Tensor, r: torch.Tensor, t: torch.Tensor,
-                          batch_size: int, margin: torch.Tensor) -> torch.Tensor:
+                          batch_size: int, margin: torch.Tensor, ent_win=None, rel_win=None) -> torch.Tensor:
     """``margin_loss(triple_l1_score(ent, rel, h, r, t, period=batch_size), batch_size, margin)`` (src/jmac_model.py:345-378)
     as one autograd node; batches that are not ``B (K + 1)`` triples long, or a margin that wants a gradient, take the two
-    ops."""
+    ops.  ``ent_win`` / ``rel_win`` = (first row, rows): the ids are local to that window of the table (a KG's block of a
+    stacked encoder output)."""
     dev = ent.device
     T, B = int(h.numel()), int(batch_size)
+    eoff, en = _win(ent, ent_win)
+    roff, rn = _win(rel, rel_win)
     if B <= 0 or T <= B or (T - B) % B != 0 or margin.numel() != 1 or margin.requires_grad:
-        return margin_loss(triple_l1_score(ent, rel, h, r, t, period=B), B, margin)
-    return _TripleL1Margin.apply(ent, rel, _index(h, ent.shape[0], dev, "batch_h"), _index(r, rel.shape[0], dev, "batch_r"),
-                                 _index(t, ent.shape[0], dev, "batch_t"), margin.reshape(1).to(torch.float32), B, (T - B) // B)
+        return margin_loss(triple_l1_score(ent[eoff:eoff + en], rel[roff:roff + rn], h, r, t, period=B), B, margin)
+    return _TripleL1Margin.apply(ent, rel, _index(h, en, dev, "batch_h"), _index(r, rn, dev, "batch_r"),
+                                 _index(t, en, dev, "batch_t"), margin.reshape(1).to(torch.float32), B, (T - B) // B, eoff, roff)
 
 
 def margin_loss(score: torch.Tensor, batch_size: int, margin: torch.Tensor) -> torch.Tensor:

@@ -102,11 +102,11 @@ class _RelAttnAggregate(torch.autograd.Function):
         dPQZ = torch.empty_like(PQZ)
         dRR = torch.empty_like(RR)
         da = torch.empty_like(a)
-        vd = graph.by_dst.view()
+        vd = graph.by_dst_bwd.view()
         vs = graph.by_src.view() if mode else None
         vr = graph.by_rel.view() if mode else None
         ws_bytes = int(L.jmac_rel_attn_bwd_workspace_bytes(
-            N, graph.E, nrel, d, graph.by_dst.n_parts_max,
+            N, graph.E, nrel, d, graph.by_dst_bwd.n_parts_max,
             graph.by_src.n_parts_max if mode else 0, graph.by_rel.n_parts_max if mode else 0, mode))
         ws = _ws(ws_bytes, dev)
         esz = PQZ.element_size()
@@ -173,8 +173,8 @@ class _RelAttnAggregateSplit(torch.autograd.Function):
         G = _f32c(G).contiguous()
         graph.ensure_backward_views()
         dP, dQZ, dRR, da = torch.empty_like(P), torch.empty_like(QZ), torch.empty_like(RR), torch.empty_like(a)
-        vd, vs, vr = graph.by_dst.view(), graph.by_src.view(), graph.by_rel.view()
-        ws_bytes = int(L.jmac_rel_attn_bwd_workspace_bytes(N, graph.E, nrel, d, graph.by_dst.n_parts_max,
+        vd, vs, vr = graph.by_dst_bwd.view(), graph.by_src.view(), graph.by_rel.view()
+        ws_bytes = int(L.jmac_rel_attn_bwd_workspace_bytes(N, graph.E, nrel, d, graph.by_dst_bwd.n_parts_max,
                                                            graph.by_src.n_parts_max, graph.by_rel.n_parts_max, 1))
         ws = _ws(ws_bytes, dev)
         ev0 = _ev() if PROFILE is not None else None

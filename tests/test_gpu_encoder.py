@@ -124,7 +124,7 @@ def test_fused_encoder_keeps_its_name_block_buffer_across_steps():
         m.zero_grad(set_to_none=True)
         a, comp, _ = fwd()
         (a.sum() + comp[1].sum()).backward()
-        slot = m._encoder_cache["cat0"]
+        (slot,) = m._encoder_cache["cat0"].values()              # one slot per name-embedding tensor; this model has one
         assert not slot.busy and slot.lease == step + 1
         got = (a.detach().clone(), m.uni_linear1_1.grad.clone())
         if first is None:
@@ -134,15 +134,56 @@ def test_fused_encoder_keeps_its_name_block_buffer_across_steps():
     m.load_state_dict(state)
     a1, comp1, _ = fwd()                                         # holds the model's buffer ...
     a2, _, _ = fwd()                                             # ... so this one allocates its own
-    assert m._encoder_cache["cat0"].buf is buf and m._encoder_cache["cat0"].busy
+    assert slot.buf is buf and slot.busy and len(m._encoder_cache["cat0"]) == 1
     a2.sum().backward()
-    assert m._encoder_cache["cat0"].busy                         # (not the owner: the first forward still holds it)
+    assert slot.busy                                             # (not the owner: the first forward still holds it)
     (a1.sum() + comp1[1].sum()).backward(retain_graph=True)      # the owner's backward releases the buffer
-    assert not m._encoder_cache["cat0"].busy
+    assert not slot.busy
     a3, _, _ = fwd()                                             # re-uses (and rewrites) it
     with pytest.raises(RuntimeError, match="re-used by a later forward"):
         a1.sum().backward()
     del a3
+
+
+def test_name_block_cache_with_host_name_embeddings_and_equal_size_kgs():
+    """ent_info_att stays on the HOST, as in the reference (src/jmac_model.py:133) and in JMAC's constructor here, and the
+    model holds two KGs of EQUAL size: every forward_name call used to upload a temporary slice whose address the allocator
+    could hand to the other KG's rows -- the cat(comp0, info) cache (keyed on that address) then served the wrong name block.
+    The device rows are now persistent per id range and the cache is keyed on them: alternating the two KGs, cached and
+    uncached, gives identical outputs, and each KG keeps its own buffer."""
+    from jmac_amd.model import JMAC
+    n, nr, d, di = 300, 11, 32, 20
+    rng = np.random.default_rng(21)
+    torch.manual_seed(21)
+    args = types.SimpleNamespace(dim=d, dropout=0.0, leaky_relu_w=0.05, comp_op="sub", num_gcn_layer=2, num_negative=4,
+                                 margin_align=1.0, margin_completion=5.0, batch_size=8, no_name_info=False, device="cuda")
+    m = JMAC(args, rng.standard_normal((2 * n, di)).astype(np.float32), 2 * nr, 2 * n).to(DEV)
+    assert not m.ent_info_att.is_cuda                            # the plain attribute did not move with .to()
+    graphs = []
+    for k in range(2):
+        ei, et = random_graph(rng, n, nr, 1200)
+        graphs.append((torch.from_numpy(ei).to(DEV), torch.from_numpy(et).to(DEV), [k * n, (k + 1) * n], [k * nr, (k + 1) * nr]))
+    m.eval()
+    with torch.no_grad():
+        ref = []
+        for g in graphs:                                         # reference results: the op-by-op path (no cache involved)
+            m.fused_encoder = False
+            for lay in (m.conv1_alignment, m.conv2_alignment, m.conv1_completion):
+                lay.fused = False
+            ref.append(m.forward_base(*g)[0].clone())
+        m.fused_encoder = True
+        for lay in (m.conv1_alignment, m.conv2_alignment, m.conv1_completion):
+            lay.fused = True
+        for rep in range(3):
+            for k in (0, 1, 1, 0):
+                junk = torch.randn(n, di, device=DEV)            # churn the allocator between calls
+                out = m.forward_base(*graphs[k])[0]
+                assert_close(out, ref[k], 2e-5, 1e-6, "kg%d rep %d" % (k, rep))
+                del junk
+    slots = m._encoder_cache["cat0"]
+    assert len(slots) == 2 and len({s_.buf.data_ptr() for s_ in slots.values()}) == 2
+    for s_ in slots.values():
+        assert s_.info.is_cuda and s_.info.shape == (n, di)
 
 
 def test_fused_encoder_inference_form_with_bf16_tables():

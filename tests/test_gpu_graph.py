@@ -79,11 +79,24 @@ def test_csr_and_schedules(n, nr, e, chunk):
         # destination of every entry in grouped order, and (small graphs) the {slot, destination} pairs of the first two
         # entries of every item inline with the schedule
         dos = ei[0][perm]
+        # the backward's views take their small-graph form on their own (lower) threshold; past it, pass A walks a plain
+        # by-destination schedule (no cooperative quarters) beside the forward's
+        small_bwd = small and n + e // g.chunk + 1 <= jgraph.SMALL_BWD_MAX_ITEMS
+        assert (g.by_dst_bwd is g.by_dst) == (small_bwd or not small)
+        if g.by_dst_bwd is not g.by_dst:
+            c2 = g.by_dst_bwd.counts.cpu().numpy()
+            its = g.by_dst_bwd.items.cpu().numpy()[: c2[0]]
+            assert g.by_dst_bwd.n_coop == 0 and g.by_dst_bwd.item_edges is None and c2[4] == 0
+            cov = np.zeros(e, dtype=np.int64)
+            for seg, b, en, ps in its:
+                assert rowptr[seg] <= b <= en <= rowptr[seg + 1] and en - b <= chunk and (ps < 0) == (degs[seg] <= chunk)
+                cov[b:en] += 1
+            assert (cov == 1).all() and len(set(its[:, 0])) == n
         for view, order in ((g.by_src, so), (g.by_rel, to)):
             ed = view.entry_dst[:e].cpu().numpy()
             assert (ed == dos[order]).all()
-            assert (view.item_edges is not None) == small
-            if small:
+            assert (view.item_edges is not None) == small_bwd
+            if small_bwd:
                 c2 = view.counts.cpu().numpy()
                 its = view.items.cpu().numpy()[: c2[0]]
                 ie = view.item_edges.cpu().numpy()[: c2[0]]

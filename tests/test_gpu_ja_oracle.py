@@ -76,12 +76,15 @@ def test_bench_workload_step_matches_oracle(d, bidir, data):
         deg = np.bincount(w.ei[0].cpu().numpy(), minlength=w.N)
         assert (int(deg.max()), int((deg == 0).sum())) == ((1221, 4332) if bidir else (28, 6380))
     captured, hooks = {}, []
-    for name in ("conv1_alignment", "conv1_completion", "conv2_alignment"):
-        def pre(mod, args, name=name):
-            captured[name] = (args[0].detach(), args[1].detach())
-        hooks.append(getattr(w.model, name).register_forward_pre_hook(pre))
     from jmac_amd import encoder
-    encoder.CAPTURE = captured if w.model.fused_encoder else None      # the fused node calls no layer module: it reports
+    fused = w.model._fused(300)
+    assert fused                                                       # the bench step runs the fused encoder node
+    if not fused:                       # op-by-op path: forward pre-hooks show each layer call's inputs (a layer WITH hooks
+        for name in ("conv1_alignment", "conv1_completion", "conv2_alignment"):   # is never taken by the node: it would skip them)
+            def pre(mod, args, name=name):
+                captured[name] = (args[0].detach(), args[1].detach())
+            hooks.append(getattr(w.model, name).register_forward_pre_hook(pre))
+    encoder.CAPTURE = captured if fused else None                      # the fused node calls no layer module: it reports
     try:                                                                # the same (ent_emb, rel_emb) pairs itself
         w.opt.zero_grad(set_to_none=True)
         loss, align_out, comp, rel = w.forward_loss()
@@ -92,6 +95,7 @@ def test_bench_workload_step_matches_oracle(d, bidir, data):
     for h in hooks:
         h.remove()
     assert {"conv1_alignment", "conv1_completion", "conv2_alignment"} <= set(captured)
+    assert "conv1_alignment.tables" in captured                        # ... and it was the node that ran
     masks = _gpu_kink_masks(w, captured)
 
     # forward: plain oracle, fp32 and float64 (no mask involved: the forward is continuous at the kink)

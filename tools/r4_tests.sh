@@ -1,0 +1,5 @@
+#!/bin/bash
+cd /root/repo
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -q 2>&1 | tail -12 > gpurun_out/r4_gpu_tests.log
+cat gpurun_out/r4_gpu_tests.log
