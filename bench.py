@@ -879,8 +879,9 @@ def union_bench(a, device, cpu=True):
         # the bf16 aggregation kernel alone on the union graph: HIP events around back-to-back launches
         g = RelGraph(ei_t, et_t, n, nr + 1)
         gen = torch.Generator(device=device).manual_seed(0)
-        PQZ = (torch.randn(n, 3 * d, device=device, generator=gen) * 0.3).to(torch.bfloat16)
-        RR = (torch.randn(nr + 1, 2 * d, device=device, generator=gen) * 0.3).to(torch.bfloat16)
+        # bf16 tables in the layout the layers produce: halves padded to a multiple of 8 elements (300 -> 304)
+        PQZ = ops.pad_table((torch.randn(n, 3 * d, device=device, generator=gen) * 0.3).to(torch.bfloat16), d, 3)
+        RR = ops.pad_table((torch.randn(nr + 1, 2 * d, device=device, generator=gen) * 0.3).to(torch.bfloat16), d, 2)
         av = torch.randn(d, device=device, generator=gen) * 0.1
         agg = lambda: ops.rel_attn_aggregate(PQZ, RR, av, g, 0.05, nr, 0.5)
         for _ in range(3):
@@ -1040,8 +1041,8 @@ def synth_measure(a, device, cpu=True):
         from jmac_amd.graph import RelGraph
         g = RelGraph(ei_t, et_t, n, nrel)
         gen = torch.Generator(device=device).manual_seed(0)
-        PQZ = (torch.randn(n, 3 * a.dim, device=device, generator=gen) * 0.3).to(torch.bfloat16)
-        RR = (torch.randn(nrel, 2 * a.dim, device=device, generator=gen) * 0.3).to(torch.bfloat16)
+        PQZ = ops.pad_table((torch.randn(n, 3 * a.dim, device=device, generator=gen) * 0.3).to(torch.bfloat16), a.dim, 3)
+        RR = ops.pad_table((torch.randn(nrel, 2 * a.dim, device=device, generator=gen) * 0.3).to(torch.bfloat16), a.dim, 2)
         av = torch.randn(a.dim, device=device, generator=gen) * 0.1
         with torch.no_grad():
             for _ in range(2):

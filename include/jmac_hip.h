@@ -161,6 +161,19 @@ int jmac_rel_attn_aggregate_fwd_bf16(
     float* out, int64_t ldo, float* seg_max, float* seg_den,
     void* ws, size_t ws_bytes, jmac_stream_t stream);
 
+/* The same on bf16 tables whose row halves are PADDED to `dh` elements (dh >= d, dh % 8 == 0: 16-byte aligned halves, e.g.
+ * d = 300 -> dh = 304): P rows hold dh elements, a [Q|Z] / [Rq|Rz] row is Q at 0 and Z at dh (2 dh elements), pad columns
+ * are ZERO (the host pads the projection weights, so the GEMM writes them).  With (d, dh) = (300, 304) or (256, 256) and
+ * 16-byte aligned rows the persistent-grid form of the kernel (large graphs) takes 16 bytes per lane and two edges per wave
+ * instruction (half a wave per edge) -- the 8-byte lane loads of the unpadded d = 300 layout run at 0.54-0.70 x the 16-byte
+ * rate; every other case reads the same layout with the 64-lane map (dh % 4 == 0).  out stays [N, d] fp32. */
+int jmac_rel_attn_aggregate_fwd_bf16_padded(const uint16_t* P, int64_t ldp, const uint16_t* QZ, int64_t ldqz,
+                                            const uint16_t* RR, int64_t ldrr, int64_t dh, const float* a_att,
+                                            const int32_t* col, const int32_t* etype, const jmac_view_t* by_dst,
+                                            int64_t N, int64_t d, float slope, int32_t loop_rel, int64_t self_off,
+                                            float out_scale, float* out, int64_t ldo, float* seg_max, float* seg_den,
+                                            void* ws, size_t ws_bytes, jmac_stream_t stream);
+
 /* Backward of the op above (replaces autograd through the same reference lines).
  *   G [N,d] (ldg) = dL/dout;  outputs: dP [N,d] (lddp), dQZ [N,2d] (lddqz), dRR [nr+1,2d] (lddrr),
  *   da [d].  All outputs are fully written (no pre-zeroing needed).

@@ -50,6 +50,7 @@ struct FwdArgs {
     int32_t N, D4, loop_rel, n_items_max;
     int32_t n_coop;       // cooperative segments (host copy of counts[4], exact): the launch geometry depends on it
     int64_t self_off;     // row of QZ that holds destination 0 (fused self term; 0 unless destinations are a slice of the sources)
+    int32_t zoff;         // element offset of the Z / Rz half inside a [Q|Z] / [Rq|Rz] row: d, or the padded half pitch (bf16)
     float slope, out_scale;
     float *out, *seg_max, *seg_den;
     float *part_acc, *part_ml;
@@ -72,7 +73,9 @@ struct Lanes {
     __device__ __forceinline__ bool any_v(int k) const { return 64 * (k + 1) > D4(); }
     __device__ __forceinline__ bool all_valid(int k) const { return 64 * (k + 1) <= 2 * D4(); }
     __device__ __forceinline__ bool is_v(int k) const { return valid[k] && !is_h[k]; }
-    __device__ __forceinline__ void init(int lane, int d4_runtime) {
+    // zpad: elements between the end of the Q half and the start of the Z half of a gathered row (padded bf16 tables: the
+    // halves sit at a 16-byte aligned pitch dh >= d; 0 for the plain [Q|Z] layout)
+    __device__ __forceinline__ void init(int lane, int d4_runtime, int zpad = 0) {
         D4r = d4_runtime;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
@@ -80,7 +83,7 @@ struct Lanes {
             valid[k] = c < 2 * D4();
             is_h[k] = c < D4();
             coff[k] = c * 4;
-            coffc[k] = valid[k] ? c * 4 : 0;
+            coffc[k] = valid[k] ? c * 4 + (is_h[k] ? 0 : zpad) : 0;
         }
     }
 };
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
     const int n_coop = a.n_coop;                  // == counts[4]; from the host so that no address below waits for it
     const int n_reg = n_items - n_empty;          // items with entries come first, the empty segments are the tail of the list
     Lanes<NCH, D4T> L;
-    L.init(lane, a.D4);
+    L.init(lane, a.D4, a.zoff - 4 * a.D4);
     const int voff = 4 * L.D4();
     float4 av[NCH];
 #pragma unroll
@@ -146,9 +149,11 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
     // The first header is fetched at a clamped index so that it does not wait for the device-side counts.
     const int it0 = blockIdx.x * kWavesPerBlock + wave;
     // the loop relation's Rz row is the same for every destination: one read per wave
-    float4 rl[NCH];
+    // (kept RAW like the Z[i] chunks below: half the registers for bf16 tables, converted where they are used)
+    raw_t rl[NCH];
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) rl[k] = (L.any_v(k) && has_loop) ? cvt4(ldraw(rloop + L.coffc[k])) : f4zero();
+    for (int k = 0; k < NCH; ++k)
+        if (L.any_v(k)) rl[k] = ldraw(rloop + L.coffc[k]);
 
     // ---- the edges [item.beg, item.end) of destination item.seg: online softmax over them into (m, l, acc) ----------
     // my_col / my_typ: source and type of entry item.beg + lane (first batch of up to 64), supplied by the caller
@@ -303,12 +308,13 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
         }
     };
     // ---- out[i] = out_scale * ( sqrt(deg) / l * acc  +  Z[i] - Rz[loop] ),  softmax statistics for the backward ---------
-    auto finish = [&](int i, int deg, float m, float l, const float4 (&acc)[NCH], const float4 (&zs)[NCH]) {
+    auto finish = [&](int i, int deg, float m, float l, const float4 (&acc)[NCH], const raw_t (&zs)[NCH]) {
         const float scale = l > 0.f ? sqrtf((float)deg) / l : 0.f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             if (L.any_v(k) && L.is_v(k)) {
-                const float4 o = add4(mul4(acc[k], scale), sub4(zs[k], rl[k]));   // + Z[i] - Rz[loop]
+                const float4 self = has_loop ? sub4(cvt4(zs[k]), cvt4(rl[k])) : f4zero();
+                const float4 o = add4(mul4(acc[k], scale), self);                 // + Z[i] - Rz[loop]
                 st4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff), mul4(o, a.out_scale));
             }
         }
@@ -330,13 +336,14 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
         const int i = item.seg;
         int ccol, ctyp;
         first_batch(item, ccol, ctyp);
-        float4 pv[NCH], acc[NCH], zs[NCH];
+        float4 pv[NCH], acc[NCH];
+        raw_t zs[NCH];
         const TT* prow = tP + (int64_t)i * a.ldp;
         const TT* zrow = tQZ + ((int64_t)i + a.self_off) * a.ldqz;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             pv[k] = L.any_h(k) ? cvt4(ldraw(prow + (L.is_h[k] ? L.coff[k] : 0))) : f4zero();
-            zs[k] = (L.any_v(k) && has_loop && wave == 0) ? cvt4(ldraw(zrow + L.coffc[k])) : f4zero();
+            if (L.any_v(k)) zs[k] = ldraw(zrow + L.coffc[k]);
             acc[k] = f4zero();
         }
 #pragma unroll
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
         const int n_packs = (n_empty + kEmptyPack - 1) / kEmptyPack;
         for (int p = p0; p < n_packs; p += nwaves) {
             int seg[kEmptyPack];
-            float4 zs[kEmptyPack][NCH];
+            raw_t zs[kEmptyPack][NCH];
 #pragma unroll
             for (int u = 0; u < kEmptyPack; ++u) seg[u] = a.items[min(n_reg + p * kEmptyPack + u, n_items - 1)].seg;
 #pragma unroll
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
                 const TT* zrow = tQZ + ((int64_t)seg[u] + a.self_off) * a.ldqz;
 #pragma unroll
                 for (int k = 0; k < NCH; ++k)
-                    zs[u][k] = (L.any_v(k) && has_loop) ? cvt4(ldraw(zrow + L.coffc[k])) : f4zero();
+                    if (L.any_v(k)) zs[u][k] = ldraw(zrow + L.coffc[k]);
             }
 #pragma unroll
             for (int u = 0; u < kEmptyPack; ++u) {
@@ -398,7 +405,8 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
 #pragma unroll
                 for (int k = 0; k < NCH; ++k)
                     if (L.any_v(k) && L.is_v(k))
-                        st4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff), mul4(sub4(zs[u][k], rl[k]), a.out_scale));
+                        st4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff),
+                            mul4(has_loop ? sub4(cvt4(zs[u][k]), cvt4(rl[k])) : f4zero(), a.out_scale));
                 if (lane == 0) {
                     a.seg_max[i] = -INFINITY;
                     a.seg_den[i] = 0.f;
@@ -437,14 +445,15 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
         int ncol, ntyp;
         first_batch(nitem, ncol, ntyp);
         const int i = item.seg;
-        float4 pv[NCH], acc[NCH], zs[NCH];
+        float4 pv[NCH], acc[NCH];
+        raw_t zs[NCH];
         const TT* prow = tP + (int64_t)i * a.ldp;
         const TT* zrow = tQZ + ((int64_t)i + a.self_off) * a.ldqz;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             pv[k] = L.any_h(k) ? cvt4(ldraw(prow + (L.is_h[k] ? L.coff[k] : 0))) : f4zero();
             // self-loop term Z[i] (v-role lanes), fetched with the header-dependent loads rather than after the edges
-            zs[k] = (L.any_v(k) && has_loop) ? cvt4(ldraw(zrow + L.coffc[k])) : f4zero();
+            if (L.any_v(k)) zs[k] = ldraw(zrow + L.coffc[k]);
             acc[k] = f4zero();
         }
 #pragma unroll
@@ -471,6 +480,459 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
         ctyp = ntyp;
     }
     empties(it - n_reg);                    // persistent grids: the waves share the empty segments after their items
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, HALF-WAVE lane map (d = 256 / 300): 32 lanes per edge, two edges per wave instruction
+// ------------------------------------------------------------------------------------------------
+// A [Q|Z] row is cut into 16-byte chunks (4 fp32 / 8 bf16 elements); chunk c = (lane & 31) + 32 k of the row belongs to
+// lane (lane & 31) of BOTH halves of the wave, and the two halves gather two DIFFERENT edges of the same destination.
+//   fp32, d = 300: 150 chunks on 5 x 32 slots (94 % of the lane slots carry data; the 64-lane map: 150 of 192 = 78 %)
+//   bf16, d = 300 (halves padded to 304 elements = 608 B, 16-byte aligned): 76 chunks on 3 x 32 slots with 16-byte lane loads
+//         (the 64-lane map loads 8 B per lane: 0.54-0.70 x the 16-byte rate, MI355X_MICROARCH.md)
+// Per edge PAIR: one set of gather instructions, ONE cross-lane reduction of the logits (five DPP steps inside the 32-lane
+// halves, lanes 31 / 63 read out), one online-softmax update with a per-half weight; the two halves' accumulators meet once
+// per item (v_permlane32_swap of two chunk registers: the lower half ends with one complete chunk, the upper half with
+// another -- no LDS, no shuffle per element).  Schedule, cooperative segments, combine pass and outputs are those of
+// rel_attn_fwd_kernel.  DC = chunks per half row (compile time: 75 / 64 fp32, 38 / 32 bf16).
+template <typename TT> struct HwElem;
+template <> struct HwElem<float> { static constexpr int CH = 4; };
+template <> struct HwElem<bf16_t> { static constexpr int CH = 8; };
+template <int CH> struct VF { float v[CH]; };
+__device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+template <typename TT> __device__ __forceinline__ VF<HwElem<TT>::CH> hw_cvt(uint4 r);
+template <> __device__ __forceinline__ VF<4> hw_cvt<float>(uint4 r) {
+    VF<4> o;
+    o.v[0] = __uint_as_float(r.x); o.v[1] = __uint_as_float(r.y); o.v[2] = __uint_as_float(r.z); o.v[3] = __uint_as_float(r.w);
+    return o;
+}
+template <> __device__ __forceinline__ VF<8> hw_cvt<bf16_t>(uint4 r) {   // bf16 -> fp32 is a 16-bit shift: exact
+    VF<8> o;
+    o.v[0] = __uint_as_float(r.x << 16); o.v[1] = __uint_as_float(r.x & 0xffff0000u);
+    o.v[2] = __uint_as_float(r.y << 16); o.v[3] = __uint_as_float(r.y & 0xffff0000u);
+    o.v[4] = __uint_as_float(r.z << 16); o.v[5] = __uint_as_float(r.z & 0xffff0000u);
+    o.v[6] = __uint_as_float(r.w << 16); o.v[7] = __uint_as_float(r.w & 0xffff0000u);
+    return o;
+}
+// sums inside the two 32-lane halves: sa = lanes 0..31, sb = lanes 32..63 (wave-uniform results), U chains interleaved
+template <int U>
+__device__ __forceinline__ void half_sum_n(float (&v)[U], float (&sa)[U], float (&sb)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] += JMAC_DPP(v[u], 0.f, 0xB1, 0xF);
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] += JMAC_DPP(v[u], 0.f, 0x4E, 0xF);
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] += JMAC_DPP(v[u], 0.f, 0x141, 0xF);
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] += JMAC_DPP(v[u], 0.f, 0x140, 0xF);
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] += JMAC_DPP(v[u], 0.f, 0x142, 0xA);   // row_bcast:15: lanes 31 / 63 hold their half's sum
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        sa[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[u]), 31));
+        sb[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[u]), 63));
+    }
+}
+// x: lower half keeps its own lanes and receives the UPPER half of ... see v_permlane32_swap: after the swap
+//   a' = { a[0..31], b[0..31] },  b' = { a[32..63], b[32..63] }   =>   a' + b' = { sum of a's halves | sum of b's halves }
+__device__ __forceinline__ float halves_meet(float a, float b) {
+    // inline asm, not __builtin_amdgcn_permlane32_swap: hipcc 7.2 folds r[0] + r[1] of the builtin's result pair into
+    // r[0] + r[0] (seen in the ISA: v_permlane32_swap v0, v52 ; v_pk_add_f32 v[4:5], v[0:1], v[0:1]) -- the same family
+    // of mis-folds common.h notes for permlane*_swap(x, x).  s_nop 1 = the two wait states between a VALU write of an
+    // operand and the swap (LLVM gfx950 hazard rule; nothing pads the inside of an asm statement).
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
+template <int DC, int GP, int PIPE, typename TT>   // PIPE: 0 = load / reduce in turn, 2 / 3 = that many groups' gathers in flight
+__global__ __launch_bounds__(kBlock) void rel_attn_fwd_hw_kernel(FwdArgs a) {
+    constexpr int CH = HwElem<TT>::CH;
+    constexpr int NCH = (2 * DC + 31) / 32;            // chunk slots per lane
+    constexpr int KH = (DC + 31) / 32;                 // slots k < KH hold attention-half (h) chunks on some lane
+    constexpr int KV0 = DC / 32;                       // slots k >= KV0 hold message-half (v) chunks on some lane
+    constexpr int NV = NCH - KV0;
+    constexpr int NP = (NV + 1) / 2;                   // v slots in pairs: one complete chunk per half after halves_meet
+    typedef VF<CH> vf;
+    __shared__ float coop_acc[kWavesPerBlock][NP][CH][64];
+    __shared__ float coop_ml[kWavesPerBlock][2];
+    const TT* const tP = static_cast<const TT*>(a.P);
+    const TT* const tQZ = static_cast<const TT*>(a.QZ);
+    const TT* const tRR = static_cast<const TT*>(a.RR);
+    const int lane = lane_id();
+    const int hl = lane & 31;
+    const bool upper = lane >= 32;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = gridDim.x * kWavesPerBlock;
+    const int n_items = a.counts[0];
+    const int n_empty = a.counts[3];
+    const int n_coop = a.n_coop;
+    const int n_reg = n_items - n_empty;
+    const int dtrue = 4 * a.D4;                        // output width (<= DC * CH: the tables' pad columns are zero)
+    int coff[NCH];                                     // element offset of the lane's chunk in a [Q|Z] row, clamped to a valid one
+    bool valid[NCH], is_h[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = hl + 32 * k;
+        valid[k] = c < 2 * DC;
+        is_h[k] = c < DC;
+        coff[k] = valid[k] ? c * CH : 0;
+    }
+    auto all_valid = [](int k) { return 32 * (k + 1) <= 2 * DC; };
+    vf av[KH];
+#pragma unroll
+    for (int k = 0; k < KH; ++k)
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            const int col = (hl + 32 * k) * CH + e;
+            av[k].v[e] = (is_h[k] && col < dtrue) ? a.a_att[col] : 0.f;
+        }
+    const bool has_loop = a.loop_rel >= 0;
+    const TT* rloop = tRR + (int64_t)(has_loop ? a.loop_rel : 0) * a.ldrr;
+    // chunk of the [Q|Z] row that OUTPUT slot p holds on this lane once the halves have met (the lower half keeps v slot
+    // KV0 + 2p, the upper half v slot KV0 + 2p + 1); -1: none (an h chunk, past the row, or an unpaired last slot)
+    int oc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int k = KV0 + 2 * p + (upper ? 1 : 0);
+        const int c = hl + 32 * k;
+        oc[p] = (k < NCH && c >= DC && c < 2 * DC) ? c : -1;
+    }
+    // Every load stays RAW (uint4) until its first use: a conversion or a select right behind a load is waited for where it
+    // stands, i.e. in front of the gathers that should be in flight together with it (one more round trip per item).
+    uint4 rlraw[NP];                                   // the loop relation's Rz chunks in the OUTPUT layout: one read per wave
+#pragma unroll
+    for (int p = 0; p < NP; ++p) rlraw[p] = ld16(rloop + (oc[p] >= 0 ? oc[p] : 0) * CH);
+
+    // ---- online softmax over the entries [item.beg, item.end) of one destination; both halves carry PARTIAL accumulators
+    auto edge_loop = [&](const jmac_item_t& item, int my_col, int my_typ, const uint4 (&praw)[KH], float& m, float& l, vf (&acc)[NCH]) {
+        auto issue = [&](const int nb, const int mc, const int mt, const int p0, uint4 (&qr)[GP][NCH], uint4 (&rr)[GP][NCH]) {
+#pragma unroll
+            for (int u = 0; u < GP; ++u) {
+                const int ea = max(min(2 * (p0 + u), nb - 1), 0), eb = max(min(2 * (p0 + u) + 1, nb - 1), 0);
+                const int ja = bcast_i(mc, ea), jb = bcast_i(mc, eb);
+                const int ta = bcast_i(mt, ea), tb = bcast_i(mt, eb);
+                const TT* qrow = tQZ + (int64_t)(upper ? jb : ja) * a.ldqz;
+                const TT* rrow = tRR + (int64_t)(upper ? tb : ta) * a.ldrr;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    qr[u][k] = ld16(qrow + coff[k]);
+                    rr[u][k] = ld16(rrow + coff[k]);
+                }
+            }
+        };
+        // the item's FIRST group of gathers goes out here, in one basic block with the loads of P[i] / Z[i] and ahead of the
+        // conversion of P[i]: that conversion waits for P[i] only (the gathers are younger), not the other way round
+        uint4 qA[GP][NCH], rA[GP][NCH];
+        issue(min(64, item.end - item.beg), my_col, my_typ, 0, qA, rA);
+        vf pv[KH];
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+            pv[k] = hw_cvt<TT>(praw[k]);
+            if (32 * (k + 1) > DC)
+#pragma unroll
+                for (int e = 0; e < CH; ++e) pv[k].v[e] = is_h[k] ? pv[k].v[e] : 0.f;
+        }
+        for (int e0 = item.beg; e0 < item.end; e0 += 64) {
+            const int nb = min(64, item.end - e0);
+            if (e0 != item.beg) {
+                const int le = min(lane, nb - 1);
+                my_col = a.col[e0 + le];
+                my_typ = a.etype[e0 + le];
+                issue(nb, my_col, my_typ, 0, qA, rA);
+            }
+            const int npairs = (nb + 1) >> 1;
+            auto consume = [&](const int p0, const uint4 (&qr)[GP][NCH], const uint4 (&rr)[GP][NCH]) {
+                vf x[GP][NCH];
+                float part[GP];
+#pragma unroll
+                for (int u = 0; u < GP; ++u) {
+                    part[u] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) {
+                        const vf q = hw_cvt<TT>(qr[u][k]), r = hw_cvt<TT>(rr[u][k]);
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) {
+                            float d = q.v[e] - r.v[e];
+                            if (!all_valid(k)) d = valid[k] ? d : 0.f;
+                            x[u][k].v[e] = d;
+                            if (k < KH) part[u] = fmaf(av[k].v[e], leaky01(pv[k].v[e] + d, a.slope), part[u]);   // av = 0 off the h lanes
+                        }
+                    }
+                }
+                float sa[GP], sb[GP];
+                half_sum_n<GP>(part, sa, sb);
+                float mn = m;
+#pragma unroll
+                for (int u = 0; u < GP; ++u) {
+                    if (2 * (p0 + u) >= nb) sa[u] = -INFINITY;          // pairs / edges past the batch: weight exp(-inf) = 0
+                    if (2 * (p0 + u) + 1 >= nb) sb[u] = -INFINITY;
+                    mn = fmaxf(mn, fmaxf(sa[u], sb[u]));
+                }
+                const float sc = fast_exp(m - mn);
+                float w[GP], wsum = 0.f;
+#pragma unroll
+                for (int u = 0; u < GP; ++u) {
+                    const float wa = fast_exp(sa[u] - mn), wb = fast_exp(sb[u] - mn);
+                    wsum += wa + wb;
+                    w[u] = upper ? wb : wa;
+                }
+                l = l * sc + wsum;
+#pragma unroll
+                for (int k = KV0; k < NCH; ++k)
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) {
+                        float t = acc[k].v[e] * sc;
+#pragma unroll
+                        for (int u = 0; u < GP; ++u) t = fmaf(x[u][k].v[e], w[u], t);
+                        acc[k].v[e] = t;
+                    }
+                m = mn;
+            };
+            if constexpr (PIPE == 3) {
+                // three groups in flight: group g + 2 is issued before group g is reduced (two waves per SIMD hold 2 x 3 x 2 rows:
+                // what three waves of the two-deep form would, without their registers)
+                uint4 qB[GP][NCH], rB[GP][NCH], qC[GP][NCH], rC[GP][NCH];
+                if (GP < npairs) issue(nb, my_col, my_typ, GP, qB, rB);
+                for (int p = 0; p < npairs; p += 3 * GP) {
+                    if (p + 2 * GP < npairs) issue(nb, my_col, my_typ, p + 2 * GP, qC, rC);
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(p, qA, rA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p + GP < npairs) {
+                        if (p + 3 * GP < npairs) issue(nb, my_col, my_typ, p + 3 * GP, qA, rA);
+                        __builtin_amdgcn_sched_barrier(0);
+                        consume(p + GP, qB, rB);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (p + 2 * GP < npairs) {
+                        if (p + 4 * GP < npairs) issue(nb, my_col, my_typ, p + 4 * GP, qB, rB);
+                        __builtin_amdgcn_sched_barrier(0);
+                        consume(p + 2 * GP, qC, rC);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else if constexpr (PIPE == 2) {
+                uint4 qB[GP][NCH], rB[GP][NCH];
+                for (int p = 0; p < npairs; p += 2 * GP) {
+                    if (p + GP < npairs) issue(nb, my_col, my_typ, p + GP, qB, rB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(p, qA, rA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p + GP < npairs) {
+                        if (p + 2 * GP < npairs) issue(nb, my_col, my_typ, p + 2 * GP, qA, rA);
+                        __builtin_amdgcn_sched_barrier(0);
+                        consume(p + GP, qB, rB);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
+                for (int p = 0; p < npairs; p += GP) {
+                    if (p > 0) issue(nb, my_col, my_typ, p, qA, rA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(p, qA, rA);
+                }
+            }
+        }
+    };
+    // ---- the two halves' partial accumulators -> NP complete chunks per lane (oc[p]): an odd last slot is paired with slot
+    // ---- KV0 once more (the upper half's copy of that pair is not used)
+    auto meet = [&](const vf (&acc)[NCH], vf (&outv)[NP]) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            constexpr int dummy = KV0;
+            const int k1 = KV0 + 2 * p, k2 = (KV0 + 2 * p + 1 < NCH) ? KV0 + 2 * p + 1 : dummy;
+#pragma unroll
+            for (int e = 0; e < CH; ++e) outv[p].v[e] = halves_meet(acc[k1].v[e], acc[k2].v[e]);
+        }
+    };
+    auto store_chunks = [&](float* rowp, const vf (&o)[NP]) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (oc[p] < 0) continue;
+            const int col = (oc[p] - DC) * CH;
+#pragma unroll
+            for (int e = 0; e < CH; e += 4)
+                if (col + e < dtrue) st4(rowp + col + e, make_float4(o[p].v[e], o[p].v[e + 1], o[p].v[e + 2], o[p].v[e + 3]));
+        }
+    };
+    // raw Z[i] chunks in the OUTPUT layout (the fused self loop); converted in finish
+    auto load_z = [&](int i, uint4 (&zraw)[NP]) {
+        const TT* zrow = tQZ + ((int64_t)i + a.self_off) * a.ldqz;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) zraw[p] = ld16(zrow + (oc[p] >= 0 ? oc[p] : 0) * CH);
+    };
+    // out[i] = out_scale * (scale * o + Z[i] - Rz[loop])
+    auto finish = [&](int i, float scale, const vf (&o)[NP], const uint4 (&zraw)[NP]) {
+        vf r[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const vf z = hw_cvt<TT>(zraw[p]), rz = hw_cvt<TT>(rlraw[p]);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const float self = has_loop ? z.v[e] - rz.v[e] : 0.f;
+                r[p].v[e] = fmaf(o[p].v[e], scale, self) * a.out_scale;
+            }
+        }
+        store_chunks(a.out + (int64_t)i * a.ldo, r);
+    };
+    auto first_batch = [&](const jmac_item_t& item, int& c, int& t) {
+        const int cnb = min(64, item.end - item.beg);
+        const int idx = cnb > 0 ? item.beg + min(lane, cnb - 1) : 0;
+        c = a.col[idx];
+        t = a.etype[idx];
+    };
+    auto load_p = [&](int i, uint4 (&praw)[KH]) {
+        const TT* prow = tP + (int64_t)i * a.ldp;
+#pragma unroll
+        for (int k = 0; k < KH; ++k) praw[k] = ld16(prow + (is_h[k] ? (hl + 32 * k) * CH : 0));
+    };
+    auto zero_acc = [&](vf (&acc)[NCH]) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int e = 0; e < CH; ++e) acc[k].v[e] = 0.f;
+    };
+
+    // ---- 1. cooperative segments: one workgroup per segment ------------------------------------------------------------
+    for (int cb = blockIdx.x; cb < n_coop; cb += gridDim.x) {
+        const jmac_item_t item = a.items[cb * kWavesPerBlock + wave];
+        const int i = item.seg;
+        int ccol, ctyp;
+        first_batch(item, ccol, ctyp);
+        uint4 praw[KH], zraw[NP];
+        vf acc[NCH], o[NP];
+        load_p(i, praw);
+        load_z(i, zraw);                                  // (wave 0 uses it)
+        zero_acc(acc);
+        float m = -INFINITY, l = 0.f;
+        edge_loop(item, ccol, ctyp, praw, m, l, acc);
+        meet(acc, o);
+        if (wave != 0) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int e = 0; e < CH; ++e) coop_acc[wave][p][e][lane] = o[p].v[e];
+            if (lane == 0) {
+                coop_ml[wave][0] = m;
+                coop_ml[wave][1] = l;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float M = m;
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) M = fmaxf(M, coop_ml[w][0]);
+            float f = fast_exp(m - M);
+            float lsum = l * f;
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int e = 0; e < CH; ++e) o[p].v[e] *= f;
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) {
+                f = fast_exp(coop_ml[w][0] - M);
+                lsum = fmaf(coop_ml[w][1], f, lsum);
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) o[p].v[e] = fmaf(coop_acc[w][p][e][lane], f, o[p].v[e]);
+            }
+            const int deg = a.rowptr[i + 1] - a.rowptr[i];
+            finish(i, lsum > 0.f ? sqrtf((float)deg) / lsum : 0.f, o, zraw);
+            if (lane == 0) {
+                a.seg_max[i] = M;
+                a.seg_den[i] = lsum;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- 3. empty segments, kEmptyPack to a wave: out = out_scale * (Z[i] - Rz[loop]) ----------------------------------------
+    auto empties = [&](int p0) {
+        const int n_packs = (n_empty + kEmptyPack - 1) / kEmptyPack;
+        for (int pk = p0; pk < n_packs; pk += nwaves) {
+            int seg[kEmptyPack];
+            uint4 zraw[kEmptyPack][NP];
+#pragma unroll
+            for (int u = 0; u < kEmptyPack; ++u) seg[u] = a.items[min(n_reg + pk * kEmptyPack + u, n_items - 1)].seg;
+#pragma unroll
+            for (int u = 0; u < kEmptyPack; ++u) load_z(seg[u], zraw[u]);
+#pragma unroll
+            for (int u = 0; u < kEmptyPack; ++u) {
+                if (pk * kEmptyPack + u >= n_empty) break;
+                vf zero[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) zero[p].v[e] = 0.f;
+                finish(seg[u], 0.f, zero, zraw[u]);
+                if (lane == 0) {
+                    a.seg_max[seg[u]] = -INFINITY;
+                    a.seg_den[seg[u]] = 0.f;
+                }
+            }
+        }
+    };
+
+    // ---- 2. items ---------------------------------------------------------------------------------------------------------
+    const int it_base = n_coop * kWavesPerBlock;
+    const int it0 = blockIdx.x * kWavesPerBlock + wave;
+    int it = it_base + it0;
+    jmac_item_t item = a.items[min(it, a.n_items_max - 1)];
+    int4 e4 = make_int4(0, 0, 0, 0);
+    if (a.item_edges) e4 = a.item_edges[min(it, a.n_items_max - 1)];
+    if (it >= n_reg) {
+        empties(it - n_reg);
+        return;
+    }
+    jmac_item_t nitem = a.items[min(it + nwaves, n_items - 1)];
+    int ccol, ctyp;
+    {
+        const int cnb = min(64, item.end - item.beg);
+        if (a.item_edges && cnb <= 2) {
+            ccol = lane == 0 ? e4.x : e4.z;
+            ctyp = lane == 0 ? e4.y : e4.w;
+            ccol = cnb > lane ? ccol : e4.x;
+            ctyp = cnb > lane ? ctyp : e4.y;
+        } else {
+            first_batch(item, ccol, ctyp);
+        }
+    }
+    for (;;) {
+        const jmac_item_t nnitem = a.items[min(it + 2 * nwaves, n_items - 1)];
+        int ncol, ntyp;
+        first_batch(nitem, ncol, ntyp);
+        const int i = item.seg;
+        uint4 praw[KH], zraw[NP];
+        vf acc[NCH], o[NP];
+        load_p(i, praw);
+        load_z(i, zraw);
+        zero_acc(acc);
+        float m = -INFINITY, l = 0.f;
+        edge_loop(item, ccol, ctyp, praw, m, l, acc);
+        meet(acc, o);
+        if (item.pslot < 0) {
+            finish(i, l > 0.f ? sqrtf((float)(item.end - item.beg)) / l : 0.f, o, zraw);
+            if (lane == 0) {
+                a.seg_max[i] = m;
+                a.seg_den[i] = l;
+            }
+        } else {
+            // partial state of a split destination: the combine pass reads d floats per slot in row order
+            store_chunks(a.part_acc + (int64_t)item.pslot * dtrue, o);
+            if (lane == 0) {
+                a.part_ml[2 * item.pslot] = m;
+                a.part_ml[2 * item.pslot + 1] = l;
+            }
+        }
+        it += nwaves;
+        if (it >= n_reg) break;
+        item = nitem;
+        nitem = nnitem;
+        ccol = ncol;
+        ctyp = ntyp;
+    }
+    empties(it - n_reg);
 }
 
 // merges the partial (max, denominator, accumulator) triples of destinations that were split: one BLOCK per split
@@ -534,8 +996,8 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_combine_kernel(FwdArgs a)
                     float4 o = add4(add4(red[0][k][lane], red[1][k][lane]), add4(red[2][k][lane], red[3][k][lane]));
                     o = mul4(o, scale);
                     if (a.loop_rel >= 0) {
-                        float4 z = cvt4(ldraw(static_cast<const TT*>(a.QZ) + ((int64_t)i + a.self_off) * a.ldqz + L.coff[k]));
-                        float4 rz = cvt4(ldraw(static_cast<const TT*>(a.RR) + (int64_t)a.loop_rel * a.ldrr + L.coff[k]));
+                        float4 z = cvt4(ldraw(static_cast<const TT*>(a.QZ) + ((int64_t)i + a.self_off) * a.ldqz + (L.coff[k] - voff + a.zoff)));
+                        float4 rz = cvt4(ldraw(static_cast<const TT*>(a.RR) + (int64_t)a.loop_rel * a.ldrr + (L.coff[k] - voff + a.zoff)));
                         o = add4(o, sub4(z, rz));
                     }
                     st4(a.out + (int64_t)i * a.ldo + (L.coff[k] - voff), mul4(o, a.out_scale));
@@ -1188,8 +1650,10 @@ void launch_reduce_rows(const float* partial, int nparts, int W, float scale, fl
 }
 }  // namespace jmac
 
+// dh: pitch of the halves of a [Q|Z] / [Rq|Rz] row in elements (Q at 0, Z at dh): d, or the padded pitch of the bf16 tables
 template <typename TT>
-static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t ldqz, const TT* RR, int64_t ldrr, const float* a_att,
+static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t ldqz, const TT* RR, int64_t ldrr, int64_t dh,
+                               const float* a_att,
                                const int32_t* col, const int32_t* etype, const jmac_view_t* v, int64_t N, int64_t d, float slope,
                                int32_t loop_rel, int64_t self_off, float out_scale, float* out, int64_t ldo, float* seg_max,
                                float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
@@ -1210,6 +1674,8 @@ static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t l
     a.item_edges = reinterpret_cast<const int4*>(v->item_edges);
     if (loop_rel >= 0 && self_off < 0) return JMAC_EINVAL;
     a.N = (int32_t)N; a.D4 = (int32_t)(d / 4); a.loop_rel = loop_rel; a.self_off = loop_rel >= 0 ? self_off : 0;
+    if (dh < d || dh % 4) return JMAC_EDIM;
+    a.zoff = (int32_t)dh;
     a.n_items_max = (int32_t)(n_items_max > 0 ? n_items_max : 1);
     a.n_coop = (int32_t)n_coop;
     a.slope = slope; a.out_scale = out_scale;
@@ -1238,7 +1704,39 @@ static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t l
     static const int fwd_u_env = env_int("JMAC_FWD_U", 0);         // tuning knob (debug)
     const int fwd_u = fwd_u_env ? fwd_u_env : ((v->item_edges || n_items_max <= 8 * kPersistBlocks) ? 2 : 4);
     const bool slope01 = slope >= 0.f && slope <= 1.f;
-    if (fwd_u == 2) {
+    // half-wave lane map (rel_attn_fwd_hw_kernel): d = 256 / 300 with 16-byte aligned rows and halves
+    static const int hw_env = env_int("JMAC_FWD_HW", 1);             // tuning knobs (debug)
+    static const int hw_gp_env = env_int("JMAC_FWD_HW_GP", 0);
+    constexpr int CHE = 16 / (int)sizeof(TT);                          // elements per 16-byte chunk
+    const bool aligned = ((((uintptr_t)P | (uintptr_t)QZ | (uintptr_t)RR) & 15) == 0) && ldp % CHE == 0 && ldqz % CHE == 0 &&
+                         ldrr % CHE == 0 && dh % CHE == 0;
+    const int dc = (int)(dh / CHE);
+    const bool hw_shape = sizeof(TT) == 4 ? ((d == 300 || d == 256) && dh == d) : ((d == 300 && dh == 304) || (d == 256 && dh == 256));
+    static const int hw_small_env = env_int("JMAC_FWD_HW_SMALL", 0);
+    // measured (rocprofv3 / HIP events, MI355X): config 4 (persistent grid) bf16 7.53 -> 6.48 ms (0.43 -> 0.50 of the HBM peak),
+    // fp32 10.93 -> 10.45 / 9.67 ms; on the 56 589-entity union (one wave per item) the 64-lane kernel stays ahead
+    // (fp32 116 against 120 us, bf16 87 against 105 us): the small-graph form keeps it
+    if (hw_env && slope01 && aligned && hw_shape && (fwd_u != 2 || hw_small_env)) {
+        static const int hw_depth_env = env_int("JMAC_FWD_HW_DEPTH", 0);
+        // gathers in flight per wave: two groups for fp32 rows (2 400 B), three for bf16 rows (1 216 B) -- config 4: fp32 9.67 ms
+        // two-deep / 10.48 ms three-deep, bf16 6.68 / 6.48 ms
+        const int depth = fwd_u == 2 ? 0 : (hw_depth_env ? hw_depth_env : (sizeof(TT) == 2 ? 3 : 2));
+        const int gp = hw_gp_env ? hw_gp_env : 1;     // one pair per group (measured, config 4 bf16: 6.66 ms against 8.94 ms with two)
+#define JMAC_HW_LAUNCH(DCv)                                                                                                   \
+        do {                                                                                                                  \
+            if (depth == 3) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 3, TT>), dim3(grid), dim3(kBlock), 0, st, a);           \
+            else if (depth == 2 && gp == 2) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 2, 2, TT>), dim3(grid), dim3(kBlock), 0, st, a);   \
+            else if (depth == 2) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 2, TT>), dim3(grid), dim3(kBlock), 0, st, a);      \
+            else if (gp == 2) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 2, 0, TT>), dim3(grid), dim3(kBlock), 0, st, a);         \
+            else hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 0, TT>), dim3(grid), dim3(kBlock), 0, st, a);                      \
+        } while (0)
+        if constexpr (sizeof(TT) == 4) {
+            if (dc == 75) JMAC_HW_LAUNCH(75); else JMAC_HW_LAUNCH(64);
+        } else {
+            if (dc == 38) JMAC_HW_LAUNCH(38); else JMAC_HW_LAUNCH(32);
+        }
+#undef JMAC_HW_LAUNCH
+    } else if (fwd_u == 2) {
         JMAC_DISPATCH_D(a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 2, D4T, TT>), dim3(grid), dim3(kBlock), 0, st, a));
     } else {
         JMAC_DISPATCH_D(a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 4, D4T, TT>), dim3(grid), dim3(kBlock), 0, st, a));
@@ -1262,7 +1760,7 @@ int jmac_rel_attn_aggregate_fwd_f32(const float* P, int64_t ldp, const float* QZ
                                     const jmac_view_t* by_dst, int64_t N, int64_t d, float slope, int32_t loop_rel,
                                     int64_t self_off, float out_scale, float* out, int64_t ldo, float* seg_max, float* seg_den,
                                     void* ws, size_t ws_bytes, jmac_stream_t stream) {
-    return launch_rel_attn_fwd<float>(P, ldp, QZ, ldqz, RR, ldrr, a_att, col, etype, by_dst, N, d, slope, loop_rel, self_off,
+    return launch_rel_attn_fwd<float>(P, ldp, QZ, ldqz, RR, ldrr, d, a_att, col, etype, by_dst, N, d, slope, loop_rel, self_off,
                                       out_scale, out, ldo, seg_max, seg_den, ws, ws_bytes, stream);
 }
 
@@ -1271,7 +1769,16 @@ int jmac_rel_attn_aggregate_fwd_bf16(const uint16_t* P, int64_t ldp, const uint1
                                      const jmac_view_t* by_dst, int64_t N, int64_t d, float slope, int32_t loop_rel,
                                      int64_t self_off, float out_scale, float* out, int64_t ldo, float* seg_max, float* seg_den,
                                      void* ws, size_t ws_bytes, jmac_stream_t stream) {
-    return launch_rel_attn_fwd<bf16_t>(P, ldp, QZ, ldqz, RR, ldrr, a_att, col, etype, by_dst, N, d, slope, loop_rel, self_off,
+    return launch_rel_attn_fwd<bf16_t>(P, ldp, QZ, ldqz, RR, ldrr, d, a_att, col, etype, by_dst, N, d, slope, loop_rel, self_off,
+                                       out_scale, out, ldo, seg_max, seg_den, ws, ws_bytes, stream);
+}
+
+int jmac_rel_attn_aggregate_fwd_bf16_padded(const uint16_t* P, int64_t ldp, const uint16_t* QZ, int64_t ldqz, const uint16_t* RR,
+                                            int64_t ldrr, int64_t dh, const float* a_att, const int32_t* col, const int32_t* etype,
+                                            const jmac_view_t* by_dst, int64_t N, int64_t d, float slope, int32_t loop_rel,
+                                            int64_t self_off, float out_scale, float* out, int64_t ldo, float* seg_max,
+                                            float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    return launch_rel_attn_fwd<bf16_t>(P, ldp, QZ, ldqz, RR, ldrr, dh, a_att, col, etype, by_dst, N, d, slope, loop_rel, self_off,
                                        out_scale, out, ldo, seg_max, seg_den, ws, ws_bytes, stream);
 }
 

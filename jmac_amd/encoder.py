@@ -116,11 +116,12 @@ def _empty(dev, *shape):
 
 
 def _agg_fwd(PQZ, RR, a, graph: RelGraph, slope, out_scale=0.5):
-    """jmac_rel_attn_aggregate_fwd_{f32,bf16} on the [P|Q|Z] table (fp32, or bf16 for the inference form: sums, softmax and
-    the output stay fp32); the self loop is the last relation row."""
+    """jmac_rel_attn_aggregate_fwd_{f32,bf16,bf16_padded} on the [P|Q|Z] table (fp32, or bf16 for the inference form: sums,
+    softmax and the output stay fp32; bf16 tables may carry padded halves, ops.bf16_pad); the self loop is the last relation
+    row."""
     L = lib()
     N, d3 = PQZ.shape
-    d = d3 // 3
+    dh, d = d3 // 3, int(a.numel())
     dev = PQZ.device
     bf16 = PQZ.dtype == torch.bfloat16
     out, smax, sden = _empty(dev, N, d), _empty(dev, max(N, 1)), _empty(dev, max(N, 1))
@@ -128,11 +129,19 @@ def _agg_fwd(PQZ, RR, a, graph: RelGraph, slope, out_scale=0.5):
     wsb = int(L.jmac_rel_attn_fwd_workspace_bytes(s.n_parts_max, d))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     ev0 = ops._ev() if ops.PROFILE is not None else None
-    fwd = L.jmac_rel_attn_aggregate_fwd_bf16 if bf16 else L.jmac_rel_attn_aggregate_fwd_f32
-    check(fwd(
-        ptr(PQZ), d3, PQZ.data_ptr() + d * PQZ.element_size(), d3, ptr(RR), RR.stride(0), ptr(a), ptr(graph.col), ptr(graph.etype),
-        C.byref(s.view()), N, d, float(slope), RR.shape[0] - 1, 0, float(out_scale), ptr(out), d, ptr(smax), ptr(sden),
-        ptr(ws), wsb, stream()), "jmac_rel_attn_aggregate_fwd_%s" % ("bf16" if bf16 else "f32"))
+    if dh != d:
+        if not bf16 or RR.shape[1] != 2 * dh:
+            raise ValueError("padded table halves exist for bf16 tables only")
+        check(L.jmac_rel_attn_aggregate_fwd_bf16_padded(
+            ptr(PQZ), d3, PQZ.data_ptr() + dh * PQZ.element_size(), d3, ptr(RR), RR.stride(0), dh, ptr(a), ptr(graph.col),
+            ptr(graph.etype), C.byref(s.view()), N, d, float(slope), RR.shape[0] - 1, 0, float(out_scale), ptr(out), d, ptr(smax),
+            ptr(sden), ptr(ws), wsb, stream()), "jmac_rel_attn_aggregate_fwd_bf16_padded")
+    else:
+        fwd = L.jmac_rel_attn_aggregate_fwd_bf16 if bf16 else L.jmac_rel_attn_aggregate_fwd_f32
+        check(fwd(
+            ptr(PQZ), d3, PQZ.data_ptr() + d * PQZ.element_size(), d3, ptr(RR), RR.stride(0), ptr(a), ptr(graph.col), ptr(graph.etype),
+            C.byref(s.view()), N, d, float(slope), RR.shape[0] - 1, 0, float(out_scale), ptr(out), d, ptr(smax), ptr(sden),
+            ptr(ws), wsb, stream()), "jmac_rel_attn_aggregate_fwd_%s" % ("bf16" if bf16 else "f32"))
     if ev0 is not None:
         ops.PROFILE.append(("rel_attn_fwd_bf16" if bf16 else "rel_attn_fwd", ev0, ops._ev()))
     return out, smax, sden
@@ -443,8 +452,18 @@ def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch
     ``table_dtype`` bf16 (inference form, no backward: BASELINE config 3): the [P|Q|Z] table comes out of a bf16 GEMM and the
     relation table is rounded to bf16; the aggregation gathers half the bytes, its arithmetic and everything after it is fp32."""
     if table_dtype == torch.bfloat16:
-        PQZ = torch.mm(X.to(torch.bfloat16), wc.to(torch.bfloat16))
-        RR = RR.to(torch.bfloat16)
+        # padded halves where the half-wave kernel has a form for them (d = 300 -> 304: 16-byte lane loads); the pad columns
+        # of the weight are zero, so the GEMM writes zero pad columns
+        d = wc.shape[0]
+        dh = ops.bf16_pad(d)
+        PQZ = torch.mm(X.to(torch.bfloat16), ops.pad_table_weight(wc, d, 3).to(torch.bfloat16))
+        if dh != d:
+            RRp = torch.zeros((RR.shape[0], 2 * dh), dtype=torch.bfloat16, device=RR.device)
+            RRp[:, :d] = RR[:, :d]
+            RRp[:, dh:dh + d] = RR[:, d:]
+            RR = RRp
+        else:
+            RR = RR.to(torch.bfloat16)
     else:
         PQZ = torch.mm(X, wc)                                         # [P|Q|Z]: one library GEMM
     slope = float(lay.atv_mlp.negative_slope)

@@ -50,7 +50,14 @@ SMALL_BWD_CHUNK = 32
 # cooperative splits (forward kernel, small graphs): rows longer than COOP_MIN and up to COOP_MAX entries are processed by
 # the four waves of one workgroup and merged in LDS.  Measured on the DBP-5L ja shape: the kernel's duration was set by
 # its longest row (28 entries = 14 dependent gather rounds in one wave); capping the rows at 8 entries took 19.4 -> 15.8 us.
-COOP_MIN, COOP_MAX = 8, 256
+COOP_MIN, COOP_MAX = int(os.environ.get("JMAC_COOP_MIN", "8")), 256     # env: tuning knob (debug)
+# ... and on graphs past COOP_SIZE_SPLIT items, which have the waves to hide a longer row behind, only rows longer than this
+# (56 589-entity union, bf16 tables: 87.3 / 79.1 / 76.5 us at 8 / 12 / 16, fp32 tables 116 +- 1 us at any of them)
+COOP_MIN_LARGE, COOP_SIZE_SPLIT = int(os.environ.get("JMAC_COOP_MIN_LARGE", "16")), 16384
+
+
+def coop_min_for(n_seg: int, n_entries: int, chunk: int) -> int:
+    return COOP_MIN if n_seg + n_entries // max(chunk, 1) + 1 <= COOP_SIZE_SPLIT else COOP_MIN_LARGE
 
 
 class _Schedule:
@@ -62,7 +69,7 @@ class _Schedule:
         dev = seg_ptr.device
         self.ptr = seg_ptr
         self.order = order
-        cmin, cmax = (COOP_MIN, COOP_MAX) if coop else (0, 0)
+        cmin, cmax = (coop_min_for(n_seg, n_entries, chunk), COOP_MAX) if coop else (0, 0)
         self.n_items_max = int(L.jmac_items_max(n_seg, n_entries, chunk, cmin))
         self.n_splits_max = int(L.jmac_splits_max(n_entries, chunk, cmin))
         self.n_parts_max = int(L.jmac_parts_max(n_entries, chunk, cmin))

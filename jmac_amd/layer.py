@@ -139,9 +139,10 @@ class RelationAwareLayer(nn.Module):
         if self.table_dtype == torch.bfloat16:
             if torch.is_grad_enabled() and (ent_emb.requires_grad or self.w_att.requires_grad):
                 raise RuntimeError("table_dtype=bfloat16 is the inference form of the layer: call it under torch.no_grad()")
-            wcat = _wcat(self.w_att, self.gcn_weight, d_in, d, dp).to(torch.bfloat16)
-            PQZ = torch.mm(ent_emb.to(torch.bfloat16), wcat)              # [N, 3dp]
-            RR = torch.mm(rel.to(torch.bfloat16), wcat[:, dp:])           # [nr+1, 2dp]
+            dh = ops.bf16_pad(dp)                                         # padded halves (300 -> 304): 16-byte lane loads
+            wcat = ops.pad_table_weight(_wcat(self.w_att, self.gcn_weight, d_in, d, dp), dp, 3).to(torch.bfloat16)
+            PQZ = torch.mm(ent_emb.to(torch.bfloat16), wcat)              # [N, 3dh]
+            RR = torch.mm(rel.to(torch.bfloat16), wcat[:, dh:])           # [nr+1, 2dh]
             return PQZ, RR, a.float(), dp
         PQZ, RR = _ProjectTables.apply(ent_emb, rel, self.w_att, self.gcn_weight, dp)
         return PQZ, RR, a.float(), dp

@@ -44,6 +44,30 @@ def _table(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def bf16_pad(d: int) -> int:
+    """Half pitch of the PADDED bf16 tables the half-wave aggregation kernel reads (16-byte aligned halves: a multiple of
+    8 elements): d = 300 -> 304; d itself where no padded form exists."""
+    return 304 if d == 300 else d
+
+
+def pad_table_weight(w: torch.Tensor, d: int, parts: int) -> torch.Tensor:
+    """[k, parts*d] projection weight -> [k, parts*bf16_pad(d)] with zero pad columns behind every d-wide part: the GEMM then
+    writes [P|Q|Z] / [Rq|Rz] rows in the padded layout, pad columns zero."""
+    dh = bf16_pad(d)
+    if dh == d:
+        return w
+    out = w.new_zeros((w.shape[0], parts * dh))
+    for p_ in range(parts):
+        out[:, p_ * dh:p_ * dh + d] = w[:, p_ * d:(p_ + 1) * d]
+    return out
+
+
+def pad_table(t: torch.Tensor, d: int, parts: int) -> torch.Tensor:
+    """[n, parts*d] table -> the padded layout [n, parts*bf16_pad(d)] (zero pad columns); benchmarks and tests that build
+    their tables directly use it -- the layers get the layout from the GEMM (pad_table_weight)."""
+    return pad_table_weight(t, d, parts)
+
+
 class _RelAttnAggregate(torch.autograd.Function):
     """out = out_scale * ( sqrt(deg) * softmax-weighted sum over in-edges of (Z[j]-Rz[t]) + [Z[i]-Rz[loop]] ).
 
@@ -58,7 +82,10 @@ class _RelAttnAggregate(torch.autograd.Function):
             raise TypeError("PQZ and RR must share a dtype")
         bf16 = PQZ.dtype == torch.bfloat16
         N, d3 = PQZ.shape
-        d = d3 // 3
+        dh = d3 // 3                       # half pitch of the table rows; > d for padded bf16 tables (bf16_pad)
+        d = int(a.numel())
+        if dh != d and not (bf16 and dh == bf16_pad(d) and RR.shape[1] == 2 * dh):
+            raise ValueError("tables of half pitch %d do not go with a_att of %d elements" % (dh, d))
         if graph.N != N:
             raise ValueError("graph has %d nodes, tables have %d rows" % (graph.N, N))
         L = lib()
@@ -71,12 +98,18 @@ class _RelAttnAggregate(torch.autograd.Function):
         ws = _ws(ws_bytes, dev)
         esz = PQZ.element_size()
         ev0 = _ev() if PROFILE is not None else None
-        fwd = L.jmac_rel_attn_aggregate_fwd_bf16 if bf16 else L.jmac_rel_attn_aggregate_fwd_f32
-        check(fwd(
-            ptr(PQZ), d3, PQZ.data_ptr() + d * esz, d3, ptr(RR), RR.shape[1], ptr(a),
-            ptr(graph.col), ptr(graph.etype), C.byref(s.view()), N, d, float(slope), int(loop_rel), 0, float(out_scale),
-            ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(ws), ws_bytes, stream()),
-            "jmac_rel_attn_aggregate_fwd_%s" % ("bf16" if bf16 else "f32"))
+        if dh != d:
+            check(L.jmac_rel_attn_aggregate_fwd_bf16_padded(
+                ptr(PQZ), d3, PQZ.data_ptr() + dh * esz, d3, ptr(RR), RR.shape[1], dh, ptr(a),
+                ptr(graph.col), ptr(graph.etype), C.byref(s.view()), N, d, float(slope), int(loop_rel), 0, float(out_scale),
+                ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(ws), ws_bytes, stream()), "jmac_rel_attn_aggregate_fwd_bf16_padded")
+        else:
+            fwd = L.jmac_rel_attn_aggregate_fwd_bf16 if bf16 else L.jmac_rel_attn_aggregate_fwd_f32
+            check(fwd(
+                ptr(PQZ), d3, PQZ.data_ptr() + d * esz, d3, ptr(RR), RR.shape[1], ptr(a),
+                ptr(graph.col), ptr(graph.etype), C.byref(s.view()), N, d, float(slope), int(loop_rel), 0, float(out_scale),
+                ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(ws), ws_bytes, stream()),
+                "jmac_rel_attn_aggregate_fwd_%s" % ("bf16" if bf16 else "f32"))
         if ev0 is not None:
             PROFILE.append(("rel_attn_fwd_bf16" if bf16 else "rel_attn_fwd", ev0, _ev()))
         if bf16:

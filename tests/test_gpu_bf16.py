@@ -39,6 +39,15 @@ def test_bf16_aggregate_matches_oracle_on_rounded_tables(n, nr, e, d, hub, chunk
     assert out.dtype == torch.float32
     assert_close(out, ref, 1e-4, what="bf16 aggregate")
     assert rel_err(out, ref) < 2e-5
+    # the layout the layers produce: halves padded to a multiple of 8 elements (d = 300 -> 304, zero pad columns) -- the
+    # half-wave kernel's 16-byte lane loads; same values, so the same result up to the summation order
+    if ops.bf16_pad(d) != d:
+        with torch.no_grad():
+            out_p = ops.rel_attn_aggregate(ops.pad_table(PQZ, d, 3).cuda(), ops.pad_table(RR, d, 2).cuda(), a.cuda(), g, 0.05,
+                                           nr - 1 if loop else -1, 0.5)
+        assert out_p.shape == out.shape
+        assert_close(out_p, ref, 1e-4, what="bf16 aggregate, padded halves")
+        assert rel_err(out_p, ref) < 2e-5
 
 
 def test_bf16_tables_refuse_autograd():

@@ -41,7 +41,7 @@ def test_csr_and_schedules(n, nr, e, chunk):
     assert cnt[3] == sch.n_empty and cnt[4] == sch.n_coop
     small = e > 0 and n + e // chunk + 1 <= jgraph.INLINE_EDGES_MAX_ITEMS
     degs = np.diff(rowptr)
-    is_coop = (degs > jgraph.COOP_MIN) & (degs <= jgraph.COOP_MAX) if small else np.zeros(n, bool)
+    is_coop = (degs > jgraph.coop_min_for(n, e, chunk)) & (degs <= jgraph.COOP_MAX) if small else np.zeros(n, bool)
     assert sch.n_coop == int(is_coop.sum()) and sch.n_empty == int((degs == 0).sum())
     cover = np.zeros(max(e, 1), dtype=np.int64)
     seen_rows = np.zeros(n, dtype=np.int64)

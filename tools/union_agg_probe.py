@@ -26,11 +26,12 @@ def t(fn, k=50):
     for _ in range(k): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / k * 1e3
-out = {"JMAC_SMALL_ITEMS": os.environ.get("JMAC_SMALL_ITEMS"), "JMAC_FWD_U": os.environ.get("JMAC_FWD_U"), "N": n, "E": int(ei.shape[1]),
+out = {"env": {k: v for k, v in os.environ.items() if k.startswith("JMAC_")}, "N": n, "E": int(ei.shape[1]),
        "items": g.by_dst.n_items_max, "coop": g.by_dst.n_coop, "inline": g.by_dst.item_edges is not None}
 with torch.no_grad():
     out["fwd_f32_us"] = t(lambda: ops.rel_attn_aggregate(PQZ, RR, av, g, 0.05, nr, 0.5))
-    P16, R16 = PQZ.to(torch.bfloat16), RR.to(torch.bfloat16)
+    pad = os.environ.get("JMAC_FWD_HW", "1") != "0"
+    P16, R16 = (ops.pad_table(PQZ.to(torch.bfloat16), d, 3), ops.pad_table(RR.to(torch.bfloat16), d, 2)) if pad else (PQZ.to(torch.bfloat16), RR.to(torch.bfloat16))
     out["fwd_bf16_us"] = t(lambda: ops.rel_attn_aggregate(P16, R16, av, g, 0.05, nr, 0.5))
 Pq = PQZ.clone().requires_grad_(True); Rq = RR.clone().requires_grad_(True); aq = av.clone().requires_grad_(True)
 o = ops.rel_attn_aggregate(Pq, Rq, aq, g, 0.05, nr, 0.5, 1)
