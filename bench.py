@@ -34,6 +34,7 @@ import numpy as np
 import torch
 
 REAL_DATA = os.path.join(ROOT, "tests", "golden", "dbp5l_ja_el_data.npz")   # the real el / ja triples as integer arrays
+REAL_ALL = os.path.join(ROOT, "tests", "golden", "dbp5l_all_data.npz")      # all five real KGs + the ten seed-pair files
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 
 
@@ -818,19 +819,38 @@ def sim_bench(device, iters=10, cpu=True):
 
 
 def union_bench(a, device, cpu=True):
-    """BASELINE configs[2]: the block-diagonal union of the five DBP-5L-shaped KGs (N = 56 589 entities, 5 x 961 relation
-    rows, E = 197 604 = train + validation triples of the four supporters + the target's train triples) with bf16 tables:
-    the encoder forward (three layers, bf16 [P|Q|Z] / [Rq|Rz] tables, fp32 logits / softmax / sums / BN) and the fused
-    completion scoring of B = 1000 queries against ALL 56 589 entities over 2 layers (jmac_linkpred_rank_bf16: filtered
+    """BASELINE configs[2] on the REAL data: the block-diagonal union of the five DBP-5L KGs (tests/golden/dbp5l_all_data.npz, the
+    reference's id offsets src/data_loader.py:162-181: N = 56 589 entities, 5 x 961 relation rows, E = 197 604 = train +
+    validation triples of the four supporters + the target's train triples) with bf16 tables: the encoder forward (three
+    layers, bf16 [P|Q|Z] / [Rq|Rz] tables, fp32 logits / softmax / sums / BN) and the fused completion scoring of B = 1000 real
+    ja validation queries against ALL 56 589 entities over 2 layers, filtered with ja's true tails (jmac_linkpred_rank_bf16:
     ranks, no [B, N] matrix).  The reference scores inside the target KG only (src/validate.py:43-44); the union is the
-    scale-up BASELINE names, with its parity checked in tests/test_gpu_fullsize.py.  CPU beside it: the oracle's encoder
+    scale-up BASELINE names, with its parity checked in tests/test_gpu_union_real.py.  Weights / name embeddings: seeded random
+    (no checkpoints offline).  ``--data synthetic``: the seeded union of the same shape.  CPU beside it: the oracle's encoder
     forward and its cdist + filter + rank on the same tables (fp32: the reference has no bf16 form)."""
     from jmac_amd import ops, scoring, synth
     from jmac_amd.graph import RelGraph
     from jmac_amd.model import JMAC
-    ei, et, n, nr, ent_bases, rel_bases = synth.dbp5l_union(1234, target="ja")
-    E, d, B = int(ei.shape[1]), a.dim, a.batch
     rng = np.random.default_rng(11)
+    B = a.batch
+    real = a.data == "real" and os.path.exists(REAL_ALL)
+    if real:
+        from jmac_amd import data as jdata
+        kgs, _, _, _ = jdata.kgs_from_arrays(jdata.load_dbp5l_arrays(REAL_ALL), "ja")
+        ei, et, n, nr, ent_bases, rel_bases = jdata.union_edges(kgs)
+        ja = kgs["ja"]
+        val = ja.val_data[rng.permutation(len(ja.val_data))[:B]]
+        hb, rb, gold_h = val[:, 0] + ja.entity_id_base, val[:, 1] + ja.relation_id_base, val[:, 2] + ja.entity_id_base
+        lists = [np.unique(np.asarray(ja.true_tail.get((int(h_), int(r_)), []), dtype=np.int64)) + ja.entity_id_base
+                 for h_, r_ in zip(val[:, 0], val[:, 1])]
+        fptr_h = np.concatenate(([0], np.cumsum([len(x) for x in lists]))).astype(np.int32)
+        fidx_h = (np.concatenate(lists) if fptr_h[-1] else np.zeros(1)).astype(np.int32)
+    else:
+        ei, et, n, nr, ent_bases, rel_bases = synth.dbp5l_union(1234, target="ja")
+        hb, rb, gold_h = rng.integers(0, n, B), rng.integers(0, nr, B), rng.integers(0, n, B)
+        fptr_h = np.arange(0, 3 * B + 1, 3, dtype=np.int32)
+        fidx_h = rng.integers(0, n, 3 * B).astype(np.int32)
+    E, d = int(ei.shape[1]), a.dim
     torch.manual_seed(11)
     margs = make_args(d, B, a.negatives, device)
     name_emb = rng.standard_normal((n, 300)).astype(np.float32)
@@ -839,10 +859,7 @@ def union_bench(a, device, cpu=True):
     m.set_table_dtype(torch.bfloat16)
     m.eval()
     ei_t, et_t = torch.from_numpy(ei).to(device), torch.from_numpy(et).to(device)
-    hb, rb, gold_h = rng.integers(0, n, B), rng.integers(0, nr, B), rng.integers(0, n, B)
-    fptr_h = np.arange(0, 3 * B + 1, 3, dtype=np.int32)
-    fidx_h = rng.integers(0, n, 3 * B).astype(np.int32)
-    hb_d, rb_d, gold = (torch.from_numpy(x).to(device) for x in (hb, rb, gold_h))
+    hb_d, rb_d, gold = (torch.from_numpy(np.asarray(x, dtype=np.int64)).to(device) for x in (hb, rb, gold_h))
     fptr, fidx = torch.from_numpy(fptr_h).to(device), torch.from_numpy(fidx_h).to(device)
     with torch.no_grad():
         enc = lambda: m.forward_base(ei_t, et_t, [0, n], [0, nr])
@@ -894,8 +911,10 @@ def union_bench(a, device, cpu=True):
         agg_ms = e0.elapsed_time(e1) / 50
     fb16 = synth.fwd_algorithmic_bytes(n, E, d, 2)
     elems = float(B) * n * d * 2                                   # (b, n, k) triples over the two layers
-    res = {"workload": "config 3: union of the five DBP-5L-shaped KGs, N=%d E=%d nr=%d d=%d, bf16 tables; scoring B=%d x N x 2 layers"
-                       % (n, E, nr, d, B),
+    res = {"workload": "config 3: union of the five %s KGs, N=%d E=%d nr=%d d=%d, bf16 tables; scoring B=%d %s x N x 2 layers"
+                       % ("REAL DBP-5L (el, en, es, fr, ja; committed integer arrays)" if real else "DBP-5L-shaped synthetic", n, E, nr, d, B,
+                          "real ja validation queries, filtered" if real else "random queries"),
+           "data": "real" if real else "synthetic",
            "encoder_fwd_ms": enc_ms, "encoder_fwd_edges_per_s": 3 * E / (enc_ms * 1e-3),
            "encoder_fwd_hipgraph_ms": enc_graph_ms,
            "encoder_fwd_hipgraph_edges_per_s": (3 * E / (enc_graph_ms * 1e-3)) if enc_graph_ms else None,
@@ -913,6 +932,11 @@ def union_bench(a, device, cpu=True):
                                     "algorithmic_bytes_per_launch": fb16, "achieved": fb16 / (agg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": fb16 / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "note": "%.0f MB per launch: Infinity-Cache resident" % (fb16 / 1e6)}}
+    if real:
+        try:
+            res["train_mode"] = union_train_step(a, device, m, kgs)
+        except Exception as ex:                            # pragma: no cover
+            res["train_mode"] = {"error": str(ex)}
     if cpu:
         import oracle.jmac_oracle as orc
         st = {k: v.detach().cpu() for k, v in m.state_dict().items()}
@@ -995,6 +1019,84 @@ def pair_bench(a, device, rank, ms_single, cpu=True):
     except Exception as ex:                                 # pragma: no cover
         res["separate_calls_error"] = str(ex)
     return res
+
+
+def union_train_step(a, device, m, kgs):
+    """Train-mode config 3: the five real KGs encoded as ONE launch set with per-KG BatchNorm statistics (JMAC.forward_stacked),
+    a completion margin loss on a batch of the target's triples (both layers) + a cosine term on the el-ja seed links of the
+    alignment output, backward through all three layers of all five KGs, Adam; fp32 tables (training form), one hipGraph.
+    Beside it: the same step as five forward_base calls."""
+    from jmac_amd import losses
+    from jmac_amd.data import edges_from_triples
+    m.set_table_dtype(torch.float32)
+    m.train()
+    blocks, E = [], 0
+    for lang in sorted(kgs):
+        kg = kgs[lang]
+        ei, et = edges_from_triples(kg.train_data, False)
+        E += ei.shape[1]
+        blocks.append((torch.from_numpy(ei).to(device), torch.from_numpy(et).to(device), [kg.entity_id_base, kg.upper_entity_base],
+                       [kg.relation_id_base, kg.upper_relation_base]))
+    ja = kgs["ja"]
+    rng = np.random.default_rng(3)
+    B, K = a.batch, a.negatives
+    trip = ja.train_data[rng.integers(0, len(ja.train_data), B)]
+    h = torch.from_numpy(np.tile(trip[:, 0], K + 1)).to(device)
+    r = torch.from_numpy(np.tile(trip[:, 1], K + 1)).to(device)
+    t = torch.from_numpy(np.concatenate([trip[:, 2], rng.integers(0, ja.num_entity, B * K)])).to(device)
+    pairs = torch.from_numpy(rng.integers(0, ja.num_entity, (2000, 2))).to(device)
+    p0, p1 = pairs[:, 0].contiguous(), pairs[:, 1].contiguous()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True, capturable=True)
+    k_ja = sorted(kgs).index("ja")
+
+    def make(batched):
+        def step():
+            opt.zero_grad(set_to_none=True)
+            m.batched_pairs = batched
+            st = m.forward_stacked(blocks)
+            if st is None:
+                outs = [m.forward_base(*b) for b in blocks]
+                al, comp, rel = outs[k_ja]
+                loss = sum(losses.triple_l1_margin_loss(c, rl, h, r, t, B, m.margin_completion) for c, rl in zip(comp, rel))
+                loss = loss + losses.pair_cosine_distance(al, p0, al, p1).mean() + sum(o[0].mean() for o in outs) * 1e-3
+            else:
+                loss = sum(losses.triple_l1_margin_loss(c, rl, h, r, t, B, m.margin_completion, st.ent_win[k_ja], st.rel_win[k_ja])
+                           for c, rl in zip(st.comp, st.rel))
+                loss = loss + losses.pair_cosine_distance(st.align_out, p0, st.align_out, p1, st.ent_win[k_ja], st.ent_win[k_ja]).mean()
+                loss = loss + st.align_out.mean() * 5e-3        # every KG's alignment output takes part (as in the separate form)
+            loss.backward()
+            opt.step()
+            return loss
+        return step
+    out = {"workload": "forward_stacked over the five real KGs (per-KG BatchNorm statistics), fp32 tables, losses on the ja block, "
+                       "backward through 3 layers x 5 KGs, Adam", "E": E}
+    for key, batched in (("ms_per_step", True), ("separate_calls_ms_per_step", False)):
+        step = make(batched)
+        w = types_ns(step=step)
+        if not a.no_gemm_tuning:
+            enable_gemm_tuning(0)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        if not a.no_gemm_tuning:
+            freeze_gemm_tuning()
+        fn = step
+        if not a.no_graph:
+            try:
+                fn = try_capture(w).replay
+            except Exception as ex:                        # pragma: no cover
+                sys.stderr.write("union train step: hipGraph capture failed (%s)\n" % (ex,))
+                torch.cuda.synchronize()
+        out[key] = time_steps(fn, 20, 3, False) / 20 * 1e3
+    out["edges_per_s"] = 3 * E / (out["ms_per_step"] * 1e-3)
+    out["speedup_over_separate_calls"] = out["separate_calls_ms_per_step"] / out["ms_per_step"]
+    m.batched_pairs = True
+    return out
+
+
+def types_ns(**kw):
+    import types
+    return types.SimpleNamespace(**kw)
 
 
 def synth_cpu_layer(scale, d):

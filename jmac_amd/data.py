@@ -134,3 +134,59 @@ def load_dbp5l(data_path: str, target_language: str):
             out[(f[0:2], f[3:5])] = _read_ints(os.path.join(d, f), 2)
         return out
     return kgs, seeds("seed_train_pairs"), seeds("seed_test_pairs"), ebase
+
+
+def kgs_from_arrays(z: Dict[str, np.ndarray], target_language: str):
+    """``load_dbp5l`` on the integer-array form of the dataset (``load_dbp5l_arrays``: tests/golden/dbp5l_all_data.npz holds all
+    five KGs and the ten seed-pair files, dbp5l_ja_el_data.npz the el / ja pair): the same KnowledgeGraph objects, id bases
+    (src/data_loader.py:162-181) and seed dictionaries, without the text files."""
+    names = sorted(str(x) for x in z["langs"])
+    num_rel = int(z["n_relation_lines"]) + 1
+    kgs: Dict[str, KnowledgeGraph] = {}
+    ebase = rbase = 0
+    for lang in names:
+        tr, va, te = (np.asarray(z["%s.%s" % (lang, part)], dtype=np.int64).reshape(-1, 3) for part in ("train", "val", "test"))
+        n_ent = int(z[lang + ".num_entity"])
+        sup = lang != target_language
+        kg = KnowledgeGraph(lang, np.concatenate((tr, va)) if sup else tr, va, te, n_ent, num_rel, sup, ebase, rbase)
+        if not sup:
+            kg.true_tail = true_tail_dict(np.concatenate((tr, va, te), axis=0))
+        ebase += n_ent
+        rbase += num_rel
+        kg.upper_entity_base, kg.upper_relation_base = ebase, rbase
+        send, recv, typ = [tr[:, 0], tr[:, 2]], [tr[:, 2], tr[:, 0]], [tr[:, 1], tr[:, 1]]     # src/utils.py:127-149
+        if sup:
+            send += [va[:, 0], va[:, 2]]
+            recv += [va[:, 2], va[:, 0]]
+            typ += [va[:, 1], va[:, 1]]
+        kg.edge_index, kg.edge_type = np.vstack((np.concatenate(send), np.concatenate(recv))), np.concatenate(typ)
+        kgs[lang] = kg
+    seeds = {"seed_train_pairs": {}, "seed_test_pairs": {}}
+    if "seed_pairs" in z:
+        for pr in [str(x) for x in z["seed_pairs"]]:
+            for sub in seeds:
+                seeds[sub][(pr[0:2], pr[3:5])] = np.asarray(z["%s.%s" % (sub, pr)], dtype=np.int64).reshape(-1, 2)
+    else:
+        pr = tuple(str(x) for x in z["seed_pair"])
+        for sub in seeds:
+            seeds[sub][pr] = np.asarray(z[sub], dtype=np.int64).reshape(-1, 2)
+    return kgs, seeds["seed_train_pairs"], seeds["seed_test_pairs"], ebase
+
+
+def union_edges(kgs: Dict[str, KnowledgeGraph], bidirectional: bool = False):
+    """BASELINE config 3: the block-diagonal union of the KGs in the model's id spaces -- entity ids offset by
+    ``entity_id_base``, relation ids by ``relation_id_base`` (src/data_loader.py:162-181) -- as ONE typed edge list.
+    ``bidirectional=False``: the train-mode graph of every KG (train.py:116-135 on ``train_data``: supporters train + val,
+    the target train); ``True``: the loader's bidirectional graphs (src/utils.py:112-149).
+    Returns (edge_index [2,E], edge_type [E], N, nr, ent_bases, rel_bases) with ``ent_bases[k] .. ent_bases[k+1]`` the rows of
+    the k-th KG in sorted-name order."""
+    eis, ets, ent_bases, rel_bases = [], [], [0], [0]
+    for lang in sorted(kgs):
+        kg = kgs[lang]
+        assert kg.entity_id_base == ent_bases[-1] and kg.relation_id_base == rel_bases[-1]
+        ei, et = (kg.edge_index, kg.edge_type) if bidirectional else edges_from_triples(kg.train_data, False)
+        eis.append(np.asarray(ei, dtype=np.int64) + kg.entity_id_base)
+        ets.append(np.asarray(et, dtype=np.int64) + kg.relation_id_base)
+        ent_bases.append(kg.upper_entity_base)
+        rel_bases.append(kg.upper_relation_base)
+    return np.concatenate(eis, axis=1), np.concatenate(ets), ent_bases[-1], rel_bases[-1], ent_bases, rel_bases

@@ -688,6 +688,59 @@ def gen_realpair():
             print("  ", k, out[k])
 
 
+def gen_realall():
+    """BASELINE config 3's data: ALL FIVE real DBP-5L KGs (el, en, es, fr, ja: train / val / test triples) and the ten seed-pair
+    files as integer arrays (dbp5l_all_data.npz; entity / relation names are not kept -- the loaders only count those lines).
+    As for the el / ja pair (gen_realpair), tests/util.py:write_dbp5l_dir turns the arrays back into the dataset's on-disk
+    format in a temporary directory, the REFERENCE's loader reads that directory here (target_language = ja) and its arrays
+    are pinned by shape, id bases, digests and degrees (dbp5l_all.npz)."""
+    from src.data_loader import ParseData
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from util import write_dbp5l_dir
+    src = os.path.join(REF, "datasetdbp5l")
+    langs = sorted(f[:2] for f in os.listdir(os.path.join(src, "entity")) if f.endswith(".tsv"))
+    data = {"langs": np.array(langs), "n_relation_lines": np.int64(sum(1 for _ in open(os.path.join(src, "relations.txt"))))}
+    for lang in langs:
+        data[lang + ".num_entity"] = np.int64(sum(1 for _ in open(os.path.join(src, "entity", lang + ".tsv"))))
+        for part in ("train", "val", "test"):
+            data["%s.%s" % (lang, part)] = np.loadtxt(os.path.join(src, "kg", "%s-%s.tsv" % (lang, part)), dtype=np.int64,
+                                                      delimiter="\t").reshape(-1, 3).astype(np.int32)
+    pairs = sorted(f[:5] for f in os.listdir(os.path.join(src, "seed_train_pairs")) if f.endswith(".tsv"))
+    data["seed_pairs"] = np.array(pairs)
+    for sub in ("seed_train_pairs", "seed_test_pairs"):
+        for pr in pairs:
+            data["%s.%s" % (sub, pr)] = np.loadtxt(os.path.join(src, sub, pr + ".tsv"), dtype=np.float64,
+                                                   delimiter="\t").reshape(-1, 2).astype(np.int32)
+    _save("dbp5l_all_data", **data)
+    root = write_dbp5l_dir(tempfile.mkdtemp(prefix="dbp5l_all_"), data)
+    lg = logging.getLogger("golden"); lg.setLevel(logging.ERROR)
+    pd_ = ParseData(types.SimpleNamespace(data_path=root, target_language="ja", device="cpu"), lg)
+    kgs, s_train, s_test = pd_.create_KG_objects_and_alignment()
+    out = {"kg_names": np.array(pd_.kg_names), "num_entities": np.int64(pd_.num_entities)}
+    for lang, kg in kgs.items():
+        ei = kg.edge_index.cpu().numpy() if hasattr(kg.edge_index, "cpu") else np.asarray(kg.edge_index)
+        et = kg.edge_type.cpu().numpy() if hasattr(kg.edge_type, "cpu") else np.asarray(kg.edge_type)
+        out[lang + ".meta"] = np.array([kg.num_entity, kg.num_relation, int(kg.is_supporter_kg), kg.entity_id_base,
+                                        kg.relation_id_base, kg.upper_entity_base, kg.upper_relation_base], dtype=np.int64)
+        out[lang + ".shapes"] = np.array([len(kg.train_data), len(kg.val_data), len(kg.test_data), ei.shape[1]], dtype=np.int64)
+        out[lang + ".digests"] = np.array([array_digest(kg.train_data), array_digest(kg.val_data), array_digest(kg.test_data),
+                                           array_digest(ei), array_digest(et)], dtype=np.uint64)
+        deg_in = np.bincount(ei[0], minlength=kg.num_entity)
+        out[lang + ".degree"] = np.array([deg_in.max(), int((deg_in == 0).sum())], dtype=np.int64)
+        tdeg = np.bincount(np.asarray(kg.train_data)[:, 0], minlength=kg.num_entity)       # train-mode graph: heads aggregate
+        out[lang + ".train_degree"] = np.array([tdeg.max(), int((tdeg == 0).sum())], dtype=np.int64)
+    for tag, sd in (("seeds_train", s_train), ("seeds_test", s_test)):
+        keys = sorted(sd)
+        out[tag + ".pairs"] = np.array(["%s-%s" % k for k in keys])
+        out[tag + ".sizes"] = np.array([len(sd[k]) for k in keys], dtype=np.int64)
+        out[tag + ".digests"] = np.array([array_digest(np.asarray(sd[k].cpu().numpy() if hasattr(sd[k], "cpu") else sd[k], dtype=np.int64))
+                                          for k in keys], dtype=np.uint64)
+    _save("dbp5l_all", **out)
+    for k in sorted(out):
+        if k.endswith("shapes") or k.endswith("meta") or k.endswith("degree"):
+            print("  ", k, out[k])
+
+
 def gen_dbpv1_model():
     """Model-level fixture of the DBPv1 variant (row a17): JMAC_DBPv1/models/jmac_model.py:116-277 JMAC_MODEL on one
     merged graph with inverse edges (jmac_trainer.py:93-96): forward_base, get_emb, completion_loss (rows L2-normalised
@@ -798,13 +851,13 @@ def gen_dbpv1():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variant", default="all", choices=["all", "root", "jafull", "dbpv1", "aligneval", "entr", "dataset", "realpair", "e2e"])
+    ap.add_argument("--variant", default="all", choices=["all", "root", "jafull", "dbpv1", "aligneval", "entr", "dataset", "realpair", "realall", "e2e"])
     a = ap.parse_args()
     if a.variant == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for v in ("root", "jafull", "dbpv1", "aligneval", "entr", "dataset", "realpair", "e2e"):
+        for v in ("root", "jafull", "dbpv1", "aligneval", "entr", "dataset", "realpair", "realall", "e2e"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--variant", v], env=env)
     else:
         _paths(a.variant)
-        {"root": gen_root, "jafull": gen_jafull, "dbpv1": gen_dbpv1, "aligneval": gen_aligneval, "entr": gen_entr, "dataset": gen_dataset, "realpair": gen_realpair,
+        {"root": gen_root, "jafull": gen_jafull, "dbpv1": gen_dbpv1, "aligneval": gen_aligneval, "entr": gen_entr, "dataset": gen_dataset, "realpair": gen_realpair, "realall": gen_realall,
          "e2e": gen_e2e}[a.variant]()

@@ -71,7 +71,12 @@ def write_dbp5l_dir(root, g):
             f.write("".join("%s%d\n" % (lang, i) for i in range(int(g[lang + ".num_entity"]))))
         for part in ("train", "val", "test"):
             np.savetxt(os.path.join(root, "kg", "%s-%s.tsv" % (lang, part)), g["%s.%s" % (lang, part)], fmt="%d", delimiter="\t")
-    pair = "-".join(str(x) for x in g["seed_pair"])
-    for sub in ("seed_train_pairs", "seed_test_pairs"):
-        np.savetxt(os.path.join(root, sub, pair + ".tsv"), g[sub].astype(np.float64), fmt="%.1f", delimiter="\t")
+    if "seed_pairs" in g:                                       # all KGs: one file per seed pair
+        for pr in [str(x) for x in g["seed_pairs"]]:
+            for sub in ("seed_train_pairs", "seed_test_pairs"):
+                np.savetxt(os.path.join(root, sub, pr + ".tsv"), g["%s.%s" % (sub, pr)].astype(np.float64), fmt="%.1f", delimiter="\t")
+    else:
+        pair = "-".join(str(x) for x in g["seed_pair"])
+        for sub in ("seed_train_pairs", "seed_test_pairs"):
+            np.savetxt(os.path.join(root, sub, pair + ".tsv"), g[sub].astype(np.float64), fmt="%.1f", delimiter="\t")
     return root
