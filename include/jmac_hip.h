@@ -516,6 +516,31 @@ int jmac_triple_l1_margin_bwd_f32(const float* ent, int64_t lde, const float* re
                                   int64_t d, const float* score, const float* gamma, const float* gloss,
                                   float* dent, int64_t ldde, float* drel, int64_t lddr, jmac_stream_t stream);
 
+/* Bitwise REPRODUCIBLE form of jmac_triple_l1_margin_bwd_f32 (same arguments + the row counts of the two gradient tables,
+ * which it scales in a second pass): the gradient of the margin ranking loss is (gloss / (2 B K)) times an INTEGER matrix (the
+ * weights of torch.max are 0, 1/2 or 1), so the float atomics add exact small integers -- order-independent below 2^24 -- and a
+ * scaling pass finishes the tables.  dent [n_ent rows] / drel [n_rel rows] must be ZERO on entry.  4 B K >= 2^24: the plain form. */
+int jmac_triple_l1_margin_bwd_exact_f32(const float* ent, int64_t lde, const float* rel, int64_t ldr, const int64_t* h,
+                                        const int64_t* r, const int64_t* t, int64_t B, int64_t K, int64_t d,
+                                        const float* score, const float* gamma, const float* gloss, float* dent,
+                                        int64_t ldde, int64_t n_ent, float* drel, int64_t lddr, int64_t n_rel,
+                                        jmac_stream_t stream);
+
+/* Pair cosine distance with a bitwise reproducible backward: the forward also leaves stats [L,4] = (a.b, a.a, b.b, 0) per pair;
+ * the backward walks the 2 L (pair, side) incidences in the order the HOST sorted them by the gradient row they touch (stable:
+ * ties in pair order) and writes every touched row ONCE with a plain store (sum in sorted order); untouched rows keep the
+ * caller's zero fill.  rec [2L][4] int32, one record per SORTED position: {pair x, own table row, partner table row,
+ * flags | gradient row} -- own / partner rows relative to the e1 / e2 pointers passed here; flags: bit 31 = first incidence of
+ * its gradient row, bit 30 = side 1 (own row in e2, partner in e1), bit 29 = the gradient row is a row of de2 (else de1);
+ * bits 0-28 = the gradient row.  The index vectors of an alignment loss are constant over many steps (seed links:
+ * train.py:347-352), so the host sorts once per index tensor (jmac_amd.losses._pair_index). */
+int jmac_pair_cosine_fwd_stats_f32(const float* e1, int64_t ld1, const float* e2, int64_t ld2, const int64_t* i1,
+                                   const int64_t* i2, int64_t L, int64_t d, float* dist, float* stats,
+                                   jmac_stream_t stream);
+int jmac_pair_cosine_bwd_sorted_f32(const float* e1, int64_t ld1, const float* e2, int64_t ld2, int64_t L, int64_t d,
+                                    const float* gdist, const float* stats, const int32_t* rec, float* de1, int64_t ldd1,
+                                    float* de2, int64_t ldd2, jmac_stream_t stream);
+
 /* dist[x] = 1 - <u, v>, u = e1[i1[x]] / max(||.||, 1e-12), v = e2[i2[x]] / max(||.||, 1e-12)
  * (replaces F.normalize(E[idx]) x2 + sum of alignment_loss / alignment_loss_simple,
  * src/jmac_model.py:245-247, 271-291). */

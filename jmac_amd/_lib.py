@@ -121,6 +121,9 @@ _SIGS = {
     "jmac_triple_l1_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp]),
     "jmac_triple_l1_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp, i64, vp, i64, vp]),
     "jmac_triple_l1_margin_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, i64, vp, i64, vp]),
+    "jmac_triple_l1_margin_bwd_exact_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, i64, i64, vp, i64, i64, vp]),
+    "jmac_pair_cosine_fwd_stats_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, vp]),
+    "jmac_pair_cosine_bwd_sorted_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, vp, vp, vp, vp, i64, vp, i64, vp]),
     "jmac_pair_cosine_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp]),
     "jmac_pair_cosine_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp]),
     "jmac_margin_loss_fwd_f32": (C.c_int, [vp, i64, i64, vp, vp, vp]),

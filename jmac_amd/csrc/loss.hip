@@ -100,7 +100,11 @@ struct MarginArgs {
     const float* gloss;
     int64_t B, K;
 };
-template <int NK, bool MARGIN>
+// EXACT (MARGIN only): every contribution of the margin ranking loss is an integer multiple of u = gloss / (2 B K) (the weights w
+// are 0, 1/2 or 1), so the kernel adds the INTEGERS G_x * sgn(.) with G_x = dscore_x / u -- sums of integers below 2^24 are exact
+// in fp32 whatever order the memory-side atomic units see them in -- and a scaling pass multiplies the finished tables by u:
+// bitwise reproducible gradients with the same atomics (launcher: jmac_triple_l1_margin_bwd_f32 whenever 4 B K < 2^24).
+template <int NK, bool MARGIN, bool EXACT = false>
 __global__ __launch_bounds__(kBlock) void triple_l1_bwd_kernel(const float* __restrict__ ent, int64_t lde,
                                                                const float* __restrict__ rel, int64_t ldr,
                                                                const int64_t* __restrict__ h, const int64_t* __restrict__ r,
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void triple_l1_bwd_kernel(const float* __re
     float mg_c = 0.f, mg_gamma = 0.f;
     if (MARGIN) {
         mg_gamma = ma.gamma[0];
-        mg_c = ma.gloss[0] / ((float)ma.B * (float)ma.K);
+        mg_c = EXACT ? 2.f : ma.gloss[0] / ((float)ma.B * (float)ma.K);      // EXACT: units of u (2 w is 0, 1 or 2)
     }
     auto gof = [&](int64_t x) -> float {                       // x is wave-uniform
         if (!MARGIN) return gscore[x];
@@ -236,7 +240,7 @@ template <bool VEC>
 __global__ __launch_bounds__(kBlock) void pair_cosine_fwd_kernel(const float* __restrict__ e1, int64_t ld1,
                                                                  const float* __restrict__ e2, int64_t ld2,
                                                                  const int64_t* __restrict__ i1, const int64_t* __restrict__ i2,
-                                                                 int64_t L, int d, float* __restrict__ dist) {
+                                                                 int64_t L, int d, float* __restrict__ dist, float* __restrict__ stats) {
     const int lane = lane_id();
     const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * kWavesPerBlock;
@@ -244,7 +248,10 @@ __global__ __launch_bounds__(kBlock) void pair_cosine_fwd_kernel(const float* __
         float ab, aa, bb;
         pair_dots<VEC>(e1 + i1[x] * ld1, e2 + i2[x] * ld2, d, lane, ab, aa, bb);
         const float na = fmaxf(sqrtf(aa), kNormEps), nb = fmaxf(sqrtf(bb), kNormEps);
-        if (lane == 0) dist[x] = 1.f - ab / (na * nb);
+        if (lane == 0) {
+            dist[x] = 1.f - ab / (na * nb);
+            if (stats) *reinterpret_cast<float4*>(stats + 4 * x) = make_float4(ab, aa, bb, 0.f);   // for the sorted backward
+        }
     }
 }
 
@@ -279,6 +286,96 @@ __global__ __launch_bounds__(kBlock) void pair_cosine_bwd_kernel(const float* __
             const float a = pa[cidx], b = pb[cidx];
             atomicAdd(qa + cidx, g * (b * inv - ka * a));
             atomicAdd(qb + cidx, g * (a * inv - kb * b));
+        }
+    }
+}
+
+// EXACT margin backward, second pass: the integer tables times u = gloss / (2 B K) (one launch for both tables)
+__global__ __launch_bounds__(kBlock) void scale_rows2_kernel(float* __restrict__ a, int64_t lda, int64_t rows_a, float* __restrict__ b,
+                                                             int64_t ldb, int64_t rows_b, int d, const float* __restrict__ gloss,
+                                                             float inv_2bk) {
+    const float u = gloss[0] * inv_2bk;
+    const int64_t na = rows_a * d, total = na + rows_b * d;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        float* p = i < na ? a + (i / d) * lda + (i % d) : b + ((i - na) / d) * ldb + ((i - na) % d);
+        *p *= u;
+    }
+}
+// the same for dense tables (ld == d, 16-byte aligned, d % 4 == 0): one flat float4 stream per table
+__global__ __launch_bounds__(kBlock) void scale_flat2_kernel(float4* __restrict__ a, int64_t na4, float4* __restrict__ b, int64_t nb4,
+                                                             const float* __restrict__ gloss, float inv_2bk) {
+    const float u = gloss[0] * inv_2bk;
+    const int64_t total = na4 + nb4;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        float4* p = i < na4 ? a + i : b + (i - na4);
+        float4 v = *p;
+        v.x *= u; v.y *= u; v.z *= u; v.w *= u;
+        *p = v;
+    }
+}
+
+// ---- pair cosine, deterministic backward -------------------------------------------------------------------------------------
+// The index vectors of an alignment loss are constant over many steps (the seed links of a KG pair: every batch of an epoch,
+// train.py:347-352; the mined negatives: until the next refresh), so the host sorts the 2 L (pair, side) incidences by the
+// gradient row they touch once per index tensor (like the graph's CSR).  One wave per sorted position; the wave at the HEAD of a
+// run of equal rows sums the run's contributions in sorted order (ties in pair order: the sort is stable) and writes the row
+// with a plain store -- no atomics, bitwise reproducible; rows no pair touches stay at the caller's zero fill.  The forward
+// leaves (a.b, a.a, b.b) per pair, so an incidence re-reads its partner row only.
+// rec [2L] int4 per SORTED position = {pair x, own table row, partner table row, flags | gradient row}: flags bit 31 = head of its
+// run, bit 30 = the incidence is side 1 (own row in e2, partner in e1), bit 29 = the gradient row lives in de2.  One 16-byte
+// record per position instead of key -> order -> index -> row (three dependent round trips before the first row read).
+constexpr unsigned kRecHead = 1u << 31, kRecSide = 1u << 30, kRecDe2 = 1u << 29, kRecRow = (1u << 29) - 1u;
+__global__ __launch_bounds__(kBlock) void pair_cosine_bwd_sorted_kernel(const float* __restrict__ e1, int64_t ld1,
+                                                                        const float* __restrict__ e2, int64_t ld2, int64_t n_inc, int d,
+                                                                        const float* __restrict__ gdist, const float* __restrict__ stats,
+                                                                        const int4* __restrict__ rec, float* __restrict__ de1,
+                                                                        int64_t ldd1, float* __restrict__ de2, int64_t ldd2) {
+    const int lane = lane_id();
+    const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * kWavesPerBlock;
+    for (int64_t p = w0; p < n_inc; p += nw) {
+        int4 rc = rec[p];
+        if (!((unsigned)rc.w & kRecHead)) continue;                    // not the head of its run (wave-uniform)
+        const float* own = ((unsigned)rc.w & kRecSide) ? e2 + (int64_t)rc.y * ld2 : e1 + (int64_t)rc.y * ld1;
+        float* dst = ((unsigned)rc.w & kRecDe2) ? de2 + (int64_t)((unsigned)rc.w & kRecRow) * ldd2
+                                                : de1 + (int64_t)((unsigned)rc.w & kRecRow) * ldd1;
+        constexpr int NKM = 8;                                         // d <= 512
+        float acc[NKM], ow[NKM];
+#pragma unroll
+        for (int k = 0; k < NKM; ++k) {
+            const int c = lane + 64 * k;
+            acc[k] = 0.f;
+            ow[k] = c < d ? own[c] : 0.f;
+        }
+        for (int64_t q = p;;) {
+            const int64_t qn = q + 1;
+            const int4 nx = rec[qn < n_inc ? qn : q];                  // the next record is in flight while this one is summed
+            const bool side = ((unsigned)rc.w & kRecSide) != 0;
+            const float* partner = side ? e1 + (int64_t)rc.z * ld1 : e2 + (int64_t)rc.z * ld2;
+            const float4 st = *reinterpret_cast<const float4*>(stats + 4 * (int64_t)rc.x);
+            const float g = -gdist[rc.x];
+            float pr[NKM];
+#pragma unroll
+            for (int k = 0; k < NKM; ++k) {
+                const int c = lane + 64 * k;
+                pr[k] = c < d ? partner[c] : 0.f;
+            }
+            const float ra = sqrtf(st.y), rb = sqrtf(st.z);
+            const float na = fmaxf(ra, kNormEps), nb = fmaxf(rb, kNormEps);
+            const float inv = 1.f / (na * nb);
+            const float c_ = st.x * inv;
+            // side 0 (row a of pair x): g (b inv - ka a);  side 1 (row b): g (a inv - kb b)
+            const float kself = side ? (rb > kNormEps ? c_ / (nb * nb) : 0.f) : (ra > kNormEps ? c_ / (na * na) : 0.f);
+#pragma unroll
+            for (int k = 0; k < NKM; ++k) acc[k] += g * (pr[k] * inv - kself * ow[k]);
+            if (qn >= n_inc || ((unsigned)nx.w & kRecHead)) break;
+            q = qn;
+            rc = nx;
+        }
+#pragma unroll
+        for (int k = 0; k < NKM; ++k) {
+            const int c = lane + 64 * k;
+            if (c < d) dst[c] = acc[k];
         }
     }
 }
@@ -439,6 +536,40 @@ int jmac_triple_l1_margin_bwd_f32(const float* ent, int64_t lde, const float* re
     return (int)hipGetLastError();
 }
 
+int jmac_triple_l1_margin_bwd_exact_f32(const float* ent, int64_t lde, const float* rel, int64_t ldr, const int64_t* h, const int64_t* r,
+                                        const int64_t* t, int64_t B, int64_t K, int64_t d, const float* score, const float* gamma,
+                                        const float* gloss, float* dent, int64_t ldde, int64_t n_ent, float* drel, int64_t lddr,
+                                        int64_t n_rel, jmac_stream_t stream) {
+    if (B <= 0 || K <= 0 || d <= 0 || B >= INT32_MAX || K >= INT32_MAX || n_ent < 0 || n_rel < 0) return JMAC_EINVAL;
+    if (d > 512) return JMAC_EDIM;
+    if (!ent || !rel || !h || !r || !t || !score || !gamma || !gloss || !dent || !drel) return JMAC_EINVAL;
+    if (4 * B * K >= (1LL << 24))          // a row's integer sum could leave fp32's exact range: the plain form
+        return jmac_triple_l1_margin_bwd_f32(ent, lde, rel, ldr, h, r, t, B, K, d, score, gamma, gloss, dent, ldde, drel, lddr, stream);
+    const int64_t T = B * (K + 1), period = B;
+    hipStream_t st = (hipStream_t)stream;
+    const int nk = (int)((d + 63) / 64);
+    const int parts = run_parts(T, period);
+    JMAC_DISPATCH_NK(nk, hipLaunchKernelGGL((triple_l1_bwd_kernel<NK, true, true>), dim3(wave_grid(period * parts)), dim3(kBlock), 0, st,
+                                            ent, lde, rel, ldr, h, r, t, T, period, parts, (int)d, score, dent, ldde, drel, lddr,
+                                            MarginArgs{gamma, gloss, B, K}));
+    const int64_t total = (n_ent + n_rel) * d;
+    if (total > 0) {
+        const float inv_2bk = 1.f / (2.f * (float)B * (float)K);
+        if (ldde == d && lddr == d && d % 4 == 0 && ((((uintptr_t)dent | (uintptr_t)drel) & 15) == 0)) {
+            int64_t blocks = (total / 4 + kBlock - 1) / kBlock;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(scale_flat2_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, reinterpret_cast<float4*>(dent),
+                               n_ent * d / 4, reinterpret_cast<float4*>(drel), n_rel * d / 4, gloss, inv_2bk);
+        } else {
+            int64_t blocks = (total + kBlock - 1) / kBlock;
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(scale_rows2_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, dent, ldde, n_ent, drel, lddr, n_rel,
+                               (int)d, gloss, inv_2bk);
+        }
+    }
+    return (int)hipGetLastError();
+}
+
 int jmac_pair_cosine_fwd_f32(const float* e1, int64_t ld1, const float* e2, int64_t ld2, const int64_t* i1, const int64_t* i2,
                              int64_t L, int64_t d, float* dist, jmac_stream_t stream) {
     if (L < 0 || d <= 0 || d >= INT32_MAX) return JMAC_EINVAL;
@@ -446,9 +577,37 @@ int jmac_pair_cosine_fwd_f32(const float* e1, int64_t ld1, const float* e2, int6
     if (!e1 || !e2 || !i1 || !i2 || !dist) return JMAC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (vec_ok(d, {ld1, ld2}, {e1, e2}))
-        hipLaunchKernelGGL(pair_cosine_fwd_kernel<true>, dim3(wave_grid(L)), dim3(kBlock), 0, st, e1, ld1, e2, ld2, i1, i2, L, (int)d, dist);
+        hipLaunchKernelGGL(pair_cosine_fwd_kernel<true>, dim3(wave_grid(L)), dim3(kBlock), 0, st, e1, ld1, e2, ld2, i1, i2, L, (int)d, dist,
+                           (float*)nullptr);
     else
-        hipLaunchKernelGGL(pair_cosine_fwd_kernel<false>, dim3(wave_grid(L)), dim3(kBlock), 0, st, e1, ld1, e2, ld2, i1, i2, L, (int)d, dist);
+        hipLaunchKernelGGL(pair_cosine_fwd_kernel<false>, dim3(wave_grid(L)), dim3(kBlock), 0, st, e1, ld1, e2, ld2, i1, i2, L, (int)d, dist,
+                           (float*)nullptr);
+    return (int)hipGetLastError();
+}
+
+int jmac_pair_cosine_fwd_stats_f32(const float* e1, int64_t ld1, const float* e2, int64_t ld2, const int64_t* i1, const int64_t* i2,
+                                   int64_t L, int64_t d, float* dist, float* stats, jmac_stream_t stream) {
+    if (L < 0 || d <= 0 || d >= INT32_MAX) return JMAC_EINVAL;
+    if (L == 0) return JMAC_OK;
+    if (!e1 || !e2 || !i1 || !i2 || !dist || !stats || ((uintptr_t)stats & 15)) return JMAC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (vec_ok(d, {ld1, ld2}, {e1, e2}))
+        hipLaunchKernelGGL(pair_cosine_fwd_kernel<true>, dim3(wave_grid(L)), dim3(kBlock), 0, st, e1, ld1, e2, ld2, i1, i2, L, (int)d, dist, stats);
+    else
+        hipLaunchKernelGGL(pair_cosine_fwd_kernel<false>, dim3(wave_grid(L)), dim3(kBlock), 0, st, e1, ld1, e2, ld2, i1, i2, L, (int)d, dist, stats);
+    return (int)hipGetLastError();
+}
+
+int jmac_pair_cosine_bwd_sorted_f32(const float* e1, int64_t ld1, const float* e2, int64_t ld2, int64_t L, int64_t d,
+                                    const float* gdist, const float* stats, const int32_t* rec, float* de1, int64_t ldd1,
+                                    float* de2, int64_t ldd2, jmac_stream_t stream) {
+    if (L < 0 || d <= 0) return JMAC_EINVAL;
+    if (d > 512) return JMAC_EDIM;
+    if (L == 0) return JMAC_OK;
+    if (2 * L >= INT32_MAX) return JMAC_ERANGE;
+    if (!e1 || !e2 || !gdist || !stats || !rec || !de1 || !de2 || ((uintptr_t)rec & 15)) return JMAC_EINVAL;
+    hipLaunchKernelGGL(pair_cosine_bwd_sorted_kernel, dim3(wave_grid(2 * L)), dim3(kBlock), 0, (hipStream_t)stream, e1, ld1, e2, ld2,
+                       2 * L, (int)d, gdist, stats, reinterpret_cast<const int4*>(rec), de1, ldd1, de2, ldd2);
     return (int)hipGetLastError();
 }
 

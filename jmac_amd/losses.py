@@ -22,7 +22,8 @@ def _index(i: torch.Tensor, n: int, device, what: str = "index") -> torch.Tensor
     """int64, contiguous, on ``device`` and range-checked against the n rows it addresses (the backward scatters into
     those rows with float atomics: the reference raises IndexError on a bad id, so does this)."""
     check_index_range(i, n, what)                      # host tensors on the host; device tensors once per tensor
-    i = i.reshape(-1)
+    if i.dim() != 1:                                   # (a 1-D tensor stays THE SAME OBJECT: per-tensor caches key on identity)
+        i = i.reshape(-1)
     if i.dtype != torch.int64 or i.device != device:
         i = i.to(device=device, dtype=torch.int64)
     return i.contiguous()
@@ -66,6 +67,51 @@ def triple_l1_score(ent: torch.Tensor, rel: torch.Tensor, h: torch.Tensor, r: to
                            _index(t, ent.shape[0], dev, "batch_t"), int(period))
 
 
+_PAIR_INDEX: dict = {}
+_PAIR_INDEX_CAP = 64
+
+
+def _pair_index(i1: torch.Tensor, i2: torch.Tensor, off1: int, off2: int, same: bool):
+    """rec int32 [2L, 4] of jmac_pair_cosine_bwd_sorted_f32: the (pair, side) incidences sorted by the gradient row they touch,
+    built ONCE per pair of index tensors (identity + version, weak references) -- the seed links of a KG pair are the same
+    tensors for every batch of an epoch (train.py:347-352), the mined negatives until the next refresh -- like the CSR of a
+    graph.  ``off1`` / ``off2``: first row of the windows the ids are local to; ``same``: both sides share one gradient table.
+    Inside a stream capture an unseen pair is sorted inside the capture (and not remembered: those tensors belong to the
+    graph's pool)."""
+    import weakref
+    key = (id(i1), id(i2), int(off1), int(off2), bool(same))
+    hit = _PAIR_INDEX.get(key)
+    if hit is not None and hit[0]() is i1 and hit[1]() is i2 and hit[2] == (i1._version, i2._version):
+        return hit[3]
+    L = i1.numel()
+    big = 1 << 40                                               # side-1 rows of a second table sort behind every side-0 row
+    keys = torch.cat((i1 + off1, i2 + (off2 if same else off2 + big)))
+    skey, order = torch.sort(keys, stable=True)
+    side = order >= L
+    x = torch.where(side, order - L, order)
+    own = torch.where(side, i2[x], i1[x])
+    partner = torch.where(side, i1[x], i2[x])
+    head = torch.ones_like(skey, dtype=torch.bool)
+    head[1:] = skey[1:] != skey[:-1]
+    row = torch.where(side & (not same), skey - big, skey) if not same else skey
+    flags = (head.to(torch.int64) << 31) | (side.to(torch.int64) << 30) | ((side & (not same)).to(torch.int64) << 29) | row
+    rec = torch.stack((x, own, partner, flags), dim=1)
+    rec = (rec & 0xFFFFFFFF).to(torch.int64)
+    rec = torch.where(rec >= (1 << 31), rec - (1 << 32), rec).to(torch.int32).contiguous()      # two's-complement int32 words
+    if not torch.cuda.is_current_stream_capturing():
+        if int(row.max()) >= (1 << 29):
+            raise ValueError("pair cosine backward: gradient rows beyond 2^29")
+        for k in [k for k, v in _PAIR_INDEX.items() if v[0]() is None or v[1]() is None]:
+            del _PAIR_INDEX[k]
+        if len(_PAIR_INDEX) >= _PAIR_INDEX_CAP:
+            _PAIR_INDEX.pop(next(iter(_PAIR_INDEX)))
+        try:
+            _PAIR_INDEX[key] = (weakref.ref(i1), weakref.ref(i2), (i1._version, i2._version), rec)
+        except TypeError:                                      # pragma: no cover
+            pass
+    return rec
+
+
 class _PairCosine(torch.autograd.Function):
     @staticmethod
     def forward(ctx, e1, e2, i1, i2, off1, off2):
@@ -76,10 +122,16 @@ class _PairCosine(torch.autograd.Function):
         if e2.shape[1] != d or i2.numel() != L:
             raise ValueError("pair_cosine_distance: shapes disagree")
         dist = torch.empty(L, dtype=torch.float32, device=e1.device)
-        check(lib().jmac_pair_cosine_fwd_f32(_wptr(e1, off1), e1.stride(0), _wptr(e2, off2), e2.stride(0), ptr(i1), ptr(i2), L, d,
-                                             ptr(dist), stream()), "jmac_pair_cosine_fwd_f32")
+        needs_grad = (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and d <= 512
+        stats = torch.empty((max(L, 1), 4), dtype=torch.float32, device=e1.device) if needs_grad else None
+        if stats is not None:
+            check(lib().jmac_pair_cosine_fwd_stats_f32(_wptr(e1, off1), e1.stride(0), _wptr(e2, off2), e2.stride(0), ptr(i1), ptr(i2), L,
+                                                       d, ptr(dist), ptr(stats), stream()), "jmac_pair_cosine_fwd_stats_f32")
+        else:
+            check(lib().jmac_pair_cosine_fwd_f32(_wptr(e1, off1), e1.stride(0), _wptr(e2, off2), e2.stride(0), ptr(i1), ptr(i2), L, d,
+                                                 ptr(dist), stream()), "jmac_pair_cosine_fwd_f32")
         ctx.save_for_backward(e1, e2, i1, i2)
-        ctx.offs = (off1, off2)
+        ctx.offs, ctx.stats = (off1, off2), stats
         return dist
 
     @staticmethod
@@ -89,12 +141,19 @@ class _PairCosine(torch.autograd.Function):
         L, d = i1.numel(), e1.shape[1]
         g = g.contiguous()
         de1 = torch.zeros((e1.shape[0], d), dtype=torch.float32, device=e1.device)
-        # both sides gathered from ONE table (pairs inside a KG, or two blocks of one stacked table): the kernel's atomics
-        # accumulate both sides' rows into one gradient buffer -- no second zero-fill, no add of the two halves afterwards
+        # both sides gathered from ONE table (pairs inside a KG, or two blocks of one stacked table): one gradient buffer --
+        # no second zero-fill, no add of the two halves afterwards
         same = ctx.same_table and e1.data_ptr() == e2.data_ptr()
         de2 = de1 if same else torch.zeros((e2.shape[0], d), dtype=torch.float32, device=e1.device)
-        check(lib().jmac_pair_cosine_bwd_f32(_wptr(e1, off1), e1.stride(0), _wptr(e2, off2), e2.stride(0), ptr(i1), ptr(i2), L, d,
-                                             ptr(g), _wptr(de1, off1), d, _wptr(de2, off2), d, stream()), "jmac_pair_cosine_bwd_f32")
+        if ctx.stats is not None and L > 0:
+            # deterministic: incidences sorted by gradient row (once per index tensor pair), every touched row written once
+            rec = _pair_index(i1, i2, off1, off2, same)
+            check(lib().jmac_pair_cosine_bwd_sorted_f32(_wptr(e1, off1), e1.stride(0), _wptr(e2, off2), e2.stride(0), L, d, ptr(g),
+                                                        ptr(ctx.stats), ptr(rec), ptr(de1), d, ptr(de2), d, stream()),
+                  "jmac_pair_cosine_bwd_sorted_f32")
+        else:                                          # d > 512: the atomic form (order-dependent sums)
+            check(lib().jmac_pair_cosine_bwd_f32(_wptr(e1, off1), e1.stride(0), _wptr(e2, off2), e2.stride(0), ptr(i1), ptr(i2), L, d,
+                                                 ptr(g), _wptr(de1, off1), d, _wptr(de2, off2), d, stream()), "jmac_pair_cosine_bwd_f32")
         return de1, (None if same else de2), None, None, None, None
 
 
@@ -151,7 +210,7 @@ class _TripleL1Margin(torch.autograd.Function):
     relation window the indices are local to."""
 
     @staticmethod
-    def forward(ctx, ent, rel, h, r, t, margin, B, K, eoff, roff):
+    def forward(ctx, ent, rel, h, r, t, margin, B, K, eoff, roff, en, rn):
         require_device(ent, rel, h, r, t, margin)
         ent, rel = _rows(ent), _rows(rel)
         T, d = h.numel(), ent.shape[1]
@@ -163,22 +222,24 @@ class _TripleL1Margin(torch.autograd.Function):
                                            T, B, d, ptr(score), stream()), "jmac_triple_l1_fwd_f32")
         check(lib().jmac_margin_loss_fwd_f32(ptr(score), B, K, ptr(margin), ptr(loss), stream()), "jmac_margin_loss_fwd_f32")
         ctx.save_for_backward(ent, rel, h, r, t, score, margin)
-        ctx.bk = (B, K, eoff, roff)
+        ctx.bk = (B, K, eoff, roff, en, rn)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         ent, rel, h, r, t, score, margin = ctx.saved_tensors
-        B, K, eoff, roff = ctx.bk
+        B, K, eoff, roff, en, rn = ctx.bk
         d = ent.shape[1]
         g = g.contiguous()
         dent = torch.zeros((ent.shape[0], d), dtype=torch.float32, device=ent.device)
         drel = torch.zeros((rel.shape[0], d), dtype=torch.float32, device=ent.device)
-        check(lib().jmac_triple_l1_margin_bwd_f32(_wptr(ent, eoff), ent.stride(0), _wptr(rel, roff), rel.stride(0), ptr(h), ptr(r),
-                                                  ptr(t), B, K, d, ptr(score), ptr(margin), ptr(g), _wptr(dent, eoff), d,
-                                                  _wptr(drel, roff), d, stream()),
-              "jmac_triple_l1_margin_bwd_f32")
-        return dent, drel, None, None, None, None, None, None, None, None
+        # bitwise reproducible: the atomics add exact integers (the loss' gradient is gloss / (2 B K) times an integer matrix),
+        # a second pass scales the two windows
+        check(lib().jmac_triple_l1_margin_bwd_exact_f32(_wptr(ent, eoff), ent.stride(0), _wptr(rel, roff), rel.stride(0), ptr(h), ptr(r),
+                                                        ptr(t), B, K, d, ptr(score), ptr(margin), ptr(g), _wptr(dent, eoff), d, en,
+                                                        _wptr(drel, roff), d, rn, stream()),
+              "jmac_triple_l1_margin_bwd_exact_f32")
+        return dent, drel, None, None, None, None, None, None, None, None, None, None
 
 
 def triple_l1_margin_loss(ent: torch.Tensor, rel: torch.Tensor, h: torch.Tensor, r: torch.Tensor, t: torch.Tensor,
@@ -194,7 +255,7 @@ def triple_l1_margin_loss(ent: torch.Tensor, rel: torch.Tensor, h: torch.Tensor,
     if B <= 0 or T <= B or (T - B) % B != 0 or margin.numel() != 1 or margin.requires_grad:
         return margin_loss(triple_l1_score(ent[eoff:eoff + en], rel[roff:roff + rn], h, r, t, period=B), B, margin)
     return _TripleL1Margin.apply(ent, rel, _index(h, en, dev, "batch_h"), _index(r, rn, dev, "batch_r"),
-                                 _index(t, en, dev, "batch_t"), margin.reshape(1).to(torch.float32), B, (T - B) // B, eoff, roff)
+                                 _index(t, en, dev, "batch_t"), margin.reshape(1).to(torch.float32), B, (T - B) // B, eoff, roff, en, rn)
 
 
 def margin_loss(score: torch.Tensor, batch_size: int, margin: torch.Tensor) -> torch.Tensor:

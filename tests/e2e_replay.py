@@ -36,9 +36,8 @@ def check_outcome(g, losses, ranks_ckpt, ranks_after, what, decided_gap=1e-4):
       of the loss scale over the whole run;
     * checkpoint (30 steps): every rank whose gold tail is separated from its nearest competitor by more than ``decided_gap``
       in the reference's own distances must be IDENTICAL, hence identical Hits@1 / Hits@10 / MRR up to the undecided handful
-      (1e-4 for the deterministic CPU oracle: 4 of 1 156 undecided; the HIP replay passes 5e-4, 19 undecided -- its loss-gather
-      backward sums with float atomics, so gradients differ at rounding level from run to run, and 30 Adam steps carry that
-      into the distances: with 1e-4 one rank in ~10^3 moved by one place in one run out of four);
+      (1e-4: 4 of 1 156 undecided -- for the CPU oracle and, since the loss-gather backward became bitwise reproducible in round
+      4, for the HIP replay too; with float atomics in those adjoints it had needed 5e-4);
     * end of the run (120 steps): Adam normalises every gradient by its running magnitude, so rounding-level differences in
       small gradients grow into visible parameter differences over a hundred steps (measured: the fp32 oracle ends 31 %
       rank-identical to the fp32 reference, the float64 oracle 99.7 %, all three at the same metrics) -- the end state is
