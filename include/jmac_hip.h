@@ -475,14 +475,18 @@ int jmac_wcat_unpack_f32(const float* const* dwcat, float* const* d_watt, float*
                          int32_t n_layers, int64_t d, const float* extra_src, float* extra_dst,
                          int64_t extra_floats, jmac_stream_t stream);
 
-/* fp32 GEMM on the bf16 matrix cores for the N-row dense products of the encoder and of the factorised layer
- * (replaces torch.mm at src/jmac_model.py:177-203 and the hoisted X [Wt|Wb|Wg] projection / its adjoint):
- *   C[M,N] = A[M,K] B[N,K]^T   ("NT": both operands k-contiguous; a weight W [K,N] is passed as its transpose),
- * fp32 in, fp32 out.  Each operand element is split into three bf16 terms (24 mantissa bits) while it is staged and the
- * six significant term pairs are accumulated in fp32: fp32-GEMM-level error at 6/16 of the fp32 MFMA's issue time.
- * K % 4 == 0, lda / ldb % 4 == 0 (16-byte rows), any M, N. */
-int jmac_gemm_nt_x3_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N,
-                        int64_t K, float* C, int64_t ldc, jmac_stream_t stream);
+/* Used-relation compaction.  A DBP-5L KG names 153-833 of its 961 relation rows in its edges (ja: 158), and the layer's
+ * relation transform + projection (src/jmac_model.py:39-42 and the hoisted R''[Wb|Wg]) matter for named rows only: the encoder
+ * runs those products on the COMPACT table of used rows (+ the loop row), with edge types renumbered accordingly.
+ *   compact: dst[t][p, :] = src[t][idx[p], :]            p < n_used            (idx: device int64 [n_used], ascending)
+ *   expand : dst[t][r, :] = src[t][pos[r], :] or 0       r < rows              (pos: device int32 [rows], -1 = unused row;
+ *            h_accumulate[t] != 0: dst[t][r, :] += src[t][pos[r], :] on used rows, other rows untouched)
+ * Up to 4 tables per launch (host arrays of device pointers); compact tables are dense [., d]; d % 4 == 0, 16-byte rows. */
+int jmac_rows_compact_f32(const float* const* h_src, const int64_t* h_ld_src, float* const* h_dst, int32_t n_tables,
+                          const int64_t* idx, int64_t n_used, int64_t d, jmac_stream_t stream);
+int jmac_rows_expand_f32(const float* const* h_src, float* const* h_dst, const int64_t* h_ld_dst,
+                         const int32_t* h_accumulate, int32_t n_tables, const int32_t* pos, int64_t rows, int64_t d,
+                         jmac_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Loss gathers.  Indices are the reference's int64 tensors (batch_h /

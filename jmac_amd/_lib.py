@@ -90,6 +90,8 @@ _SIGS = {
     "jmac_gemm_grouped_f32": (C.c_int, [C.POINTER(GemmTask), i32, vp]),
     "jmac_wcat_pack_f32": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, vp, vp, i64, C.POINTER(vp), i32, vp]),
     "jmac_wcat_unpack_f32": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, vp, vp, i64, vp]),
+    "jmac_rows_compact_f32": (C.c_int, [C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), i32, vp, i64, i64, vp]),
+    "jmac_rows_expand_f32": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(i32), i32, vp, i64, i64, vp]),
     "jmac_col_moments_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, sz, vp]),
     "jmac_bn_tanh_apply_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, vp, i64, vp]),
     "jmac_bn_tanh_bwd_sums_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, vp, vp, vp, vp, sz, vp]),
@@ -116,7 +118,6 @@ _SIGS = {
     "jmac_col_softmax_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, f32, f32, vp, i64, vp, vp, sz, vp]),
     "jmac_csls_rank_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, vp]),
     "jmac_csls_apply_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, i64, vp]),
-    "jmac_gemm_nt_x3_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, vp]),
     "jmac_gemm_f32": (C.c_int, [vp, i64, i32, vp, i64, i32, i64, i64, i64, vp, i64, vp]),
     "jmac_triple_l1_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp]),
     "jmac_triple_l1_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp, i64, vp, i64, vp]),
@@ -131,6 +132,12 @@ _SIGS = {
     "jmac_scatter_sum_f32": (C.c_int, [vp, vp, i64, i64, i64, vp, vp]),
     "jmac_scatter_softmax_workspace_bytes": (sz, [i64, i64]),
     "jmac_scatter_softmax_f32": (C.c_int, [vp, vp, i64, i64, i64, vp, vp, sz, vp]),
+}
+
+
+# entry points of libjmac_hip_testing.so only (include/jmac_hip_testing.h)
+_TESTING_SIGS = {
+    "jmac_gemm_nt_x3_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, i64, vp, i64, vp]),
 }
 
 
@@ -173,6 +180,9 @@ def testing_lib() -> C.CDLL:
         for name in ("jmac_rel_attn_aggregate_bwd_f32", "jmac_rel_attn_bwd_workspace_bytes", "jmac_strerror"):
             fn = getattr(l, name)
             fn.restype, fn.argtypes = _SIGS[name]
+        for name, (res, args) in _TESTING_SIGS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
         _tlib = l
     return _tlib
 

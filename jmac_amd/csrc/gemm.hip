@@ -647,6 +647,45 @@ __global__ __launch_bounds__(256) void wcat_kernel(const WcatArgs a) {
     }
 }
 
+// ---- used-relation compaction (jmac_rows_compact_f32 / jmac_rows_expand_f32) ------------------------------------------------
+// A DBP-5L KG touches 153-833 of its 961 relation rows (ja: 158); the layer's relation transform R'' = act(cat(R, loop) W1) W2 and
+// its projection [Rq|Rz] are needed for the rows some edge names and for nothing else, so the encoder runs the relation-side
+// products on the compact table of used rows (six times fewer rows on ja) and these two kernels move rows in and gradients out.
+constexpr int kRowsMax = 4;
+struct RowsArgs {
+    const float* src[kRowsMax];
+    float* dst[kRowsMax];
+    int64_t ld[kRowsMax];          // compact: leading dimension of src;  expand: of dst
+    int accumulate[kRowsMax];
+    const int64_t* idx;            // compact: row of src for each compact row
+    const int32_t* pos;            // expand: compact row of each full row, -1 = none
+    int64_t rows;                  // compact: n_used;  expand: rows of the full tables
+    int D4, n;
+};
+template <bool EXPAND>
+__global__ __launch_bounds__(256) void rows_move_kernel(const RowsArgs a) {
+    const int t = blockIdx.y;
+    const int64_t total = a.rows * a.D4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / a.D4;
+        const int c = (int)(i % a.D4) * 4;
+        if (!EXPAND) {
+            st4(a.dst[t] + r * (4 * a.D4) + c, ld4(a.src[t] + a.idx[r] * a.ld[t] + c));
+        } else {
+            const int p = a.pos[r];
+            float* q = a.dst[t] + r * a.ld[t] + c;
+            if (a.accumulate[t]) {
+                if (p >= 0) {
+                    const float4 v = ld4(a.src[t] + (int64_t)p * (4 * a.D4) + c), o = ld4(q);
+                    st4(q, make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w));
+                }
+            } else {
+                st4(q, p >= 0 ? ld4(a.src[t] + (int64_t)p * (4 * a.D4) + c) : make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -713,12 +752,16 @@ int jmac_gemm_grouped_f32(const jmac_gemm_task_t* tasks, int32_t n_tasks, jmac_s
         tiles = nx > tiles ? nx : tiles;
     }
     if (tiles == 0) return JMAC_OK;
-    static bool lds_ok = false;                       // 77 KB of dynamic LDS per block: above the 64 KB default
-    if (!lds_ok) {
+    // 77 KB of dynamic LDS per block: above the 64 KB default.  The attribute is PER DEVICE (a process that launches on a second
+    // GPU needs it there too): remembered per device ordinal, set unconditionally past the table
+    static bool lds_ok[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    if (dev < 0 || dev >= 64 || !lds_ok[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kGroupedLds) != hipSuccess)
             return (int)hipGetLastError();
-        lds_ok = true;
+        if (dev >= 0 && dev < 64) lds_ok[dev] = true;
     }
     hipLaunchKernelGGL(grouped_gemm_kernel, dim3((unsigned)tiles, (unsigned)n), dim3(kBlock), kGroupedLds, (hipStream_t)stream, tab);
     return (int)hipGetLastError();
@@ -768,6 +811,45 @@ int jmac_wcat_unpack_f32(const float* const* dwcat, float* const* d_watt, float*
     if (int rc = wcat_extra(a, extra_src, extra_dst, extra_floats)) return rc;
     hipLaunchKernelGGL(wcat_kernel<true>, dim3((unsigned)((total + 255) / 256), (unsigned)(n_layers + (a.extra_src ? 1 : 0))),
                        dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+int jmac_rows_compact_f32(const float* const* h_src, const int64_t* h_ld_src, float* const* h_dst, int32_t n_tables,
+                          const int64_t* idx, int64_t n_used, int64_t d, jmac_stream_t stream) {
+    if (n_tables <= 0 || n_tables > kRowsMax || n_used < 0 || d <= 0 || !h_src || !h_ld_src || !h_dst) return JMAC_EINVAL;
+    if (d % 4) return JMAC_EDIM;
+    if (n_used == 0) return JMAC_OK;
+    if (!idx) return JMAC_EINVAL;
+    RowsArgs a{};
+    a.idx = idx; a.rows = n_used; a.D4 = (int)(d / 4); a.n = n_tables;
+    for (int t = 0; t < n_tables; ++t) {
+        if (!h_src[t] || !h_dst[t] || h_ld_src[t] % 4 || (((uintptr_t)h_src[t] | (uintptr_t)h_dst[t]) & 15)) return JMAC_EINVAL;
+        a.src[t] = h_src[t]; a.dst[t] = h_dst[t]; a.ld[t] = h_ld_src[t];
+    }
+    const int64_t total = n_used * (d / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(rows_move_kernel<false>, dim3((unsigned)blocks, (unsigned)n_tables), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+int jmac_rows_expand_f32(const float* const* h_src, float* const* h_dst, const int64_t* h_ld_dst, const int32_t* h_accumulate,
+                         int32_t n_tables, const int32_t* pos, int64_t rows, int64_t d, jmac_stream_t stream) {
+    if (n_tables <= 0 || n_tables > kRowsMax || rows < 0 || d <= 0 || !h_src || !h_ld_dst || !h_dst) return JMAC_EINVAL;
+    if (d % 4) return JMAC_EDIM;
+    if (rows == 0) return JMAC_OK;
+    if (!pos) return JMAC_EINVAL;
+    RowsArgs a{};
+    a.pos = pos; a.rows = rows; a.D4 = (int)(d / 4); a.n = n_tables;
+    for (int t = 0; t < n_tables; ++t) {
+        if (!h_dst[t] || h_ld_dst[t] % 4 || (((uintptr_t)h_src[t] | (uintptr_t)h_dst[t]) & 15)) return JMAC_EINVAL;
+        a.src[t] = h_src[t]; a.dst[t] = h_dst[t]; a.ld[t] = h_ld_dst[t];
+        a.accumulate[t] = h_accumulate ? h_accumulate[t] : 0;
+    }
+    const int64_t total = rows * (d / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(rows_move_kernel<true>, dim3((unsigned)blocks, (unsigned)n_tables), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "jmac_hip_testing.h"
 
 using namespace jmac;
 

@@ -29,6 +29,7 @@ from types import SimpleNamespace
 from typing import List, Optional, Sequence
 
 import torch
+import torch.nn.functional as F
 
 from . import ops
 from ._lib import GemmTask, check, lib, ptr, require_device, stream
@@ -115,7 +116,7 @@ def _empty(dev, *shape):
     return torch.empty(shape, dtype=torch.float32, device=dev)
 
 
-def _agg_fwd(PQZ, RR, a, graph: RelGraph, slope, out_scale=0.5):
+def _agg_fwd(PQZ, RR, a, graph: RelGraph, slope, out_scale=0.5, compact=False):
     """jmac_rel_attn_aggregate_fwd_{f32,bf16,bf16_padded} on the [P|Q|Z] table (fp32, or bf16 for the inference form: sums,
     softmax and the output stay fp32; bf16 tables may carry padded halves, ops.bf16_pad); the self loop is the last relation
     row."""
@@ -128,41 +129,48 @@ def _agg_fwd(PQZ, RR, a, graph: RelGraph, slope, out_scale=0.5):
     s = graph.by_dst
     wsb = int(L.jmac_rel_attn_fwd_workspace_bytes(s.n_parts_max, d))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    etype = graph.etype_c if compact else graph.etype         # compact: RR holds the rows of graph.rel_used + the loop row
+    sview = s.view_compact(graph.col, graph.etype_c) if compact else s.view()
     ev0 = ops._ev() if ops.PROFILE is not None else None
     if dh != d:
         if not bf16 or RR.shape[1] != 2 * dh:
             raise ValueError("padded table halves exist for bf16 tables only")
         check(L.jmac_rel_attn_aggregate_fwd_bf16_padded(
             ptr(PQZ), d3, PQZ.data_ptr() + dh * PQZ.element_size(), d3, ptr(RR), RR.stride(0), dh, ptr(a), ptr(graph.col),
-            ptr(graph.etype), C.byref(s.view()), N, d, float(slope), RR.shape[0] - 1, 0, float(out_scale), ptr(out), d, ptr(smax),
+            ptr(etype), C.byref(sview), N, d, float(slope), RR.shape[0] - 1, 0, float(out_scale), ptr(out), d, ptr(smax),
             ptr(sden), ptr(ws), wsb, stream()), "jmac_rel_attn_aggregate_fwd_bf16_padded")
     else:
         fwd = L.jmac_rel_attn_aggregate_fwd_bf16 if bf16 else L.jmac_rel_attn_aggregate_fwd_f32
         check(fwd(
-            ptr(PQZ), d3, PQZ.data_ptr() + d * PQZ.element_size(), d3, ptr(RR), RR.stride(0), ptr(a), ptr(graph.col), ptr(graph.etype),
-            C.byref(s.view()), N, d, float(slope), RR.shape[0] - 1, 0, float(out_scale), ptr(out), d, ptr(smax), ptr(sden),
+            ptr(PQZ), d3, PQZ.data_ptr() + d * PQZ.element_size(), d3, ptr(RR), RR.stride(0), ptr(a), ptr(graph.col), ptr(etype),
+            C.byref(sview), N, d, float(slope), RR.shape[0] - 1, 0, float(out_scale), ptr(out), d, ptr(smax), ptr(sden),
             ptr(ws), wsb, stream()), "jmac_rel_attn_aggregate_fwd_%s" % ("bf16" if bf16 else "f32"))
     if ev0 is not None:
         ops.PROFILE.append(("rel_attn_fwd_bf16" if bf16 else "rel_attn_fwd", ev0, ops._ev()))
     return out, smax, sden
 
 
-def _agg_bwd(PQZ, RR, a, graph: RelGraph, slope, out, smax, sden, G, out_scale=0.5):
+def _agg_bwd(PQZ, RR, a, graph: RelGraph, slope, out, smax, sden, G, out_scale=0.5, compact=False):
     """Deterministic backward (three launches): dPQZ [N,3d], dRR [nrel,2d], da [d]."""
     L = lib()
     N, d3 = PQZ.shape
     d = d3 // 3
     dev = PQZ.device
     nrel = RR.shape[0]
-    graph.ensure_backward_views()
+    if compact:
+        graph.ensure_backward_views_compact()
+    else:
+        graph.ensure_backward_views()
+    by_rel, etype = (graph.by_rel_c, graph.etype_c) if compact else (graph.by_rel, graph.etype)
     dPQZ, dRR, da = _empty(dev, N, d3), _empty(dev, nrel, 2 * d), _empty(dev, d)
-    vd, vs, vr = graph.by_dst_bwd.view(), graph.by_src.view(), graph.by_rel.view()
+    vd = graph.by_dst_bwd.view_compact(graph.col, graph.etype_c) if compact else graph.by_dst_bwd.view()
+    vs, vr = graph.by_src.view(), by_rel.view()
     wsb = int(L.jmac_rel_attn_bwd_workspace_bytes(N, graph.E, nrel, d, graph.by_dst_bwd.n_parts_max, graph.by_src.n_parts_max,
-                                                  graph.by_rel.n_parts_max, 1))
+                                                  by_rel.n_parts_max, 1))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     ev0 = ops._ev() if ops.PROFILE is not None else None
     check(L.jmac_rel_attn_aggregate_bwd_f32(
-        ptr(PQZ), d3, PQZ.data_ptr() + d * 4, d3, ptr(RR), RR.stride(0), ptr(a), ptr(graph.col), ptr(graph.etype),
+        ptr(PQZ), d3, PQZ.data_ptr() + d * 4, d3, ptr(RR), RR.stride(0), ptr(a), ptr(graph.col), ptr(etype),
         ptr(graph.dst_of_slot), C.byref(vd), C.byref(vs), C.byref(vr), N, N, graph.E, nrel, d, float(slope), nrel - 1, 0,
         float(out_scale), ptr(out), d, ptr(smax), ptr(sden), ptr(G), G.stride(0), ptr(dPQZ), d3, dPQZ.data_ptr() + d * 4, d3,
         ptr(dRR), 2 * d, ptr(da), 1, ptr(ws), wsb, stream()), "jmac_rel_attn_aggregate_bwd_f32")
@@ -291,6 +299,59 @@ _TRACKERS = None      # list while an encoder node's forward runs: the num_batch
 def _bump_trackers(trackers) -> None:
     if trackers:
         torch._foreach_add_(trackers, 1)
+
+
+# ---- used-relation compaction ------------------------------------------------------------------------------------------
+class _RelCompact:
+    """The relation side of a node on the rows the graph's edges name (graph.rel_used + the loop row) instead of all nr rows.
+
+    A DBP-5L KG touches 153-833 of its 961 relation rows (ja: 158), and a layer's relation transform and projection
+    (src/jmac_model.py:39-42, the hoisted R''[Wb|Wg]) reach the output through the edges' gathers only -- rows no edge names
+    contribute nothing forward and receive a zero gradient.  ``gather`` cuts the used rows of the relation tables out in one
+    launch, the chains run on them (six times fewer rows on ja), ``scatter`` puts their gradients back into full tables
+    (zeros elsewhere, or added onto a full-table gradient another branch wrote).  Off (tables pass through) when every row is
+    used or none is."""
+
+    def __init__(self, graph: RelGraph, nr: int):
+        graph.ensure_rel_compact()
+        self.graph, self.nr = graph, int(nr)
+        self.on = 0 < graph.n_used < nr and graph.num_rel == nr + 1 and COMPACT_RELATIONS
+        self.n = graph.n_used if self.on else self.nr
+
+    def gather(self, tables):
+        if not self.on:
+            return list(tables)
+        g, d = self.graph, tables[0].shape[1]
+        tables = [t_ if t_.stride(-1) == 1 else t_.contiguous() for t_ in tables]
+        out = [_empty(t_.device, g.n_used, d) for t_ in tables]
+        ld = (C.c_int64 * len(tables))(*[t_.stride(0) for t_ in tables])
+        check(lib().jmac_rows_compact_f32(_vp_array(tables), ld, _vp_array(out), len(tables), ptr(g.rel_used), g.n_used, d, stream()),
+              "jmac_rows_compact_f32")
+        return out
+
+    def scatter(self, items):
+        """items: [(compact gradient [n_used, d], full buffer or None, accumulate)] -> the full [nr, d] gradients (one launch)."""
+        if not self.on:
+            return [c for c, _, _ in items]
+        g, d = self.graph, items[0][0].shape[1]
+        full = [(f if f is not None else _empty(c.device, self.nr, d)) for c, f, _ in items]
+        ld = (C.c_int64 * len(items))(*[f.stride(0) for f in full])
+        acc = (C.c_int32 * len(items))(*[1 if (a_ and f0 is not None) else 0 for (_, f0, a_) in items])
+        check(lib().jmac_rows_expand_f32(_vp_array([c for c, _, _ in items]), _vp_array(full), ld, acc, len(items), ptr(g.rel_pos),
+                                         self.nr, d, stream()), "jmac_rows_expand_f32")
+        return full
+
+    def full_rows(self, compact_rows, fill=0.0):
+        """tests / CAPTURE: a [n + 1, w] compact tensor (used rows + loop row) as [nr + 1, w], ``fill`` on unused rows."""
+        if not self.on:
+            return compact_rows
+        out = torch.full((self.nr + 1, compact_rows.shape[1]), fill, dtype=compact_rows.dtype, device=compact_rows.device)
+        out[self.graph.rel_used] = compact_rows[:-1]
+        out[-1] = compact_rows[-1]
+        return out
+
+
+COMPACT_RELATIONS = True      # tests / A-B: False runs every relation-side product on all nr rows
 
 
 # ---- layer pieces -------------------------------------------------------------------------------------------------------
@@ -447,7 +508,7 @@ class _MlpChain:
                  gemm_task(self.L12u, dWp, dW1, ta=True, accumulate=True)]], (dW1, dW2, dloop), (dL11u, dL12u)
 
 
-def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch.float32, seg=None):
+def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch.float32, seg=None, compact=False):
     """Node side of one RelationAwareLayer (src/jmac_model.py:44-52) given its relation tables: state for the backward.
     ``table_dtype`` bf16 (inference form, no backward: BASELINE config 3): the [P|Q|Z] table comes out of a bf16 GEMM and the
     relation table is rounded to bf16; the aggregation gathers half the bytes, its arithmetic and everything after it is fp32."""
@@ -467,17 +528,17 @@ def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch
     else:
         PQZ = torch.mm(X, wc)                                         # [P|Q|Z]: one library GEMM
     slope = float(lay.atv_mlp.negative_slope)
-    pre, smax, sden = _agg_fwd(PQZ, RR, a, graph, slope)
+    pre, smax, sden = _agg_fwd(PQZ, RR, a, graph, slope, compact=compact)
     mean, invstd, use_batch = _bn_fwd(pre, lay.bn, training, y, y2, seg)
     return SimpleNamespace(X=X, wc=wc, RR=RR, a=a, PQZ=PQZ, pre=pre, smax=smax, sden=sden, y=y, mean=mean, invstd=invstd,
-                           use_batch=use_batch, slope=slope, bn_weight=lay.bn.weight, seg=seg)
+                           use_batch=use_batch, slope=slope, bn_weight=lay.bn.weight, seg=seg, compact=compact)
 
 
 def _layer_bwd(st, graph, gy, gy2, dX, dX_accumulate):
     """Backward of _layer_fwd.  dX: destination of the input gradient (None: not needed).  Returns dRR, dwc (node part),
     da, gbw."""
     gpre, gbw = _bn_bwd(st.pre, st.y, gy, gy2, st.bn_weight, st.mean, st.invstd, st.use_batch, st.seg)
-    dPQZ, dRR, da = _agg_bwd(st.PQZ, st.RR, st.a, graph, st.slope, st.pre, st.smax, st.sden, gpre)
+    dPQZ, dRR, da = _agg_bwd(st.PQZ, st.RR, st.a, graph, st.slope, st.pre, st.smax, st.sden, gpre, compact=st.compact)
     if dX is not None:
         if dX_accumulate:
             dX.addmm_(dPQZ, st.wc.t())
@@ -538,15 +599,19 @@ class _LayerNode(torch.autograd.Function):
         N, d = X.shape
         t = SimpleNamespace()
         (t.wc,) = _wcat_pack([pl[3]], [pl[5]], d)
-        t.ch = _Chain(lay, R, pl[0], pl[1], pl[2], t.wc, d)
+        t.rc = _RelCompact(cfg.graph, R.shape[0])                 # relation side on the rows the edges name
+        (Ru,) = t.rc.gather([R])
+        t.ch = _Chain(lay, Ru, pl[0], pl[1], pl[2], t.wc, d)
         w2g, tt, rr = t.ch.fwd_tasks()
         run_levels([[w2g, tt], [rr]])
         y = _empty(X.device, N, d)
-        t.st = _layer_fwd(lay, X, t.wc, t.ch.RR, pl[4].reshape(-1), cfg.graph, cfg.training, y, seg=getattr(cfg, "seg", None))
+        t.st = _layer_fwd(lay, X, t.wc, t.ch.RR, pl[4].reshape(-1), cfg.graph, cfg.training, y, seg=getattr(cfg, "seg", None),
+                          compact=t.rc.on)
         t.st.y = None                                            # the output reaches the backward through save_for_backward
         if CAPTURE is not None:                                  # tests: the very tables the kernel gathered + the relation
-            CAPTURE["layer.tables"] = (t.st.PQZ, t.st.RR)        # transform's activation (its sign is its pre-activation's)
-            CAPTURE["layer.rel_act"] = t.ch.T
+            CAPTURE["layer.tables"] = (t.st.PQZ, t.rc.full_rows(t.st.RR))   # transform's activation (its sign is its pre-activation's)
+            CAPTURE["layer.rel_act"] = t.ch.T                    # compact rows: CAPTURE["layer.rel_used"] + the loop row
+            CAPTURE["layer.rel_used"] = cfg.graph.rel_used if t.rc.on else None
         ctx.t, ctx.cfg, ctx.dims = t, cfg, (N, d)
         ctx.save_for_backward(y)
         return y
@@ -561,9 +626,10 @@ class _LayerNode(torch.autograd.Function):
         dev = y.device
         dX = _empty(dev, N, d) if ctx.needs_input_grad[1] else None
         dRR, dwc, da, gbw = _layer_bwd(st, cfg.graph, gy.contiguous(), None, dX, False)
-        dR = _empty(dev, *t.ch.R.shape)
-        lv, cg = t.ch.bwd_tasks(dRR, dwc, dR, False)
+        dRu = _empty(dev, *t.ch.R.shape)
+        lv, cg = t.ch.bwd_tasks(dRR, dwc, dRu, False)
         run_levels(lv)
+        (dR,) = t.rc.scatter([(dRu, None, False)])
         return (None, dX, dR, *_layer_grads(cg, _wcat_unpack([dwc], d)[0], da, gbw, d))
 
 
@@ -679,11 +745,13 @@ class _EncoderName(torch.autograd.Function):
         t.bumped = [lay.bn.num_batches_tracked for lay in (la, lc, l2) if training and lay.bn.track_running_stats]
         t.wc = _wcat_pack([p[3] for p in (pa, pc, p2)], [p[5] for p in (pa, pc, p2)], d, copy=(u11[:d], t.w[:d]),
                           counters=t.bumped)
-        # ---- relation side: three dependency levels, one launch each
-        t.cha = _Chain(la, Ra, pa[0], pa[1], pa[2], t.wc[0], d)
-        t.chc = _Chain(lc, Rc, pc[0], pc[1], pc[2], t.wc[1], d)
-        t.mlc = _RelMLP(Rc, L11, L12, mslope)                          # rel_c1      (:195)
-        t.ch2 = _MlpChain(l2, Ra, L11u, L12u, mslope, p2[0], p2[1], p2[2], t.wc[2], d)   # rel_a_in (:196) + conv2's chain
+        # ---- relation side: three dependency levels, one launch each; the layers' chains on the rows the edges name
+        t.rc = _RelCompact(graph, Rc.shape[0])
+        Ra_u, Rc_u = t.rc.gather([Ra, Rc])
+        t.cha = _Chain(la, Ra_u, pa[0], pa[1], pa[2], t.wc[0], d)
+        t.chc = _Chain(lc, Rc_u, pc[0], pc[1], pc[2], t.wc[1], d)
+        t.mlc = _RelMLP(Rc, L11, L12, mslope)                          # rel_c1      (:195): an OUTPUT, all nr rows
+        t.ch2 = _MlpChain(l2, Ra_u, L11u, L12u, mslope, p2[0], p2[1], p2[2], t.wc[2], d)   # rel_a_in (:196) + conv2's chain
         fa, fc, f2, mc = t.cha.fwd_tasks(), t.chc.fwd_tasks(), t.ch2.fwd_tasks(), t.mlc.fwd_tasks()
         run_levels([[fa[0], fa[1], fc[0], fc[1], *f2[0], mc[0], gemm_task(NL, U11[d:], t.w[d:])],
                     [fa[2], fc[2], *f2[1], mc[1]],
@@ -702,21 +770,25 @@ class _EncoderName(torch.autograd.Function):
         a_att = [p[4].reshape(-1) for p in (pa, pc, p2)]
         seg = getattr(cfg, "seg", None)
         t.sa = _layer_fwd(la, align0, t.wc[0], t.cha.RR, a_att[0], graph, training, t.catA[:, d:2 * d], t.cat1[:, d:],
-                          table_dtype=cfg.table_dtype, seg=seg)                                        # :183
+                          table_dtype=cfg.table_dtype, seg=seg, compact=t.rc.on)                                        # :183
         c1 = _empty(dev, N, d)
-        t.sc = _layer_fwd(lc, E, t.wc[1], t.chc.RR, a_att[1], graph, training, c1, table_dtype=cfg.table_dtype, seg=seg)   # :190
+        t.sc = _layer_fwd(lc, E, t.wc[1], t.chc.RR, a_att[1], graph, training, c1, table_dtype=cfg.table_dtype, seg=seg,
+                          compact=t.rc.on)                                           # :190
         t.inv1, t.drop1 = _norm_drop_fwd(c1, p_drop, training, t.cat1[:, :d], seed=sd(1))                 # :191
         t.a_in = torch.mm(t.cat1, U21)                                                          # :192
         t.s2 = _layer_fwd(l2, t.a_in, t.wc[2], t.ch2.RR, a_att[2], graph, training, t.catA[:, 2 * d:],
-                          table_dtype=cfg.table_dtype, seg=seg)                                        # :197
+                          table_dtype=cfg.table_dtype, seg=seg, compact=t.rc.on)                                        # :197
         align_out = torch.mm(t.catA, Wall)                                                      # :203
         if CAPTURE is not None:
+            rel_a_in = torch.mm(F.leaky_relu(torch.mm(Ra.detach(), L11u.detach()), mslope), L12u.detach())   # (:196) on all rows
             CAPTURE.update(conv1_alignment=(align0.clone(), Ra.detach()), conv1_completion=(E.detach(), Rc.detach()),
-                           conv2_alignment=(t.a_in.clone(), t.ch2.rel_in()))
+                           conv2_alignment=(t.a_in.clone(), rel_a_in))
             for name, st, ch in (("conv1_alignment", t.sa, t.cha), ("conv1_completion", t.sc, t.chc), ("conv2_alignment", t.s2, t.ch2)):
-                CAPTURE[name + ".tables"] = (st.PQZ, st.RR)              # the very tables the aggregation kernel gathered
+                CAPTURE[name + ".tables"] = (st.PQZ, t.rc.full_rows(st.RR))  # the very tables the aggregation kernel gathered
                 CAPTURE[name + ".rel_act"] = ch.T                        # the relation transform's activation (its sign = the kink side)
-            CAPTURE["rel_linear11.act"], CAPTURE["rel_linear11_uni.act"] = t.mlc.M, t.ch2.M
+            # rows of the compact relation tables (graph.rel_used, then the loop row), None = all rows
+            CAPTURE["rel_used"] = graph.rel_used if t.rc.on else None
+            CAPTURE["rel_linear11.act"], CAPTURE["rel_linear11_uni.act"] = t.mlc.M, t.ch2.M      # (the second: compact rows)
         # c1 and rel_c1 are OUTPUTS: they reach the backward through save_for_backward / not at all (an attribute on ctx
         # would tie the output to its own grad_fn in a reference cycle)
         rel_c1, t.mlc.out, t.sc.y = t.mlc.out, None, None
@@ -783,25 +855,35 @@ class _EncoderName(torch.autograd.Function):
             dU11 = _empty(dev, 2 * d, d)                                         # [:d] <- dw[:d] by the unpack launch below
             dNL = _empty(dev, di, d)
             levels[0].extend([gemm_task(dw[d:], U11[d:], dNL, tb=True, defer=True), gemm_task(NL, dw[d:], dU11[d:], ta=True, defer=True)])
-        # ---- relation side
+        # ---- relation side.  The chains' relation gradients land in COMPACT buffers (the rows the edges name) and are put back
+        # into full tables by one expand launch; rel_c1's MLP (an output: all rows) writes the full d rel_comp directly
         if have_align or g_relc1 is not None or have_c:
-            dRa_buf, dRc_buf = _empty(dev, *Ra.shape), _empty(dev, *Rc.shape)
-            wrote_a = wrote_c = False
+            rc = t.rc
+            dRa_u = _empty(dev, rc.n, d) if have_align else None
+            dRc_full = _empty(dev, *Rc.shape) if (g_relc1 is not None or (have_c and not rc.on)) else None
+            dRc_u = (_empty(dev, rc.n, d) if rc.on else dRc_full) if have_c else None
             if have_align:
-                cga = add(0, t.cha.bwd_tasks(dRRa, dwca, dRa_buf, False))        # levels 0-1 -> d rel_align (first writer)
-                wrote_a = True
-                lv2, cg2, (gL11u, gL12u) = t.ch2.bwd_tasks(dRR2, dwc2, dRa_buf, True)   # levels 0-2; d rel_align += at level 2
+                cga = add(0, t.cha.bwd_tasks(dRRa, dwca, dRa_u, False))          # levels 0-1 -> d rel_align (first writer)
+                lv2, cg2, (gL11u, gL12u) = t.ch2.bwd_tasks(dRR2, dwc2, dRa_u, True)     # levels 0-2; d rel_align += at level 2
                 add(0, (lv2, None))
+            wrote_c = False
             if g_relc1 is not None:                                               # rel_c1 = MLP(rel_comp) needs only the loss' gradient:
-                gL11, gL12 = add(0, t.mlc.bwd_tasks(g_relc1.contiguous(), dRc_buf, False))   # levels 0-1 -> d rel_comp (first writer)
+                gL11, gL12 = add(0, t.mlc.bwd_tasks(g_relc1.contiguous(), dRc_full, False))   # levels 0-1 -> d rel_comp (first writer)
                 wrote_c = True
             if have_c:
-                # d rel_comp: the MLP writes it at level 1, the chain adds to it one level later (or writes it at level 1)
-                cgc = add(1 if wrote_c else 0, t.chc.bwd_tasks(dRRc, dwcc, dRc_buf, wrote_c))
-                wrote_c = True
+                if rc.on:                            # own buffer: no ordering against the MLP's write
+                    cgc = add(0, t.chc.bwd_tasks(dRRc, dwcc, dRc_u, False))
+                else:                                # one buffer: the MLP writes it at level 1, the chain adds one level later
+                    cgc = add(1 if wrote_c else 0, t.chc.bwd_tasks(dRRc, dwcc, dRc_full, wrote_c))
             run_levels(levels, balance=True)
-            dRa = dRa_buf if wrote_a else None
-            dRc = dRc_buf if wrote_c else None
+            items = ([(dRa_u, None, False)] if have_align else []) + ([(dRc_u, dRc_full if wrote_c else None, True)] if (have_c and rc.on) else [])
+            outs = rc.scatter(items) if items else []
+            if have_align:
+                dRa = outs[0]
+            if have_c and rc.on:
+                dRc = outs[-1]
+            elif have_c or wrote_c:
+                dRc = dRc_full
         dwcs = ([dwca, dwc2] if have_align else []) + ([dwcc] if have_c else [])
         cut = _wcat_unpack(dwcs, d, copy=(dw[:d], dU11[:d]) if have_align else None) if dwcs else []
         if have_align:
@@ -827,16 +909,18 @@ class _EncoderNoName(torch.autograd.Function):
         N, d = E.shape
         t = SimpleNamespace()
         (t.wc,) = _wcat_pack([pc[3]], [pc[5]], d)
-        t.chc = _Chain(lc, Rc, pc[0], pc[1], pc[2], t.wc, d)
+        t.rc = _RelCompact(cfg.graph, Rc.shape[0])
+        (Rc_u,) = t.rc.gather([Rc])
+        t.chc = _Chain(lc, Rc_u, pc[0], pc[1], pc[2], t.wc, d)
         t.mlc = _RelMLP(Rc, L11, L12, cfg.mlp_slope)
         fc, mc = t.chc.fwd_tasks(), t.mlc.fwd_tasks()
         run_levels([[fc[0], fc[1], mc[0]], [fc[2], mc[1]]])
         c1 = _empty(E.device, N, d)
         t.sc = _layer_fwd(lc, E, t.wc, t.chc.RR, pc[4].reshape(-1), cfg.graph, cfg.training, c1, table_dtype=cfg.table_dtype,
-                          seg=getattr(cfg, "seg", None))
+                          seg=getattr(cfg, "seg", None), compact=t.rc.on)
         if CAPTURE is not None:
             CAPTURE.update(conv1_completion=(E.detach(), Rc.detach()))
-            CAPTURE["conv1_completion.tables"] = (t.sc.PQZ, t.sc.RR)
+            CAPTURE["conv1_completion.tables"] = (t.sc.PQZ, t.rc.full_rows(t.sc.RR))
         rel_c1, t.mlc.out, t.sc.y = t.mlc.out, None, None
         ctx.t, ctx.cfg, ctx.dims = t, cfg, (N, d)
         ctx.save_for_backward(E, Rc, L11, L12, c1)
@@ -853,22 +937,31 @@ class _EncoderNoName(torch.autograd.Function):
         dE = dRc = None
         gc = [None] * 8
         levels: List[List[GemmTask]] = [[] for _ in range(5)]
-        dRc_buf = _empty(dev, *Rc.shape)
+        rc = t.rc
+        dRc_full = _empty(dev, *Rc.shape) if (g_relc1 is not None or not rc.on) else None
+        dRc_u = _empty(dev, rc.n, d) if rc.on else dRc_full
         wrote = False
         if g_c1 is not None:
             dE = _empty(dev, N, d)
             dRRc, dwcc, dac, gbwc = _layer_bwd(sc, cfg.graph, g_c1.contiguous(), None, dE, False)
-            lv, cgc = t.chc.bwd_tasks(dRRc, dwcc, dRc_buf, False)
+            lv, cgc = t.chc.bwd_tasks(dRRc, dwcc, dRc_u, False)
             for i, l in enumerate(lv):
                 levels[i].extend(l)
             wrote = True
         gL11 = gL12 = None
+        wrote_full = False
         if g_relc1 is not None:
-            lv, (gL11, gL12) = t.mlc.bwd_tasks(g_relc1.contiguous(), dRc_buf, wrote)
+            first = rc.on or not wrote                       # compact: the MLP has the full buffer to itself
+            lv, (gL11, gL12) = t.mlc.bwd_tasks(g_relc1.contiguous(), dRc_full, not first)
             for i, l in enumerate(lv):
-                levels[(2 if wrote else 0) + i].extend(l)
-            wrote = True
+                levels[(0 if first else 2) + i].extend(l)
+            wrote_full = True
         run_levels(levels)
+        if rc.on and wrote:
+            (dRc_buf,) = rc.scatter([(dRc_u, dRc_full if wrote_full else None, True)])
+        else:
+            dRc_buf = dRc_full
+        wrote = wrote or wrote_full
         if g_c1 is not None:
             gc = _layer_grads(cgc, _wcat_unpack([dwcc], d)[0], dac, gbwc, d)
         dRc = dRc_buf if wrote else None

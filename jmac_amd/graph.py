@@ -97,6 +97,20 @@ class _Schedule:
                               self.n_coop, ptr(self.entry_dst))
         return self._view
 
+    def view_compact(self, col: torch.Tensor, etype_c: torch.Tensor) -> View:
+        """The same schedule for kernels that read COMPACT relation numbering (RelGraph.ensure_rel_compact): the inline
+        {col, type} pairs of a by-destination schedule carry relation ids, so they exist a second time with ``etype_c``."""
+        if self.item_edges is None:
+            return self.view()
+        if getattr(self, "_view_c", None) is None:
+            self.item_edges_c = torch.empty((self.n_items_max, 4), dtype=torch.int32, device=col.device)
+            check(lib().jmac_item_edges_build(ptr(self.items), ptr(self.counts), self.n_items_max, ptr(col), ptr(etype_c),
+                                              ptr(self.item_edges_c), stream()), "jmac_item_edges_build")
+            self._view_c = View(ptr(self.ptr), ptr(self.order), ptr(self.items), ptr(self.splits), ptr(self.counts),
+                                self.n_items_max, self.n_splits_max, self.n_parts_max, ptr(self.item_edges_c), self.n_empty,
+                                self.n_coop, ptr(self.entry_dst))
+        return self._view_c
+
     def build_item_edges(self, col: torch.Tensor, etype: torch.Tensor) -> None:
         """{col, type} of the first two entries of every item, inline with the schedule (small graphs: one dependent
         round trip fewer per wave).  By-source / by-relation schedules pass (order, entry_dst)."""
@@ -164,6 +178,29 @@ class RelGraph:
         self.dst_of_slot = None
         self.by_src = None
         self.by_rel = None
+        self._relc = False             # used-relation compaction (ensure_rel_compact): built on first use
+        self.rel_used = self.rel_pos = self.etype_c = self.by_rel_c = None
+        self.n_used = 0
+
+    def ensure_rel_compact(self) -> None:
+        """Used-relation compaction: a DBP-5L KG names 153-833 of its 961 relation rows in its edges (ja: 158), and the
+        layer's relation transform / projection (src/jmac_model.py:39-42) matter for named rows only.  ``rel_used`` (int64,
+        ascending) = the non-loop relation ids some edge carries, ``n_used`` their number, ``rel_pos`` (int32 [num_rel]) the
+        compact row of every relation (-1: unused; the loop relation num_rel - 1 -> n_used), ``etype_c`` the CSR's edge types in
+        compact numbering.  One host read at build time (torch.unique), never on the hot path."""
+        if self._relc:
+            return
+        dev, E, loop = self.device, self.E, self.num_rel - 1
+        et = self.etype[:E].long() if E > 0 else torch.zeros(0, dtype=torch.int64, device=dev)
+        used = torch.unique(et)
+        self.rel_used = used[used < loop].contiguous()
+        self.n_used = int(self.rel_used.numel())
+        pos = torch.full((self.num_rel,), -1, dtype=torch.int32, device=dev)
+        pos[self.rel_used] = torch.arange(self.n_used, dtype=torch.int32, device=dev)
+        pos[loop] = self.n_used
+        self.rel_pos = pos
+        self.etype_c = (pos[et] if E > 0 else torch.zeros(1, dtype=torch.int32, device=dev)).contiguous()
+        self._relc = True
 
     # the backward needs the by-source and by-relation groupings of the CSR slots; built on first use
     def ensure_backward_views(self) -> None:
@@ -200,8 +237,19 @@ class RelGraph:
 
         self.by_src = group(self.col, self.num_src)
         self.by_rel = group(self.etype, self.num_rel)
+        if self._relc:
+            self.by_rel_c = group(self.etype_c, self.n_used + 1)
+        self._group = group
         self._ei = None
         self._bwd_ready = True
+
+    def ensure_backward_views_compact(self) -> None:
+        """by_rel_c: the by-relation grouping of the CSR slots in compact relation numbering (pass C of the backward on compact
+        relation tables)."""
+        self.ensure_rel_compact()
+        self.ensure_backward_views()
+        if self.by_rel_c is None:
+            self.by_rel_c = self._group(self.etype_c, self.n_used + 1)
 
     def degrees(self) -> torch.Tensor:
         return (self.rowptr[1:] - self.rowptr[:-1])

@@ -378,7 +378,8 @@ def gemm_nt_x3(A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = N
     if B.shape[1] != K:
         raise ValueError("gemm_nt_x3: %s x %s^T" % (tuple(A.shape), tuple(B.shape)))
     C_ = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
-    check(lib().jmac_gemm_nt_x3_f32(ptr(A), A.stride(0), ptr(B), B.stride(0), M, N, K, ptr(C_), C_.stride(0), stream()),
+    # the testing library only (measured, rejected: DESIGN.md section 5): never the product library
+    check(testing_lib().jmac_gemm_nt_x3_f32(ptr(A), A.stride(0), ptr(B), B.stride(0), M, N, K, ptr(C_), C_.stride(0), stream()),
           "jmac_gemm_nt_x3_f32")
     return C_
 

@@ -477,3 +477,60 @@ def test_layer_node_equals_op_by_op_layer(relu):
     scale = max(float(g.abs().max()) for g in b[6].values())
     for k in b[6]:
         assert_close(a[6][k], b[6][k], 1e-4, (1e-4 if k == "loop_rel" else 1e-6) * scale, k)
+
+
+@pytest.mark.parametrize("no_name", [False, True], ids=["forward_name", "forward_no_name"])
+def test_relation_side_on_used_rows_equals_all_rows(no_name):
+    """encoder._RelCompact: the layers' relation chains run on the relation rows the graph's edges name (a DBP-5L KG: 153-833 of
+    961) -- same outputs and the same gradients as with every row (rows no edge names reach no output; their gradient is the
+    MLP's alone for rel_init_att_completion and exactly zero for rel_init_att_alignment), for each pattern of used outputs."""
+    from jmac_amd import encoder
+    n, nr, d, di = 600, 61, 32, 20
+    rng = np.random.default_rng(17)
+    ei, et = random_graph(rng, n, 9, 2400, hub=150)
+    used = np.array([3, 7, 8, 20, 21, 40, 41, 42, 60])                  # 9 of the 61 relation rows carry edges
+    et = used[et]
+    ei, et = torch.from_numpy(ei).to(DEV), torch.from_numpy(et).to(DEV)
+    m = _model(d, n, nr, di, no_name, 23)
+    m.train()
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    G = [torch.randn(n, d, device=DEV, generator=gen), torch.randn(n, d, device=DEV, generator=gen),
+         torch.randn(nr, d, device=DEV, generator=gen)]
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    res = {}
+    for use in ((True, True, True), (False, True, True), (True, False, False)):
+        for flag in (True, False):
+            encoder.COMPACT_RELATIONS = flag
+            try:
+                m.load_state_dict(state)
+                m.zero_grad(set_to_none=True)
+                a, comp, rel = m.forward_base(ei, et, [0, n], [0, nr])
+                loss = 0
+                if use[0] and not no_name:
+                    loss = loss + (a * G[0]).sum()
+                if use[1]:
+                    loss = loss + (comp[1] * G[1]).sum()
+                if use[2]:
+                    loss = loss + (rel[1] * G[2]).sum()
+                if not torch.is_tensor(loss):
+                    continue
+                loss.backward()
+                res[(use, flag)] = (float(loss), [x.detach().clone() for x in (a, comp[1], rel[1])],
+                                    {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()})
+            finally:
+                encoder.COMPACT_RELATIONS = True
+        if (use, True) not in res:
+            continue
+        (l1, o1, g1), (l0, o0, g0) = res[(use, True)], res[(use, False)]
+        assert abs(l1 - l0) <= 1e-5 * abs(l0)
+        for x, y in zip(o1, o0):
+            assert_close(x, y, 1e-5, 1e-6, "outputs %s" % (use,))
+        gscale = max(float(g.abs().max()) for g in g0.values() if g is not None)
+        for k in g0:
+            if g0[k] is None:
+                assert g1[k] is None or float(g1[k].abs().max()) == 0.0, k
+                continue
+            assert_close(g1[k], g0[k], 2e-5, 1e-6 * gscale, "grad %s %s" % (k, use))
+        unused = np.setdiff1d(np.arange(nr), used)
+        if not no_name and g1["rel_init_att_alignment"] is not None:
+            assert float(g1["rel_init_att_alignment"][unused].abs().max()) == 0.0       # exactly zero on rows no edge names

@@ -21,7 +21,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from util import assert_close
+from util import assert_close, expand_rel_act, rel_rows
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RTOL = 1e-4
@@ -52,14 +52,18 @@ def _gpu_kink_masks(w, captured):
             masks[name] = (h > 0).cpu()
             # the relation side's own LeakyReLUs: between the two relation transforms of the layer (src/jmac_model.py:41) ...
             # (the fused node reports the activation it computed: LeakyReLU / ReLU keep the sign of their argument)
-            if name + ".rel_act" in captured:
-                masks[name + ".rel"] = (captured[name + ".rel_act"] > 0).cpu()
+            if name + ".rel_act" in captured:                   # compact relation rows (the rows the edges name) -> all rows
+                masks[name + ".rel"] = expand_rel_act(captured[name + ".rel_act"], captured.get("rel_used"), r.shape[0])
             else:
                 masks[name + ".rel"] = (torch.mm(torch.cat([r, lay.loop_rel], 0), lay.rel_transform_weight1) > 0).cpu()
         m = w.model                               # ... and inside the two relation MLPs (src/jmac_model.py:195-196)
         for key, table, weight in (("rel_linear11", m.rel_init_att_completion, m.rel_linear11),
                                    ("rel_linear11_uni", m.rel_init_att_alignment, m.rel_linear11_uni)):
-            masks[key] = ((captured[key + ".act"] if key + ".act" in captured else torch.mm(table, weight)) > 0).cpu()
+            if key + ".act" in captured:               # rel_linear11_uni feeds conv2's chain only: reported on the compact rows
+                used = captured.get("rel_used") if key == "rel_linear11_uni" else None
+                masks[key] = expand_rel_act(captured[key + ".act"], used, table.shape[0], loop=False)
+            else:
+                masks[key] = (torch.mm(table, weight) > 0).cpu()
     return masks
 
 
@@ -125,9 +129,11 @@ def test_bench_workload_step_matches_oracle(d, bidir, data):
         x, r = captured[name]
         p = orc._sub(st64, name)
         pre = torch.cat([r.cpu().double(), p["loop_rel"]], 0) @ p["rel_transform_weight1"]
-        rflips += int(((pre > 0) != masks[name + ".rel"]).sum())
+        rows = rel_rows(captured.get("rel_used"), r.shape[0])                # counted where the node evaluated the activation
+        rflips += int(((pre > 0) != masks[name + ".rel"])[rows].sum())
     rflips += int(((st64["rel_init_att_completion"] @ st64["rel_linear11"] > 0) != masks["rel_linear11"]).sum())
-    rflips += int(((st64["rel_init_att_alignment"] @ st64["rel_linear11_uni"] > 0) != masks["rel_linear11_uni"]).sum())
+    rows = rel_rows(captured.get("rel_used"), w.nr, loop=False)
+    rflips += int(((st64["rel_init_att_alignment"] @ st64["rel_linear11_uni"] > 0) != masks["rel_linear11_uni"])[rows].sum())
     assert rflips <= 8, rflips
 
     # the L1 triple score |(h + r) - t| (src/jmac_model.py:345-350) has the same kind of kink at 0 in each of its 26 000 x d

@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import oracle.jmac_oracle as orc
-from util import LAYER_CASES, assert_close, layer_grads, layer_params, load_golden, make_args, random_graph, rel_err, t
+from util import expand_rel_act, rel_rows, LAYER_CASES, assert_close, layer_grads, layer_params, load_golden, make_args, random_graph, rel_err, t
 
 RTOL = 1e-4
 
@@ -87,7 +87,9 @@ def _kink_flips(lay, p64, X64, R64, ei, et, Xg, Rg, captured=None):
             PQZ, RR = captured["layer.tables"]            # the op-by-op products may round differently), and the relation
             dp = d                                        # transform's own LeakyReLU (src/jmac_model.py:41), same kind of kink
             pre64 = torch.cat([R64, p64["loop_rel"]], 0) @ p64["rel_transform_weight1"]
-            rel_flips = int(((captured["layer.rel_act"].cpu() > 0) != (pre64 > 0)).sum())
+            nr = R64.shape[0]                             # (the node reports the rows its edges name: compact relation side)
+            rows = rel_rows(captured.get("layer.rel_used"), nr)
+            rel_flips = int((expand_rel_act(captured["layer.rel_act"], captured.get("layer.rel_used"), nr)[rows] != (pre64 > 0)[rows]).sum())
         else:
             rel32 = lay.transform_relations(Rg)
             PQZ, RR, _, dp = lay._tables(Xg, rel32)

@@ -22,7 +22,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from util import assert_close, random_graph
+from util import assert_close, expand_rel_act, random_graph
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RTOL = 1e-4
@@ -232,10 +232,12 @@ def _kg_masks(w, captured, k):
         PQZ, RR = captured[name + ".tables"]
         h = PQZ[ei[0] + eo, :d] + (PQZ[ei[1] + eo, d:2 * d] - RR[et + ro, :d])
         masks[name] = (h > 0).cpu()
-        T = captured[name + ".rel_act"]                        # [2 nr + 1, d]: both KGs' relation rows, then the loop row
-        masks[name + ".rel"] = (torch.cat((T[ro:ro + nr], T[-1:]), 0) > 0).cpu()
-    for key in ("rel_linear11", "rel_linear11_uni"):
-        masks[key] = (captured[key + ".act"][ro:ro + nr] > 0).cpu()
+        # relation-transform activations: reported on the compact rows of the STACKED relation table (the rows the union graph's
+        # edges name, then the loop row) -> all 2 nr + 1 rows -> this KG's nr rows + the loop row
+        T = expand_rel_act(captured[name + ".rel_act"], captured.get("rel_used"), 2 * nr)
+        masks[name + ".rel"] = torch.cat((T[ro:ro + nr], T[-1:]), 0)
+    masks["rel_linear11"] = (captured["rel_linear11.act"][ro:ro + nr] > 0).cpu()
+    masks["rel_linear11_uni"] = expand_rel_act(captured["rel_linear11_uni.act"], captured.get("rel_used"), 2 * nr, loop=False)[ro:ro + nr]
     return masks
 
 

@@ -367,3 +367,34 @@ def test_sim_topk_fused_overflowing_rows_recompute_exactly():
     idx, val = scoring.sim_topk(a, b2, k, return_values=True)
     val2, idx2 = _two_step_topk(a, b2, k)
     assert torch.equal(idx, idx2) and torch.equal(val, val2)
+
+
+def test_get_neg_at_config5_size_against_oracle_mm_topk():
+    """BASELINE config 5's hard-negative mining at full size -- get_neg on [3 000 seeds, 30 000 entities], d = 300, k = 25
+    (JMAC_DBPv1/modules/utils/util.py:35-58; root: modules/utils/util.py:31-54), i.e. the FUSED similarity + running top-k path --
+    directly against the oracle's mm + topk in float64 on the same normalised embeddings (not through the two-step HIP form):
+    every row whose 25th and 26th largest similarities are at least 1e-6 apart (fp32 rounding of a 300-term dot product of
+    unit rows is ~1e-7) must return the oracle's index SET, and where all of its top-26 gaps are decided, the oracle's ORDER."""
+    import oracle.jmac_oracle as orc
+    from jmac_amd import scoring
+    gen = torch.Generator().manual_seed(5)
+    N, L, d, k = 30000, 3000, 300, 25
+    emb = torch.nn.functional.normalize(torch.randn(N, d, generator=gen) + 0.3 * torch.randn(1, d, generator=gen))
+    ill = torch.randperm(N, generator=gen)[:L].tolist()
+    got = scoring.get_neg_dbpv1(ill, emb.cuda(), k).cpu().view(L, k)
+    sim = emb[ill].double() @ emb.double().t()
+    top = torch.topk(sim, k + 1, dim=1)
+    ref = top.indices[:, :k]
+    assert torch.equal(orc.dbpv1_get_neg(ill, emb.double(), k).view(L, k), ref)         # the oracle IS mm + topk
+    gaps = top.values[:, :-1] - top.values[:, 1:]                                        # [L, k]: gap below each of the top k
+    set_decided = gaps[:, k - 1] >= 1e-6
+    order_decided = (gaps >= 1e-6).all(1)
+    assert set_decided.float().mean() > 0.95 and order_decided.float().mean() > 0.5
+    same_set = (got.sort(1).values == ref.sort(1).values).all(1)
+    assert bool(same_set[set_decided].all()), int((~same_set[set_decided]).sum())
+    assert bool((got == ref)[order_decided].all()), int((got != ref)[order_decided].any(1).sum())
+    # undecided rows differ only inside their near-tie: by at most the entries whose similarity is within 1e-6 of the k-th
+    kth = top.values[:, k - 1:k]
+    for r in torch.nonzero(~same_set).flatten().tolist():
+        wrong = set(got[r].tolist()) ^ set(ref[r].tolist())
+        assert all(abs(float(sim[r, j] - kth[r])) < 1e-6 for j in wrong), r

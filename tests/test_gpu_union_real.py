@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 import oracle.jmac_oracle as orc
 from conftest import load_golden
-from util import assert_close, make_args
+from util import assert_close, expand_rel_act, make_args
 
 D = 300
 LANGS = ("el", "en", "es", "fr", "ja")
@@ -167,7 +167,7 @@ def test_layer_on_each_real_bidirectional_kg_matches_oracle(real, lang):
     with torch.no_grad():
         dst, src, typ = ei[0].cuda(), ei[1].cuda(), et.cuda()
         kmask = ((PQZ[dst, :D] + (PQZ[src, D:2 * D] - RR[typ, :D])) > 0).cpu()
-        rmask = (captured["layer.rel_act"] > 0).cpu()
+        rmask = expand_rel_act(captured["layer.rel_act"], captured.get("layer.rel_used"), nr)   # compact relation rows -> all rows
     # forward: fp32 oracle (no masks: the forward is continuous at the kinks)
     ref32 = orc.layer_forward(p32, X, R, ei, et, 0.05, "sub", "leaky_relu", True, torch.zeros(D), torch.ones(D))
     assert_close(out, ref32, 1e-4, 1e-6, "out vs fp32 oracle " + lang)

@@ -80,3 +80,27 @@ def write_dbp5l_dir(root, g):
         for sub in ("seed_train_pairs", "seed_test_pairs"):
             np.savetxt(os.path.join(root, sub, pair + ".tsv"), g[sub].astype(np.float64), fmt="%.1f", delimiter="\t")
     return root
+
+
+def expand_rel_act(act, rel_used, nr, loop=True):
+    """Sign pattern (> 0) of a relation-side activation the encoder nodes report on their COMPACT relation rows
+    (encoder._RelCompact: rows ``rel_used`` of the table, then the loop row when ``loop``) as a bool [nr (+1), w] pattern over all
+    rows -- False on rows no edge names: those rows reach no output and receive a zero gradient, so the side of the kink the
+    oracle takes for them changes nothing.  ``rel_used`` None: ``act`` already covers every row."""
+    m = (act > 0).cpu()
+    if rel_used is None:
+        return m
+    out = torch.zeros((nr + (1 if loop else 0), m.shape[1]), dtype=torch.bool)
+    idx = rel_used.cpu()
+    out[idx] = m[: len(idx)]
+    if loop:
+        out[-1] = m[-1]
+    return out
+
+
+def rel_rows(rel_used, nr, loop=True):
+    """Row indices (into the full table, loop row = nr) the compact relation side covers: where kink-side counts are meaningful."""
+    if rel_used is None:
+        return torch.arange(nr + (1 if loop else 0))
+    idx = rel_used.cpu()
+    return torch.cat((idx, torch.tensor([nr]))) if loop else idx
