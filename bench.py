@@ -105,6 +105,10 @@ def parse():
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the library GEMM heuristics as they are")
     ap.add_argument("--bwd-mode", type=int, default=1)
     ap.add_argument("--synth-scale", type=float, default=1.0, help="scale of the config-4 side measurement")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="sharded workload (--workload synth-1m, or any --gpus N > 1): weak = 1M entities / 20M triples x synth-scale "
+                         "PER GPU; strong = ONE global graph of 200k entities / 20M triples x synth-scale (north_star's 8-GPU "
+                         "configuration: --scaling strong --synth-scale 10 = 2M / 200M), the same graph at every N")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the first pass")
     ap.add_argument("--wire-bf16", action="store_true",
                     help="sharded workload: the [Q|Z] all-gather travels as bf16 (not the reference's fp32 result: see DESIGN.md)")

@@ -29,13 +29,45 @@ def _local_graph(rank, world, n_loc, e_loc, nr, seed=1234):
     return ei, et
 
 
+STRONG_BLOCKS = 8          # the strong-scaled graph is cut into this many fixed row blocks; a rank owns 8 / world of them
+
+
+def _strong_graph(rank, world, n_glob, e_glob, nr, seed=4321):
+    """north_star's 8-GPU configuration ("a 10x synthetic graph", strong-scaled against one GPU): ONE global graph, the same for
+    every world size -- STRONG_BLOCKS fixed row blocks of n_glob / 8 entities and e_glob / 8 triples each (power-law in-degree
+    inside the block, sources uniform over the whole graph, types Zipf), generated from the block's own seed; rank r of a world
+    of W owns blocks [r 8/W, (r+1) 8/W), i.e. a contiguous destination range with an equal share of the edges (what
+    dist.partition_rows gives on this graph).  Only the rank's own edges are generated."""
+    from jmac_amd import synth
+    if STRONG_BLOCKS % world:
+        raise SystemExit("--scaling strong: world size must divide %d" % STRONG_BLOCKS)
+    nb, eb = n_glob // STRONG_BLOCKS, e_glob // STRONG_BLOCKS
+    per = STRONG_BLOCKS // world
+    eis, ets = [], []
+    for b in range(rank * per, (rank + 1) * per):
+        ei, et, _, _ = synth.power_law_graph(nb, eb, nr, seed=seed + 17 * b)
+        rng = np.random.default_rng(seed + 1000 + b)
+        ei[0] += b * nb
+        ei[1] = rng.integers(0, nb * STRONG_BLOCKS, size=eb, dtype=np.int64)
+        eis.append(ei)
+        ets.append(et)
+    return np.concatenate(eis, axis=1), np.concatenate(ets), nb * per, eb * per
+
+
 def run_sharded(a, rank, world, device):
     from jmac_amd import ops, synth
     from jmac_amd.dist import ShardedGraph, ShardedRelationAwareLayer, allreduce_grads
     from jmac_amd.layer import RelationAwareLayer
     d, nr = a.dim, 1000
-    n_loc, e_loc = int(1_000_000 * a.synth_scale), int(20_000_000 * a.synth_scale)
-    ei, et = _local_graph(rank, world, n_loc, e_loc, nr)
+    strong = getattr(a, "scaling", "weak") == "strong"
+    if strong:
+        # 10x config 4 in triples; 2M entities (not 10M): the [P|Q|Z] tables, their adjoints and two layers' saved activations of
+        # 10M x 300 fp32 rows do not fit one GPU's 288 GB beside the per-edge records (SURVEY 8d: "else 2 M / 200 M -- state it")
+        n_glob, e_glob = int(200_000 * a.synth_scale), int(20_000_000 * a.synth_scale)
+        ei, et, n_loc, e_loc = _strong_graph(rank, world, n_glob, e_glob, nr)
+    else:
+        n_loc, e_loc = int(1_000_000 * a.synth_scale), int(20_000_000 * a.synth_scale)
+        ei, et = _local_graph(rank, world, n_loc, e_loc, nr)
     bounds = np.arange(world + 1, dtype=np.int64) * n_loc
     sg = ShardedGraph(ei, et, bounds, rank, already_local=True)
     del ei, et
@@ -108,12 +140,15 @@ def run_sharded(a, rank, world, device):
         comm[cname + "_ms_per_layer"] = float(np.mean(ts)) if ts else 0.0
         comm[cname + "_bytes_per_layer"] = int(np.mean(by)) if by else 0
     comm["collective_ms_per_step"] = len(layers) * (comm["all_gather_qz_ms_per_layer"] + comm["reduce_scatter_dqz_ms_per_layer"])
+    what = ("config 4 x%g STRONG-scaled: ONE global graph of %d entities / %d triples / %d relations (8 fixed row blocks, power-law "
+            "in-degree inside a block), the same for every world size; this rank owns %d entities / %d triples"
+            % (a.synth_scale, n_loc * world, e_total, nr, n_loc, e_loc)) if strong else \
+           ("config 4 weak-scaled: per GPU %d entities / %d triples / %d relations (power-law in-degree)" % (n_loc, e_loc, nr))
     line = {"metric": "gnn_layer_edges_per_s", "value": value, "unit": "edges/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config 4 weak-scaled: per GPU %d entities / %d triples / %d relations (power-law "
-                                   "in-degree), d=%d; 2 stacked RelationAwareLayers fwd+bwd + grad all-reduce + Adam; "
-                                   "destination-sharded, all-gather of [Q|Z] per layer" % (n_loc, e_loc, nr, d),
+            "config": {"workload": what + ", d=%d; 2 stacked RelationAwareLayers fwd+bwd + grad all-reduce + Adam; "
+                                          "destination-sharded, all-gather of [Q|Z] per layer" % d,
                        "global_entities": n_loc * world, "global_triples": e_total, "parallelism": "dst-shard x%d" % world,
                        "wire": "bf16 [Q|Z] all-gather (flag)" if wire is not None else "fp32",
                        "edges_counted_per_step": 2 * e_total},
@@ -124,4 +159,40 @@ def run_sharded(a, rank, world, device):
                              "frac": bb / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": bms,
                              "bytes": "SURVEY 8d backward formula"},
             "comm": comm, "rccl_world": world, "cpu_baseline": None}
+    if rank == 0:
+        line["scaling_model"] = scaling_model(el / a.steps * 1e3, fms, bms, len(layers), n_loc * world, e_total, d, world, strong,
+                                              wire_bytes=2 if wire is not None else 4)
     return line
+
+
+XGMI_LINK_GBS, XGMI_EFF = 153.0, 0.8     # one xGMI link per peer pair (MI355X: 7 links x ~153 GB/s per GPU), sustained fraction assumed
+
+
+def scaling_model(step_ms, agg_fwd_ms, agg_bwd_ms, n_layers, n_glob, e_glob, d, world, strong, wire_bytes=4):
+    """What this run's own measurements predict for 2 / 4 / 8 GPUs -- an explicit model, NOT a measurement (no multi-GPU node has
+    run this code).  Per layer and GPU at world W (destination sharding):
+      aggregation   = the measured kernel time x (edges per GPU at W / edges per GPU in this run)       (HBM-bound in E)
+      other compute = (step - aggregation) of this run x (rows per GPU at W / rows per GPU in this run)  (N-row GEMMs, BN, Adam)
+      all-gather    = every peer sends its (N / W) x 2d x wire-bytes slab over ITS OWN link: (N / W) 2d s / (153 GB/s x 0.8)
+      reduce-scatter= the same bytes the other way (fp32)
+    no overlap of exchange and compute is assumed beyond what the single-rank step already contains."""
+    agg = n_layers * (agg_fwd_ms + agg_bwd_ms)
+    other = max(step_ms - agg, 0.0)
+    n_run, e_run = n_glob / world, e_glob / world                     # per GPU in THIS run
+    out = {"assumptions": {"xgmi_link_GBps": XGMI_LINK_GBS, "sustained_fraction": XGMI_EFF, "overlap": "none beyond the measured step",
+                           "wire_bytes_per_element": wire_bytes, "kind": "strong" if strong else "weak"},
+           "measured_here": {"world": world, "step_ms": step_ms, "aggregation_ms": agg, "other_ms": other}, "predicted": {}}
+    for W in (1, 2, 4, 8):
+        n_tot, e_tot = (n_glob, e_glob) if strong else (n_run * W, e_run * W)
+        n_w, e_w = n_tot / W, e_tot / W
+        comp = agg * (e_w / e_run) + other * (n_w / n_run)
+        slab = n_w * 2 * d
+        ag = (slab * wire_bytes) / (XGMI_LINK_GBS * XGMI_EFF * 1e9) * 1e3 if W > 1 else 0.0
+        rs = (slab * 4) / (XGMI_LINK_GBS * XGMI_EFF * 1e9) * 1e3 if W > 1 else 0.0
+        t = comp + n_layers * (ag + rs)
+        out["predicted"][str(W)] = {"step_ms": t, "edges_per_s": n_layers * e_tot / (t * 1e-3), "compute_ms": comp,
+                                    "exchange_ms": n_layers * (ag + rs)}
+    base = out["predicted"]["1"]["edges_per_s"]
+    for W in ("2", "4", "8"):
+        out["predicted"][W]["speedup_vs_1"] = out["predicted"][W]["edges_per_s"] / base
+    return out

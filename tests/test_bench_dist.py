@@ -1,0 +1,36 @@
+"""CPU: the strong-scaled sharded workload of bench.py (--scaling strong: north_star's 8-GPU configuration) and the scaling model
+it puts on the line."""
+import numpy as np
+
+
+def test_strong_graph_is_the_same_graph_at_every_world_size():
+    """One global graph, fixed row blocks: the ranks of a world of 2, 4 or 8 generate exactly the edges the single rank of a
+    world of 1 generates, each rank a contiguous destination range with an equal share of the edges."""
+    import bench_dist
+    n, e, nr = 8000, 160000, 50
+    ei1, et1, n1, e1 = bench_dist._strong_graph(0, 1, n, e, nr)
+    assert (n1, e1) == (n, e) and ei1.shape == (2, e) and ei1[0].max() < n and ei1[1].max() < n
+    for W in (2, 4, 8):
+        parts = [bench_dist._strong_graph(r, W, n, e, nr) for r in range(W)]
+        assert all(p[2] == n // W and p[3] == e // W for p in parts)
+        for r, p in enumerate(parts):
+            assert p[0][0].min() >= r * (n // W) and p[0][0].max() < (r + 1) * (n // W)      # own destination range
+        assert (np.concatenate([p[0] for p in parts], axis=1) == ei1).all()
+        assert (np.concatenate([p[1] for p in parts]) == et1).all()
+
+
+def test_scaling_model_is_consistent():
+    """The model reproduces the measured step at the measured world size, counts edges per step like the line's value, and
+    its exchange term follows the per-link slab (N / W rows x 2d x bytes over one 153 GB/s link at 0.8)."""
+    import bench_dist
+    m = bench_dist.scaling_model(110.0, 10.5, 20.0, 2, 1_000_000, 20_000_000, 300, 1, False)
+    p1, p8 = m["predicted"]["1"], m["predicted"]["8"]
+    assert abs(p1["step_ms"] - 110.0) < 1e-9 and p1["exchange_ms"] == 0.0
+    assert abs(p1["edges_per_s"] - 2 * 20_000_000 / 0.110) < 1e-3
+    slab_ms = 1_000_000 * 600 * 4 / (153e9 * 0.8) * 1e3
+    assert abs(p8["exchange_ms"] - 2 * 2 * slab_ms) < 1e-9 and abs(p8["compute_ms"] - 110.0) < 1e-9       # weak: per-GPU work fixed
+    s = bench_dist.scaling_model(110.0, 10.5, 20.0, 2, 2_000_000, 200_000_000, 300, 1, True)
+    q8 = s["predicted"]["8"]
+    assert abs(q8["compute_ms"] - 110.0 / 8) < 1e-9                                                      # strong: 1/8 of the rows and edges
+    assert abs(q8["exchange_ms"] - 2 * 2 * (250_000 * 600 * 4 / (153e9 * 0.8) * 1e3)) < 1e-9
+    assert s["predicted"]["2"]["speedup_vs_1"] < 2 and q8["speedup_vs_1"] < 8
