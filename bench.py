@@ -935,6 +935,9 @@ def union_bench(a, device, cpu=True):
            "aggregation_roofline": {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<..., bf16>", "avg_launch_ms": agg_ms,
                                     "algorithmic_bytes_per_launch": fb16, "achieved": fb16 / (agg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": fb16 / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "traffic": (pmc_traffic("union", "rel_attn_fwd_kernel<3, 2, 75, unsigned short>") if (real and d == 300) else None),
+                                    "traffic_source": "profiles/r4_pmc_union.json (committed rocprofv3 --pmc passes on the same real union; "
+                                                      "not collected by this run)",
                                     "note": "%.0f MB per launch: Infinity-Cache resident" % (fb16 / 1e6)}}
     if real:
         try:
@@ -1169,8 +1172,9 @@ def synth_measure(a, device, cpu=True):
            "N": n, "E": e, "max_in_degree": int(deg.max()), "d": a.dim,
            "fwd_ms": r["fwd_ms"], "fwd_edges_per_s": e / (r["fwd_ms"] * 1e-3),
            "fwd_GBps": fb / (r["fwd_ms"] * 1e-3) / 1e9, "fwd_frac_hbm": fb / (r["fwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "fwd_traffic_bytes": pmc_traffic("config4", "rel_attn_fwd_kernel") if (a.dim == 300 and a.synth_scale == 1.0) else None,
-           "fwd_traffic_source": "profiles/r3_pmc_config4.json (committed rocprofv3 --pmc passes; not collected by this run)",
+           "fwd_traffic_bytes": pmc_traffic("config4", "rel_attn_fwd") if (a.dim == 300 and a.synth_scale == 1.0) else None,
+           "fwd_bf16_traffic_bytes": pmc_traffic("config4", "rel_attn_fwd", section="kernels_bf16") if (a.dim == 300 and a.synth_scale == 1.0) else None,
+           "fwd_traffic_source": "profiles/r4_pmc_config4.json (committed rocprofv3 --pmc passes; not collected by this run)",
            "bwd_ms": r["bwd_ms"], "bwd_GBps": bb / (r["bwd_ms"] * 1e-3) / 1e9,
            "bwd_frac_hbm": bb / (r["bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bwd_bytes": "SURVEY 8d backward formula",
            "bwd_edges_per_s": e / (r["bwd_ms"] * 1e-3)}
@@ -1198,18 +1202,18 @@ def complete_sharded_line(line, a):
         except Exception as ex:                              # pragma: no cover
             line["cpu_baseline"] = {"error": str(ex)}
     if a.dim == 300 and a.synth_scale == 1.0:
-        line["roofline"]["traffic"] = pmc_traffic("config4", "rel_attn_fwd_kernel")
-        line["roofline"]["traffic_source"] = ("profiles/r3_pmc_config4.json (committed rocprofv3 --pmc passes of the same kernel on "
+        line["roofline"]["traffic"] = pmc_traffic("config4", "rel_attn_fwd")
+        line["roofline"]["traffic_source"] = ("profiles/r4_pmc_config4.json (committed rocprofv3 --pmc passes of the same kernel on "
                                               "one rank's graph; not collected by this run)")
 
 
-def pmc_traffic(key, kernel_prefix, rounds=("r3", "r2")):
+def pmc_traffic(key, kernel_prefix, rounds=("r4", "r3", "r2"), section="kernels"):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r2_pmc_<key>.json), or None.
     PMC collection needs rocprofv3 around the process, so bench.py reports the committed measurement."""
     for rnd in rounds:
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, key))))
-            for k, v in d["kernels"].items():
+            for k, v in d[section].items():
                 if k.startswith(kernel_prefix):
                     return v["traffic_bytes_corrected"]
         except (OSError, KeyError, ValueError):
@@ -1314,7 +1318,7 @@ def main():
     ms = el / a.steps * 1e3
     layer_calls = 3
     value = world * layer_calls * w.E * a.steps / el
-    roof_src = "profiles/r3_pmc_ja.json (committed rocprofv3 --pmc passes on the same real-graph workload; not collected by this run)"
+    roof_src = "profiles/r4_pmc_ja.json (committed rocprofv3 --pmc passes on the same real-graph workload; not collected by this run)"
     if dist_on:
         # N > 1: the headline is the path that actually shards -- BASELINE config 4 weak-scaled, destination-sharded, RCCL
         # all-gather / reduce-scatter per layer (north_star: "Partition ... across the 8 GPUs ... only when the graph
@@ -1355,7 +1359,7 @@ def main():
     fwd_ms = raw["fwd_ms"]
     roof = {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<3, 2, 75, float>", "achieved": fbytes / (fwd_ms * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fbytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": (pmc_traffic("ja", "rel_attn_fwd_kernel", ("r3",) if a.data == "real" else ("r2",))
+            "traffic": (pmc_traffic("ja", "rel_attn_fwd_kernel", ("r4", "r3") if a.data == "real" else ("r2",))
                         if (w.d == 300 and a.workload == "dbp5l-ja") else None),
             "traffic_source": roof_src,
             "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": fwd_ms, "launches": raw["fwd_launches"],
@@ -1369,7 +1373,7 @@ def main():
                 "avg_launch_ms": prof["rel_attn_bwd"][0], "back_to_back_ms": raw["bwd_ms"],
                 "implementation_bytes": synth.bwd_implementation_bytes(w.N, w.E, w.d)}
     if a.data == "real" and a.dim == 300:             # the three launches' HBM-side bytes from the committed PMC passes
-        parts = [pmc_traffic("ja", k, ("r3",)) for k in ("rel_attn_bwd_dst_kernel", "rel_attn_bwd_gather_kernel", "bwd_finalize_kernel")]
+        parts = [pmc_traffic("ja", k, ("r4", "r3")) for k in ("rel_attn_bwd_dst_kernel", "rel_attn_bwd_gather_kernel", "bwd_finalize_kernel")]
         roof_bwd["traffic"] = float(sum(parts)) if all(p is not None for p in parts) else None
         roof_bwd["traffic_source"] = roof_src
 

@@ -120,9 +120,9 @@ def train_epoch(model: JMAC, kgs: Dict[str, KnowledgeGraph], seeds_train: Dict[T
         st = state.setdefault(idx, {"entropy": [-1], "seeds": [links]})
         if refresh or "feeddict" not in st:
             model.eval()
-            with torch.no_grad():
-                o1 = torch.from_numpy(model.get_emb(ei1, et1, eb1, rb1)[0]).to(dev)
-                o2 = torch.from_numpy(model.get_emb(ei2, et2, eb2, rb2)[0]).to(dev)
+            with torch.no_grad():                      # train.py:450-451: get_emb once per KG of the pair -- one encoder pass here
+                (a1, _), (a2, _) = model.get_emb_blocks([(ei1, et1, eb1, rb1), (ei2, et2, eb2, rb2)])
+                o1, o2 = torch.from_numpy(a1).to(dev), torch.from_numpy(a2).to(dev)
             model.train()
             test_pairs = seeds_test.get((l1, l2), links)
             new1, new2, k1, k2, feed, _ = entr.seed_enlargement_triple_transferring(

@@ -25,8 +25,8 @@ RR = (torch.randn(nrel, 2 * d, device=dev, generator=gen) * 0.3).requires_grad_(
 a = (torch.randn(d, device=dev, generator=gen) * 0.1).requires_grad_(True)
 G = torch.randn(n, d, device=dev, generator=gen)
 bf16 = bool(os.environ.get("BF16"))
-if bf16:
-    PQZ, RR = PQZ.detach().to(torch.bfloat16), RR.detach().to(torch.bfloat16)
+if bf16:      # the layout the layers produce: halves padded to a multiple of 8 elements (300 -> 304)
+    PQZ, RR = ops.pad_table(PQZ.detach().to(torch.bfloat16), d, 3), ops.pad_table(RR.detach().to(torch.bfloat16), d, 2)
     do_bwd = 0
 fb = synth.fwd_algorithmic_bytes(n, e, d, 2 if bf16 else 4)
 with torch.no_grad():

@@ -9,7 +9,12 @@ from jmac_amd import ops, synth
 from jmac_amd.graph import RelGraph
 
 dev = torch.device("cuda")
-ei, et, n, nr, eb, rb = synth.dbp5l_union(1234, target="ja")
+if os.environ.get("UNION_SYNTH"):
+    ei, et, n, nr, eb, rb = synth.dbp5l_union(1234, target="ja")
+else:                      # the REAL union of the five DBP-5L KGs (committed integer arrays)
+    from jmac_amd import data as jdata
+    kgs, _, _, _ = jdata.kgs_from_arrays(jdata.load_dbp5l_arrays(os.path.join(ROOT, "tests", "golden", "dbp5l_all_data.npz")), "ja")
+    ei, et, n, nr, eb, rb = jdata.union_edges(kgs)
 ei_t, et_t = torch.from_numpy(ei).to(dev), torch.from_numpy(et).to(dev)
 d = 300
 g = RelGraph(ei_t, et_t, n, nr + 1)
