@@ -500,6 +500,11 @@ template <> struct HwElem<float> { static constexpr int CH = 4; };
 template <> struct HwElem<bf16_t> { static constexpr int CH = 8; };
 template <int CH> struct VF { float v[CH]; };
 __device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+typedef unsigned jmac_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld16_nt(const void* p) {   // streaming: the line is first in line for eviction from L2
+    const jmac_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const jmac_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 template <typename TT> __device__ __forceinline__ VF<HwElem<TT>::CH> hw_cvt(uint4 r);
 template <> __device__ __forceinline__ VF<4> hw_cvt<float>(uint4 r) {
     VF<4> o;
@@ -544,7 +549,10 @@ __device__ __forceinline__ float halves_meet(float a, float b) {
     return a + b;
 }
 
-template <int DC, int GP, int PIPE, typename TT>   // PIPE: 0 = load / reduce in turn, 2 / 3 = that many groups' gathers in flight
+// HOT > 0 (experiment, JMAC_FWD_HOT=1: north_star's "LDS-staged relation tiles"): rows 0 .. HOT-1 of [Rq|Rz] -- the hottest
+// relations when the ids are ordered by frequency -- are staged in LDS once per workgroup; an edge of such a relation reads its
+// relation chunks from LDS (its global load is pointed at row 0, an L1 hit), the Zipf tail keeps its L2 / Infinity-Cache path.
+template <int DC, int GP, int PIPE, typename TT, int HOT = 0, int NT = 0>   // PIPE: 0 = load / reduce in turn, 2 / 3 = that many groups' gathers in flight
 __global__ __launch_bounds__(kBlock) void rel_attn_fwd_hw_kernel(FwdArgs a) {
     constexpr int CH = HwElem<TT>::CH;
     constexpr int NCH = (2 * DC + 31) / 32;            // chunk slots per lane
@@ -555,6 +563,7 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_hw_kernel(FwdArgs a) {
     typedef VF<CH> vf;
     __shared__ float coop_acc[kWavesPerBlock][NP][CH][64];
     __shared__ float coop_ml[kWavesPerBlock][2];
+    __shared__ uint4 hot_rows[HOT > 0 ? HOT * 2 * DC : 1];
     const TT* const tP = static_cast<const TT*>(a.P);
     const TT* const tQZ = static_cast<const TT*>(a.QZ);
     const TT* const tRR = static_cast<const TT*>(a.RR);
@@ -599,23 +608,47 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_hw_kernel(FwdArgs a) {
     }
     // Every load stays RAW (uint4) until its first use: a conversion or a select right behind a load is waited for where it
     // stands, i.e. in front of the gathers that should be in flight together with it (one more round trip per item).
+    // relation table as a buffer resource (HOT only): 32-bit lane offsets, out-of-range lanes are dropped by the range check
+    const auto rr_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<TT*>(tRR), 0, (int)0xFFFFFFF0u, 0x00020000);
+    if constexpr (HOT > 0) {                           // stage the hot relation rows (the table has more than HOT rows: launcher)
+        for (int i = threadIdx.x; i < HOT * 2 * DC; i += kBlock)
+            hot_rows[i] = ld16(tRR + (int64_t)(i / (2 * DC)) * a.ldrr + (i % (2 * DC)) * CH);
+        __syncthreads();
+    }
     uint4 rlraw[NP];                                   // the loop relation's Rz chunks in the OUTPUT layout: one read per wave
 #pragma unroll
     for (int p = 0; p < NP; ++p) rlraw[p] = ld16(rloop + (oc[p] >= 0 ? oc[p] : 0) * CH);
 
     // ---- online softmax over the entries [item.beg, item.end) of one destination; both halves carry PARTIAL accumulators
     auto edge_loop = [&](const jmac_item_t& item, int my_col, int my_typ, const uint4 (&praw)[KH], float& m, float& l, vf (&acc)[NCH]) {
-        auto issue = [&](const int nb, const int mc, const int mt, const int p0, uint4 (&qr)[GP][NCH], uint4 (&rr)[GP][NCH]) {
+        auto issue = [&](const int nb, const int mc, const int mt, const int p0, uint4 (&qr)[GP][NCH], uint4 (&rr)[GP][NCH], int (&th)[GP]) {
 #pragma unroll
             for (int u = 0; u < GP; ++u) {
                 const int ea = max(min(2 * (p0 + u), nb - 1), 0), eb = max(min(2 * (p0 + u) + 1, nb - 1), 0);
                 const int ja = bcast_i(mc, ea), jb = bcast_i(mc, eb);
                 const int ta = bcast_i(mt, ea), tb = bcast_i(mt, eb);
                 const TT* qrow = tQZ + (int64_t)(upper ? jb : ja) * a.ldqz;
-                const TT* rrow = tRR + (int64_t)(upper ? tb : ta) * a.ldrr;
+                const int tsel = upper ? tb : ta;
+                th[u] = -1;
+                const TT* rrow = tRR + (int64_t)tsel * a.ldrr;
+                if constexpr (HOT > 0) {
+                    // hot: the chunks come from LDS and the lane's relation load must cost NOTHING -- pointed at a dummy row (row 0,
+                    // or the lane's own [Q|Z] chunk) it still went to L2 and the kernel ran 2.4 x longer.  A buffer load whose
+                    // offset lies past the descriptor's range is dropped by the range check: no request leaves the CU.
+                    th[u] = tsel < HOT ? tsel : -1;
+                    const unsigned rb = tsel < HOT ? 0xFFFFFFFFu : (unsigned)tsel * (unsigned)(a.ldrr * sizeof(TT));
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) {
+                        qr[u][k] = ld16(qrow + coff[k]);
+                        const unsigned vo = tsel < HOT ? 0xFFFFFFFFu : rb + (unsigned)(coff[k] * sizeof(TT));
+                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rr_rsrc, (int)vo, 0, 0);
+                        rr[u][k] = make_uint4(v[0], v[1], v[2], v[3]);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
-                    qr[u][k] = ld16(qrow + coff[k]);
+                    qr[u][k] = NT ? ld16_nt(qrow + coff[k]) : ld16(qrow + coff[k]);
                     rr[u][k] = ld16(rrow + coff[k]);
                 }
             }
@@ -623,7 +656,8 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_hw_kernel(FwdArgs a) {
         // the item's FIRST group of gathers goes out here, in one basic block with the loads of P[i] / Z[i] and ahead of the
         // conversion of P[i]: that conversion waits for P[i] only (the gathers are younger), not the other way round
         uint4 qA[GP][NCH], rA[GP][NCH];
-        issue(min(64, item.end - item.beg), my_col, my_typ, 0, qA, rA);
+        int tA[GP];
+        issue(min(64, item.end - item.beg), my_col, my_typ, 0, qA, rA, tA);
         vf pv[KH];
 #pragma unroll
         for (int k = 0; k < KH; ++k) {
@@ -638,10 +672,10 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_hw_kernel(FwdArgs a) {
                 const int le = min(lane, nb - 1);
                 my_col = a.col[e0 + le];
                 my_typ = a.etype[e0 + le];
-                issue(nb, my_col, my_typ, 0, qA, rA);
+                issue(nb, my_col, my_typ, 0, qA, rA, tA);
             }
             const int npairs = (nb + 1) >> 1;
-            auto consume = [&](const int p0, const uint4 (&qr)[GP][NCH], const uint4 (&rr)[GP][NCH]) {
+            auto consume = [&](const int p0, const uint4 (&qr)[GP][NCH], const uint4 (&rr)[GP][NCH], const int (&th)[GP]) {
                 vf x[GP][NCH];
                 float part[GP];
 #pragma unroll
@@ -649,7 +683,16 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_hw_kernel(FwdArgs a) {
                     part[u] = 0.f;
 #pragma unroll
                     for (int k = 0; k < NCH; ++k) {
-                        const vf q = hw_cvt<TT>(qr[u][k]), r = hw_cvt<TT>(rr[u][k]);
+                        uint4 rraw = rr[u][k];
+                        if constexpr (HOT > 0) {
+                            const uint4 lv = hot_rows[max(th[u], 0) * (2 * DC) + min(hl + 32 * k, 2 * DC - 1)];
+                            // component-wise: hipcc lowers a ternary over uint4 STRUCTS to two scratch stores and an indexed
+                            // scratch load (48 B of private segment, 2.4 x the kernel's time); on dwords it is v_cndmask
+                            const bool hsel = th[u] >= 0;
+                            rraw.x = hsel ? lv.x : rraw.x; rraw.y = hsel ? lv.y : rraw.y;
+                            rraw.z = hsel ? lv.z : rraw.z; rraw.w = hsel ? lv.w : rraw.w;
+                        }
+                        const vf q = hw_cvt<TT>(qr[u][k]), r = hw_cvt<TT>(rraw);
 #pragma unroll
                         for (int e = 0; e < CH; ++e) {
                             float d = q.v[e] - r.v[e];
@@ -692,44 +735,46 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_hw_kernel(FwdArgs a) {
                 // three groups in flight: group g + 2 is issued before group g is reduced (two waves per SIMD hold 2 x 3 x 2 rows:
                 // what three waves of the two-deep form would, without their registers)
                 uint4 qB[GP][NCH], rB[GP][NCH], qC[GP][NCH], rC[GP][NCH];
-                if (GP < npairs) issue(nb, my_col, my_typ, GP, qB, rB);
+                int tB[GP], tC[GP];
+                if (GP < npairs) issue(nb, my_col, my_typ, GP, qB, rB, tB);
                 for (int p = 0; p < npairs; p += 3 * GP) {
-                    if (p + 2 * GP < npairs) issue(nb, my_col, my_typ, p + 2 * GP, qC, rC);
+                    if (p + 2 * GP < npairs) issue(nb, my_col, my_typ, p + 2 * GP, qC, rC, tC);
                     __builtin_amdgcn_sched_barrier(0);
-                    consume(p, qA, rA);
+                    consume(p, qA, rA, tA);
                     __builtin_amdgcn_sched_barrier(0);
                     if (p + GP < npairs) {
-                        if (p + 3 * GP < npairs) issue(nb, my_col, my_typ, p + 3 * GP, qA, rA);
+                        if (p + 3 * GP < npairs) issue(nb, my_col, my_typ, p + 3 * GP, qA, rA, tA);
                         __builtin_amdgcn_sched_barrier(0);
-                        consume(p + GP, qB, rB);
+                        consume(p + GP, qB, rB, tB);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (p + 2 * GP < npairs) {
-                        if (p + 4 * GP < npairs) issue(nb, my_col, my_typ, p + 4 * GP, qB, rB);
+                        if (p + 4 * GP < npairs) issue(nb, my_col, my_typ, p + 4 * GP, qB, rB, tB);
                         __builtin_amdgcn_sched_barrier(0);
-                        consume(p + 2 * GP, qC, rC);
+                        consume(p + 2 * GP, qC, rC, tC);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             } else if constexpr (PIPE == 2) {
                 uint4 qB[GP][NCH], rB[GP][NCH];
+                int tB[GP];
                 for (int p = 0; p < npairs; p += 2 * GP) {
-                    if (p + GP < npairs) issue(nb, my_col, my_typ, p + GP, qB, rB);
+                    if (p + GP < npairs) issue(nb, my_col, my_typ, p + GP, qB, rB, tB);
                     __builtin_amdgcn_sched_barrier(0);
-                    consume(p, qA, rA);
+                    consume(p, qA, rA, tA);
                     __builtin_amdgcn_sched_barrier(0);
                     if (p + GP < npairs) {
-                        if (p + 2 * GP < npairs) issue(nb, my_col, my_typ, p + 2 * GP, qA, rA);
+                        if (p + 2 * GP < npairs) issue(nb, my_col, my_typ, p + 2 * GP, qA, rA, tA);
                         __builtin_amdgcn_sched_barrier(0);
-                        consume(p + GP, qB, rB);
+                        consume(p + GP, qB, rB, tB);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             } else {
                 for (int p = 0; p < npairs; p += GP) {
-                    if (p > 0) issue(nb, my_col, my_typ, p, qA, rA);
+                    if (p > 0) issue(nb, my_col, my_typ, p, qA, rA, tA);
                     __builtin_amdgcn_sched_barrier(0);
-                    consume(p, qA, rA);
+                    consume(p, qA, rA, tA);
                 }
             }
         }
@@ -1722,9 +1767,19 @@ static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t l
         // two-deep / 10.48 ms three-deep, bf16 6.68 / 6.48 ms
         const int depth = fwd_u == 2 ? 0 : (hw_depth_env ? hw_depth_env : (sizeof(TT) == 2 ? 3 : 2));
         const int gp = hw_gp_env ? hw_gp_env : 1;     // one pair per group (measured, config 4 bf16: 6.66 ms against 8.94 ms with two)
+        // experiment: the hottest relation rows (ids 0 .. HOT-1: tables whose relation ids are ordered by frequency) in LDS
+        static const int hot_env = env_int("JMAC_FWD_HOT", 0);
+        static const int nt_env = env_int("JMAC_FWD_NT", 0);          // experiment: streaming [Q|Z] gathers
+        constexpr int HOTN = sizeof(TT) == 2 ? 40 : 20;                 // 48 KB of rows either way
+        const bool hot = hot_env && depth != 0 && v->n_items_max > 0 && loop_rel >= HOTN &&
+                         (uint64_t)(loop_rel + 1) * (uint64_t)ldrr * sizeof(TT) < 0xFFFFFFF0ull;
 #define JMAC_HW_LAUNCH(DCv)                                                                                                   \
         do {                                                                                                                  \
-            if (depth == 3) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 3, TT>), dim3(grid), dim3(kBlock), 0, st, a);           \
+            if (hot && depth == 3) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 3, TT, HOTN>), dim3(grid), dim3(kBlock), 0, st, a); \
+            else if (hot) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 2, TT, HOTN>), dim3(grid), dim3(kBlock), 0, st, a); \
+            else if (nt_env && depth == 3) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 3, TT, 0, 1>), dim3(grid), dim3(kBlock), 0, st, a); \
+            else if (nt_env && depth == 2 && gp == 1) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 2, TT, 0, 1>), dim3(grid), dim3(kBlock), 0, st, a); \
+            else if (depth == 3) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 3, TT>), dim3(grid), dim3(kBlock), 0, st, a);           \
             else if (depth == 2 && gp == 2) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 2, 2, TT>), dim3(grid), dim3(kBlock), 0, st, a);   \
             else if (depth == 2) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 2, TT>), dim3(grid), dim3(kBlock), 0, st, a);      \
             else if (gp == 2) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 2, 0, TT>), dim3(grid), dim3(kBlock), 0, st, a);         \

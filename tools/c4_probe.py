@@ -27,6 +27,9 @@ fb, fb16 = synth.fwd_algorithmic_bytes(n, e, d), synth.fwd_algorithmic_bytes(n, 
 with torch.no_grad():
     ms = t(lambda: ops.rel_attn_aggregate(PQZ, RR, av, g, 0.05, nrel - 1, 0.5))
     out["fwd_f32_ms"], out["fwd_f32_frac"] = ms, fb / (ms * 1e-3) / 8e12
+    o = ops.rel_attn_aggregate(PQZ, RR, av, g, 0.05, nrel - 1, 0.5)
+    out["f32_checksum"] = [float(o.double().sum()), float(o.double().abs().sum()), float(o[12345].double().sum())]
+    del o
     pad = os.environ.get("JMAC_FWD_HW", "1") != "0"
     P16, R16 = PQZ.to(torch.bfloat16), RR.to(torch.bfloat16)
     if pad:
@@ -34,4 +37,6 @@ with torch.no_grad():
     del PQZ
     ms = t(lambda: ops.rel_attn_aggregate(P16, R16, av, g, 0.05, nrel - 1, 0.5))
     out["fwd_bf16_ms"], out["fwd_bf16_frac"] = ms, fb16 / (ms * 1e-3) / 8e12
+    o = ops.rel_attn_aggregate(P16, R16, av, g, 0.05, nrel - 1, 0.5)
+    out["bf16_checksum"] = [float(o.double().sum()), float(o.double().abs().sum()), float(o[12345].double().sum())]
 print(json.dumps(out), flush=True)
