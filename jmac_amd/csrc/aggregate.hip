@@ -552,8 +552,11 @@ __device__ __forceinline__ float halves_meet(float a, float b) {
 // HOT > 0 (experiment, JMAC_FWD_HOT=1: north_star's "LDS-staged relation tiles"): rows 0 .. HOT-1 of [Rq|Rz] -- the hottest
 // relations when the ids are ordered by frequency -- are staged in LDS once per workgroup; an edge of such a relation reads its
 // relation chunks from LDS (its global load is pointed at row 0, an L1 hit), the Zipf tail keeps its L2 / Infinity-Cache path.
-template <int DC, int GP, int PIPE, typename TT, int HOT = 0, int NT = 0>   // PIPE: 0 = load / reduce in turn, 2 / 3 = that many groups' gathers in flight
-__global__ __launch_bounds__(kBlock) void rel_attn_fwd_hw_kernel(FwdArgs a) {
+// PIPE: 0 = load / reduce in turn (one wave per item); 12 = two groups' gathers in flight, uniform issue (the persistent form);
+// 2 = two groups, conditional issue (A/B knob).  One pair of edges per group (GP = 1: two pairs measured 8.94 against 6.66 ms)
+template <int DC, int PIPE, typename TT, int HOT = 0, int NT = 0>
+__device__ __forceinline__ void rel_attn_fwd_hw_body(const FwdArgs& a) {
+    constexpr int GP = 1;
     constexpr int CH = HwElem<TT>::CH;
     constexpr int NCH = (2 * DC + 31) / 32;            // chunk slots per lane
     constexpr int KH = (DC + 31) / 32;                 // slots k < KH hold attention-half (h) chunks on some lane
@@ -731,29 +734,28 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_hw_kernel(FwdArgs a) {
                     }
                 m = mn;
             };
-            if constexpr (PIPE == 3) {
-                // three groups in flight: group g + 2 is issued before group g is reduced (two waves per SIMD hold 2 x 3 x 2 rows:
-                // what three waves of the two-deep form would, without their registers)
-                uint4 qB[GP][NCH], rB[GP][NCH], qC[GP][NCH], rC[GP][NCH];
-                int tB[GP], tC[GP];
-                if (GP < npairs) issue(nb, my_col, my_typ, GP, qB, rB, tB);
-                for (int p = 0; p < npairs; p += 3 * GP) {
-                    if (p + 2 * GP < npairs) issue(nb, my_col, my_typ, p + 2 * GP, qC, rC, tC);
+            if constexpr (PIPE == 12) {
+                // two groups in flight, EVERY path issuing the same loads: a group past the batch's end re-reads the last pair's rows
+                // (an L1 hit; it is never reduced).  The compiler's vmcnt bookkeeping is exact only when all paths into a wait have
+                // issued the same number of loads: behind a conditional issue (the PIPE 2 form below, and the three-deep form this
+                // replaced) it falls back to vmcnt(0) -- the whole pipeline drained once per trip, seen in the ISA; here the waits
+                // count down vmcnt(11) .. vmcnt(6) chunk by chunk while the younger group stays in flight
+                uint4 qB[GP][NCH], rB[GP][NCH];
+                int tB[GP];
+                int p = 0;
+                for (;;) {
+                    issue(nb, my_col, my_typ, p + GP, qB, rB, tB);
                     __builtin_amdgcn_sched_barrier(0);
                     consume(p, qA, rA, tA);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (p + GP < npairs) {
-                        if (p + 3 * GP < npairs) issue(nb, my_col, my_typ, p + 3 * GP, qA, rA, tA);
-                        __builtin_amdgcn_sched_barrier(0);
-                        consume(p + GP, qB, rB, tB);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (p + 2 * GP < npairs) {
-                        if (p + 4 * GP < npairs) issue(nb, my_col, my_typ, p + 4 * GP, qB, rB, tB);
-                        __builtin_amdgcn_sched_barrier(0);
-                        consume(p + 2 * GP, qC, rC, tC);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    p += GP;
+                    if (p >= npairs) break;
+                    issue(nb, my_col, my_typ, p + GP, qA, rA, tA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(p, qB, rB, tB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    p += GP;
+                    if (p >= npairs) break;
                 }
             } else if constexpr (PIPE == 2) {
                 uint4 qB[GP][NCH], rB[GP][NCH];
@@ -978,6 +980,11 @@ __global__ __launch_bounds__(kBlock) void rel_attn_fwd_hw_kernel(FwdArgs a) {
         ctyp = ntyp;
     }
     empties(it - n_reg);
+}
+
+template <int DC, int PIPE, typename TT, int HOT = 0, int NT = 0>
+__global__ __launch_bounds__(kBlock) void rel_attn_fwd_hw_kernel(FwdArgs a) {
+    rel_attn_fwd_hw_body<DC, PIPE, TT, HOT, NT>(a);
 }
 
 // merges the partial (max, denominator, accumulator) triples of destinations that were split: one BLOCK per split
@@ -1751,7 +1758,6 @@ static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t l
     const bool slope01 = slope >= 0.f && slope <= 1.f;
     // half-wave lane map (rel_attn_fwd_hw_kernel): d = 256 / 300 with 16-byte aligned rows and halves
     static const int hw_env = env_int("JMAC_FWD_HW", 1);             // tuning knobs (debug)
-    static const int hw_gp_env = env_int("JMAC_FWD_HW_GP", 0);
     constexpr int CHE = 16 / (int)sizeof(TT);                          // elements per 16-byte chunk
     const bool aligned = ((((uintptr_t)P | (uintptr_t)QZ | (uintptr_t)RR) & 15) == 0) && ldp % CHE == 0 && ldqz % CHE == 0 &&
                          ldrr % CHE == 0 && dh % CHE == 0;
@@ -1763,27 +1769,26 @@ static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t l
     // (fp32 116 against 120 us, bf16 87 against 105 us): the small-graph form keeps it
     if (hw_env && slope01 && aligned && hw_shape && (fwd_u != 2 || hw_small_env)) {
         static const int hw_depth_env = env_int("JMAC_FWD_HW_DEPTH", 0);
-        // gathers in flight per wave: two groups for fp32 rows (2 400 B), three for bf16 rows (1 216 B) -- config 4: fp32 9.67 ms
-        // two-deep / 10.48 ms three-deep, bf16 6.68 / 6.48 ms
-        const int depth = fwd_u == 2 ? 0 : (hw_depth_env ? hw_depth_env : (sizeof(TT) == 2 ? 3 : 2));
-        const int gp = hw_gp_env ? hw_gp_env : 1;     // one pair per group (measured, config 4 bf16: 6.66 ms against 8.94 ms with two)
-        // experiment: the hottest relation rows (ids 0 .. HOT-1: tables whose relation ids are ordered by frequency) in LDS
+        // gathers in flight per wave (persistent form): two groups, EVERY path issuing the same loads (PIPE 12: exact vmcnt waits).
+        // Config 4, MI355X: bf16 6.9 ms with the three-deep conditional form this replaced (one vmcnt(0) per trip in its ISA)
+        // -> 6.1-6.2 ms two- or three-deep uniform (0.47 -> 0.53 of the HBM peak); four-deep conditional 7.2 ms; held to three waves
+        // per SIMD (168 VGPRs) 6.3 ms.  fp32: 10.3 ms either way (the launch moves 62 GB at 6 TB/s: the fabric's rate); the
+        // conditional two-deep form stays selectable (JMAC_FWD_HW_DEPTH=2) for A/B runs.
+        const int depth = fwd_u == 2 ? 0 : (hw_depth_env ? hw_depth_env : 12);
+        // experiments (default off, profiles/r4_pmc_config4_experiments.json): the hottest relation rows (ids 0 .. HOT-1: tables
+        // whose relation ids are ordered by frequency) in LDS; streaming [Q|Z] gathers
         static const int hot_env = env_int("JMAC_FWD_HOT", 0);
-        static const int nt_env = env_int("JMAC_FWD_NT", 0);          // experiment: streaming [Q|Z] gathers
+        static const int nt_env = env_int("JMAC_FWD_NT", 0);
         constexpr int HOTN = sizeof(TT) == 2 ? 40 : 20;                 // 48 KB of rows either way
-        const bool hot = hot_env && depth != 0 && v->n_items_max > 0 && loop_rel >= HOTN &&
+        const bool hot = hot_env && depth == 12 && v->n_items_max > 0 && loop_rel >= HOTN &&
                          (uint64_t)(loop_rel + 1) * (uint64_t)ldrr * sizeof(TT) < 0xFFFFFFF0ull;
 #define JMAC_HW_LAUNCH(DCv)                                                                                                   \
         do {                                                                                                                  \
-            if (hot && depth == 3) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 3, TT, HOTN>), dim3(grid), dim3(kBlock), 0, st, a); \
-            else if (hot) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 2, TT, HOTN>), dim3(grid), dim3(kBlock), 0, st, a); \
-            else if (nt_env && depth == 3) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 3, TT, 0, 1>), dim3(grid), dim3(kBlock), 0, st, a); \
-            else if (nt_env && depth == 2 && gp == 1) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 2, TT, 0, 1>), dim3(grid), dim3(kBlock), 0, st, a); \
-            else if (depth == 3) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 3, TT>), dim3(grid), dim3(kBlock), 0, st, a);           \
-            else if (depth == 2 && gp == 2) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 2, 2, TT>), dim3(grid), dim3(kBlock), 0, st, a);   \
-            else if (depth == 2) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 2, TT>), dim3(grid), dim3(kBlock), 0, st, a);      \
-            else if (gp == 2) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 2, 0, TT>), dim3(grid), dim3(kBlock), 0, st, a);         \
-            else hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 1, 0, TT>), dim3(grid), dim3(kBlock), 0, st, a);                      \
+            if (hot) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 12, TT, HOTN>), dim3(grid), dim3(kBlock), 0, st, a);     \
+            else if (nt_env && depth == 12) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 12, TT, 0, 1>), dim3(grid), dim3(kBlock), 0, st, a); \
+            else if (depth == 12) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 12, TT>), dim3(grid), dim3(kBlock), 0, st, a); \
+            else if (depth == 2) hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 2, TT>), dim3(grid), dim3(kBlock), 0, st, a);  \
+            else hipLaunchKernelGGL((rel_attn_fwd_hw_kernel<DCv, 0, TT>), dim3(grid), dim3(kBlock), 0, st, a);                  \
         } while (0)
         if constexpr (sizeof(TT) == 4) {
             if (dc == 75) JMAC_HW_LAUNCH(75); else JMAC_HW_LAUNCH(64);
