@@ -152,7 +152,7 @@ def run_sharded(a, rank, world, device):
                        "global_entities": n_loc * world, "global_triples": e_total, "parallelism": "dst-shard x%d" % world,
                        "wire": "bf16 [Q|Z] all-gather (flag)" if wire is not None else "fp32",
                        "edges_counted_per_step": 2 * e_total},
-            "roofline": {"bound": "hbm", "kernel": "rel_attn_fwd_kernel (rank 0, local rows)", "achieved": fb / (fms * 1e-3) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "rel_attn_fwd_hw_kernel (half-wave lane map, persistent form; rank 0, local rows)", "achieved": fb / (fms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": fb, "avg_launch_ms": fms, "launches": len(fwd)},
             "roofline_bwd": {"bound": "hbm", "achieved": bb / (bms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
