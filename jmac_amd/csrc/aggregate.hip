@@ -1517,16 +1517,13 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a, int
 //   row[h-half] = sign * sum_e ds_e * a (.) lrelu'(h_e)         (sign bits from pass A)
 //   row[v-half] = sign * sum_e w_e * g_{dst(e)}  (+ g_j for the fused self loop in pass B)
 // Both passes share ONE launch: blocks [0, grid_b) run pass B (arguments ab), the rest pass C (arguments ac).
+// The body is instantiated once per pass, each reading ITS argument struct straight from the kernel arguments: a reference
+// picked at run time (`is_b ? ab : ac`) made the compiler park the structs' pointers in scratch and reach everything through
+// flat loads (40 B of private segment, a scratch load + vmcnt(0) per 64-edge batch).
 template <int NCH, int U, int D4T>
-__global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs ab, float* __restrict__ outb, int64_t ldoutb, int grid_b,
-                                                                     BwdArgs ac, float* __restrict__ outc, int64_t ldoutc) {
+__device__ __forceinline__ void rel_attn_bwd_gather_body(const BwdArgs& a, float* __restrict__ outp, const int64_t ldout, const int bid,
+                                                         const int nblk) {
     constexpr int NCH_H = (NCH + 1) / 2;
-    const bool is_b = (int)blockIdx.x < grid_b;                       // block-uniform
-    const BwdArgs& a = is_b ? ab : ac;
-    float* const outp = is_b ? outb : outc;
-    const int64_t ldout = is_b ? ldoutb : ldoutc;
-    const int bid = is_b ? (int)blockIdx.x : (int)blockIdx.x - grid_b;
-    const int nblk = is_b ? grid_b : (int)gridDim.x - grid_b;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = nblk * kWavesPerBlock;
@@ -1629,6 +1626,15 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs ab,
             st4(row + L.coff[k], v);
         }
     }
+}
+
+template <int NCH, int U, int D4T>
+__global__ __launch_bounds__(kBlock) void rel_attn_bwd_gather_kernel(BwdArgs ab, float* __restrict__ outb, int64_t ldoutb, int grid_b,
+                                                                     BwdArgs ac, float* __restrict__ outc, int64_t ldoutc) {
+    if ((int)blockIdx.x < grid_b)                                     // block-uniform
+        rel_attn_bwd_gather_body<NCH, U, D4T>(ab, outb, ldoutb, (int)blockIdx.x, grid_b);
+    else
+        rel_attn_bwd_gather_body<NCH, U, D4T>(ac, outc, ldoutc, (int)blockIdx.x - grid_b, (int)gridDim.x - grid_b);
 }
 
 // atomic mode: dQZ starts at [0 | kappa*G[i]] (the fused self loop's dZ term) or at zero
