@@ -1848,6 +1848,97 @@ int jmac_rel_attn_aggregate_fwd_bf16_padded(const uint16_t* P, int64_t ldp, cons
                                        out_scale, out, ldo, seg_max, seg_den, ws, ws_bytes, stream);
 }
 
+// ---- merge of per-source-chunk partial aggregations (slab-pipelined exchange, jmac_amd/dist.py) --------------------------------
+// Part c is the forward above run on the edges whose SOURCE lies in chunk c (no self loop, out_scale 1): out_c[i] =
+// sqrt(deg_c) * sum_e softmax_c(e) x_e with the chunk's own (max m_c, denominator l_c).  Over all edges of destination i:
+//   M = max_c m_c,  L = sum_c exp(m_c - M) l_c,  nb[i] = sqrt(deg) * sum_c (exp(m_c - M) l_c / L) * out_c[i] / sqrt(deg_c)
+// (M, L) are what the backward of the whole graph expects as seg_max / seg_den.
+struct MergeArgs {
+    const float* out[JMAC_MERGE_MAX_PARTS];
+    const float* smax[JMAC_MERGE_MAX_PARTS];
+    const float* sden[JMAC_MERGE_MAX_PARTS];
+    const int32_t* rowptr[JMAC_MERGE_MAX_PARTS];
+    int n_parts;
+    int64_t N, ldo, ldn;
+    int d4;
+    float* nb;
+    float* seg_max;
+    float* seg_den;
+};
+
+__global__ __launch_bounds__(kBlock) void softmax_parts_merge_kernel(MergeArgs a) {
+    const int lane = lane_id();
+    const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (i >= a.N) return;
+    float m[JMAC_MERGE_MAX_PARTS], l[JMAC_MERGE_MAX_PARTS];
+    int deg[JMAC_MERGE_MAX_PARTS];
+    float M = -INFINITY;
+    int dtot = 0;
+#pragma unroll
+    for (int c = 0; c < JMAC_MERGE_MAX_PARTS; ++c) {
+        if (c < a.n_parts) {
+            m[c] = a.smax[c][i];
+            l[c] = a.sden[c][i];
+            deg[c] = a.rowptr[c][i + 1] - a.rowptr[c][i];
+        } else {
+            m[c] = -INFINITY;
+            l[c] = 0.f;
+            deg[c] = 0;
+        }
+        if (deg[c] > 0) M = fmaxf(M, m[c]);
+        dtot += deg[c];
+    }
+    float L = 0.f, f[JMAC_MERGE_MAX_PARTS];
+#pragma unroll
+    for (int c = 0; c < JMAC_MERGE_MAX_PARTS; ++c) {
+        f[c] = deg[c] > 0 ? __expf(m[c] - M) * l[c] : 0.f;      // parts are visited in index order: a fixed summation order
+        L += f[c];
+    }
+    const float sq = sqrtf((float)dtot);
+#pragma unroll
+    for (int c = 0; c < JMAC_MERGE_MAX_PARTS; ++c) f[c] = (deg[c] > 0 && L > 0.f) ? f[c] / L * sq * rsqrtf((float)deg[c]) : 0.f;
+    for (int q = lane; q < a.d4; q += 64) {
+        float4 acc = f4zero();
+#pragma unroll
+        for (int c = 0; c < JMAC_MERGE_MAX_PARTS; ++c)
+            if (c < a.n_parts && deg[c] > 0) acc = fma4(ld4(a.out[c] + i * a.ldo + 4 * q), f[c], acc);
+        st4(a.nb + i * a.ldn + 4 * q, acc);
+    }
+    if (lane == 0) {
+        a.seg_max[i] = dtot > 0 ? M : -INFINITY;
+        a.seg_den[i] = L;
+    }
+}
+
+int jmac_softmax_parts_merge_f32(const float* const* h_out, int64_t ldo, const float* const* h_seg_max, const float* const* h_seg_den,
+                                 const int32_t* const* h_rowptr, int32_t n_parts, int64_t N, int64_t d, float* nb, int64_t ldn,
+                                 float* seg_max, float* seg_den, jmac_stream_t stream) {
+    if (n_parts < 0 || n_parts > JMAC_MERGE_MAX_PARTS) return JMAC_EINVAL;
+    if (d <= 0 || d % 4 || ldo % 4 || ldn % 4 || d > ldo || d > ldn) return JMAC_EDIM;
+    if (N < 0 || (N > 0 && (!nb || !seg_max || !seg_den)) || (n_parts > 0 && (!h_out || !h_seg_max || !h_seg_den || !h_rowptr)))
+        return JMAC_EINVAL;
+    if (N == 0) return JMAC_OK;
+    MergeArgs a{};
+    for (int c = 0; c < n_parts; ++c) {
+        if (!h_out[c] || !h_seg_max[c] || !h_seg_den[c] || !h_rowptr[c]) return JMAC_EINVAL;
+        a.out[c] = h_out[c];
+        a.smax[c] = h_seg_max[c];
+        a.sden[c] = h_seg_den[c];
+        a.rowptr[c] = h_rowptr[c];
+    }
+    a.n_parts = n_parts;
+    a.N = N;
+    a.ldo = ldo;
+    a.ldn = ldn;
+    a.d4 = (int)(d / 4);
+    a.nb = nb;
+    a.seg_max = seg_max;
+    a.seg_den = seg_den;
+    hipLaunchKernelGGL(softmax_parts_merge_kernel, dim3((unsigned)((N + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
 // ---- backward workspace carving (shared by the size query and the launcher) ----
 struct BwdWs {
     size_t da_part, colsum_part, part_dst, part_src, part_rel, wds, bits, total;

@@ -50,10 +50,16 @@ class ShardedGraph:
 
     Destinations are re-indexed locally (dst - lo); sources are re-indexed into the PADDED all-gather
     layout, position = owner_rank * n_max + (src - bounds[owner]), so the gathered [world*n_max, 2d] table
-    is used as it arrives."""
+    is used as it arrives.
+
+    ``chunks`` > 1 (slab-pipelined exchange): every rank's slab of n_max rows is cut into ``chunks`` row ranges
+    [cb[c], cb[c+1]); the table is laid out CHUNK-major -- position = world * cb[c] + owner * rows_c + (local - cb[c]) --
+    so that the all-gather of chunk c (every rank contributes its rows of that range: all xGMI links busy, like the
+    one-piece all-gather) fills ONE contiguous slice of the table, and the rank's edges are split by the chunk of their
+    SOURCE into ``chunks`` sub-graphs over the same destinations (``chunk_graph``)."""
 
     def __init__(self, edge_index: np.ndarray, edge_type: np.ndarray, bounds: Sequence[int], rank: int,
-                 already_local: bool = False):
+                 already_local: bool = False, chunks: int = 1):
         bounds = np.asarray(bounds, dtype=np.int64)
         self.bounds, self.rank, self.world = bounds, rank, len(bounds) - 1
         self.lo, self.hi = int(bounds[rank]), int(bounds[rank + 1])
@@ -65,15 +71,33 @@ class ShardedGraph:
             keep = (dst >= self.lo) & (dst < self.hi)
             dst, src, edge_type = dst[keep], src[keep], np.asarray(edge_type)[keep]
         owner = np.searchsorted(bounds, src, side="right") - 1
+        local = src - bounds[owner]
         self.dst_local = (dst - self.lo).astype(np.int64)
-        self.src_padded = (owner * self.n_max + (src - bounds[owner])).astype(np.int64)
+        self.chunks = max(1, min(int(chunks), max(self.n_max, 1)))
+        cb = np.asarray([(k * self.n_max) // self.chunks for k in range(self.chunks + 1)], dtype=np.int64)
+        self.chunk_bounds = cb
+        if self.chunks == 1:
+            self.src_chunk = np.zeros(local.shape[0], dtype=np.int64)
+            self.src_padded = (owner * self.n_max + local).astype(np.int64)
+        else:
+            ch = np.searchsorted(cb, local, side="right") - 1
+            self.src_chunk = ch.astype(np.int64)
+            self.src_padded = (self.world * cb[ch] + owner * (cb[ch + 1] - cb[ch]) + (local - cb[ch])).astype(np.int64)
         self.edge_type = np.asarray(edge_type).astype(np.int64)
         self.E_local = int(self.dst_local.shape[0])
         self._rel_graph = None
+        self._chunk_graphs: dict = {}
 
-    def coo(self, device) -> Tuple[torch.Tensor, torch.Tensor]:
-        ei = torch.from_numpy(np.stack([self.dst_local, self.src_padded])).to(device)
-        return ei, torch.from_numpy(self.edge_type).to(device)
+    def coo(self, device, chunk: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        if chunk is None:
+            d, s, t = self.dst_local, self.src_padded, self.edge_type
+        else:
+            sel = self.src_chunk == chunk
+            d, s, t = self.dst_local[sel], self.src_padded[sel], self.edge_type[sel]
+        return torch.from_numpy(np.stack([d, s])).to(device), torch.from_numpy(t).to(device)
+
+    def chunk_edges(self, chunk: int) -> int:
+        return int((self.src_chunk == chunk).sum())
 
     def rel_graph(self, device, num_rel: int):
         """CSR + schedules on the HIP device (cached)."""
@@ -82,6 +106,14 @@ class ShardedGraph:
             ei, et = self.coo(device)
             self._rel_graph = RelGraph(ei, et, self.n_local, num_rel, None, num_src=self.world * self.n_max)
         return self._rel_graph
+
+    def chunk_graph(self, chunk: int, device, num_rel: int):
+        """CSR + schedules of the edges whose source lies in ``chunk`` (same destinations, same table positions)."""
+        if chunk not in self._chunk_graphs:
+            from .graph import RelGraph
+            ei, et = self.coo(device, chunk)
+            self._chunk_graphs[chunk] = RelGraph(ei, et, self.n_local, num_rel, None, num_src=self.world * self.n_max)
+        return self._chunk_graphs[chunk]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -401,6 +433,142 @@ class _EvalBnTanh(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------
+# slab-pipelined exchange: the all-gather in row chunks, chunk c aggregated while chunk c+1 is on the links
+# ------------------------------------------------------------------------------------------------
+class _HipChunked:
+    """HIP kernels of the pipelined path (tests inject a torch stand-in with the same three methods under gloo on CPU)."""
+
+    @staticmethod
+    def partial(P, table, RR, a, sg: "ShardedGraph", chunk: int, slope: float):
+        from . import ops
+        g = sg.chunk_graph(chunk, P.device, RR.shape[0])
+        out, m, l = ops.rel_attn_split_fwd_raw(P, table, RR, a, g, slope, 1.0, -1, 0)
+        return out, m, l, g.rowptr
+
+    @staticmethod
+    def merge(parts, n: int, d: int, device):
+        from . import ops
+        return ops.softmax_parts_merge(parts, n, d, device)
+
+    @staticmethod
+    def backward(P, table, RR, a, sg: "ShardedGraph", slope: float, nb, seg_max, seg_den, G):
+        from . import ops
+        return ops.rel_attn_split_bwd_raw(P, table, RR, a, sg.rel_graph(P.device, RR.shape[0]), slope, 1.0, -1, 0, nb, seg_max,
+                                          seg_den, G)
+
+
+class _ChunkedAllGather(torch.autograd.Function):
+    """[n_max, w] per rank -> the CHUNK-major [world*n_max, w] table, as ``sg.chunks`` all-gathers queued at once (RCCL runs
+    them in order on its own stream, each one on all links).  Returns at once: ``pending[c]`` is chunk c's work handle, which
+    ``_ChunkedAggregate`` waits for one by one.  Backward: one reduce-scatter per chunk slice."""
+
+    pending = None          # [(work, profile event, slice) or None] * chunks of the table returned last
+
+    @staticmethod
+    def forward(ctx, x, sg: ShardedGraph, group):
+        ctx.sg, ctx.group = sg, group
+        world = _world(group)
+        cb = sg.chunk_bounds
+        x = x.contiguous()
+        if x.shape[0] != sg.n_max:
+            raise ValueError("the rank's table must be padded to n_max rows")
+        works = [None] * sg.chunks
+        _ChunkedAllGather.pending = works
+        if _skip(group):
+            return x.clone()                                 # one rank: the chunk-major table is the input
+        table = torch.empty((world * sg.n_max,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        gloo = dist.get_backend(group) == "gloo"
+        for c in range(sg.chunks):                           # every chunk's collective is queued now, in order
+            dst, src = table[world * cb[c]:world * cb[c + 1]], x[cb[c]:cb[c + 1]]
+            if src.shape[0] == 0:
+                continue
+            e0 = _cev(src)
+            if gloo and src.is_cuda:                         # tests only: stage through the host
+                h = torch.empty(dst.shape, dtype=src.dtype)
+                dist.all_gather_into_tensor(h, src.cpu(), group=group)
+                dst.copy_(h)
+                _cdone("all_gather_qz_chunk", e0, dst)
+            elif gloo:
+                dist.all_gather_into_tensor(dst, src, group=group)
+            else:
+                works[c] = (dist.all_gather_into_tensor(dst, src, group=group, async_op=True), e0, dst)
+        return table
+
+    @staticmethod
+    def wait(chunk: int) -> None:
+        """Make the compute stream wait for chunk ``chunk`` of the pending table (no host block under RCCL)."""
+        p = _ChunkedAllGather.pending
+        if p is not None and p[chunk] is not None:
+            work, e0, dst = p[chunk]
+            p[chunk] = None
+            work.wait()
+            _cdone("all_gather_qz_chunk", e0, dst)
+
+    @staticmethod
+    def backward(ctx, g):
+        sg, group = ctx.sg, ctx.group
+        if _skip(group):
+            return g, None, None
+        world = _world(group)
+        cb = sg.chunk_bounds
+        g = g.contiguous()
+        out = torch.empty((sg.n_max,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        r = dist.get_rank(group)
+        gloo = dist.get_backend(group) == "gloo"
+        for c in range(sg.chunks):                           # adjoint of each chunk's all-gather
+            rows = int(cb[c + 1] - cb[c])
+            if rows == 0:
+                continue
+            gc = g[world * cb[c]:world * cb[c + 1]]
+            if gloo:                                         # gloo has no reduce_scatter: all-reduce + slice
+                gc = gc.clone()
+                _all_reduce(gc, group)
+                out[cb[c]:cb[c + 1]] = gc[r * rows:(r + 1) * rows]
+            else:
+                e0 = _cev(gc)
+                dist.reduce_scatter_tensor(out[cb[c]:cb[c + 1]], gc, group=group)
+                _cdone("reduce_scatter_dqz_chunk", e0, gc)
+        return out, None, None
+
+
+class _ChunkedAggregate(torch.autograd.Function):
+    """nb[i] = sqrt(deg_i) * sum_e alpha_e (Z[j] - Rz[t]) over the rank's rows from a table whose chunks are still arriving:
+    the compute stream waits for chunk c only, aggregates the sub-graph of sources in chunk c into a partial (out_c, max_c,
+    den_c) and goes on to c+1 while that chunk is on the links; one merge pass combines the partials per destination
+    (jmac_softmax_parts_merge_f32) and yields the whole graph's (max, den) -- so the BACKWARD is the ordinary one on the whole
+    graph and the whole table.  Price: ``chunks`` partial [n, d] outputs written and read once more (the merge)."""
+
+    @staticmethod
+    def forward(ctx, P, table, RR, a, sg: ShardedGraph, slope: float, kernels):
+        P, RR, a = P.contiguous(), RR.contiguous(), a.contiguous()
+        n, d = sg.n_local, P.shape[1]
+        parts = []
+        for c in range(sg.chunks):
+            _ChunkedAllGather.wait(c)
+            if n > 0 and sg.chunk_edges(c) > 0:
+                parts.append(kernels.partial(P, table, RR, a, sg, c, slope))
+        _ChunkedAllGather.pending = None
+        nb, seg_max, seg_den = kernels.merge(parts, n, d, P.device)
+        ctx.save_for_backward(P, table, RR, a, nb, seg_max, seg_den)
+        ctx.sg, ctx.slope, ctx.kernels = sg, slope, kernels
+        return nb
+
+    @staticmethod
+    def backward(ctx, G):
+        P, table, RR, a, nb, seg_max, seg_den = ctx.saved_tensors
+        dP, dT, dRR, da = ctx.kernels.backward(P, table, RR, a, ctx.sg, ctx.slope, nb, seg_max, seg_den, G.contiguous())
+        return dP, dT, dRR, da, None, None, None
+
+
+def chunked_all_gather(x: torch.Tensor, sg: ShardedGraph, group=None) -> torch.Tensor:
+    return _ChunkedAllGather.apply(x, sg, group)
+
+
+def chunked_aggregate(P, table, RR, a, sg: ShardedGraph, slope: float, kernels=None) -> torch.Tensor:
+    return _ChunkedAggregate.apply(P, table, RR, a, sg, float(slope), kernels if kernels is not None else _HipChunked)
+
+
+# ------------------------------------------------------------------------------------------------
 # the sharded layer
 # ------------------------------------------------------------------------------------------------
 def hip_local_aggregate(P, QZ, RR, a, sg: ShardedGraph, slope: float) -> torch.Tensor:
@@ -428,12 +596,13 @@ class ShardedRelationAwareLayer(nn.Module):
     ``local_aggregate`` (CPU test double) the torch formulation of the same steps is used."""
 
     def __init__(self, layer: nn.Module, group=None, local_aggregate: Optional[Callable] = None, bn_kernels=None,
-                 wire_dtype=None):
+                 wire_dtype=None, chunk_kernels=None):
         super().__init__()
         self.layer = layer                       # a jmac_amd.layer.RelationAwareLayer (holds the parameters)
         self.group = group
         self.local_aggregate = local_aggregate
         self.bn_kernels = bn_kernels
+        self.chunk_kernels = chunk_kernels       # None: the HIP kernels; a CPU stand-in in the gloo tests (sg.chunks > 1)
         # None / torch.float32: the [Q|Z] table crosses xGMI in fp32 (default: results equal the one-GPU layer's).
         # torch.bfloat16: it crosses as bf16 -- half the bytes of the exchange that bounds the 8-GPU step (16.8 GB
         # received per GPU and layer at config 4 x 8) -- and is widened on arrival; the gathered Q / Z values then
@@ -457,13 +626,28 @@ class ShardedRelationAwareLayer(nn.Module):
         Z_loc = QZ_loc[:, d:]
         if sg.n_local < sg.n_max:                                    # pad to the common slab height
             QZ_loc = F.pad(QZ_loc, (0, 0, 0, sg.n_max - sg.n_local))
+        slope = L.atv_mlp.negative_slope
+        if sg.chunks > 1:
+            # slab-pipelined exchange: the table crosses in sg.chunks row chunks, chunk c is aggregated while c+1 is on the
+            # links (_ChunkedGatherAggregate); the self term and the /2 are then separate (own Z rows: no exchange)
+            if self.wire_dtype is not None and self.wire_dtype != QZ_loc.dtype:
+                raise NotImplementedError("the pipelined exchange carries the fp32 wire only")
+            table = chunked_all_gather(QZ_loc, sg, self.group)       # all chunks queued; nothing waits yet
+            P = torch.mm(x_local, L.w_att[:d_in])
+            rel = L.transform_relations(rel_emb)
+            RR = L._rel_mm(rel, wqz)
+            a = L.a_att.reshape(-1).float()
+            nb = chunked_aggregate(P, table, RR, a, sg, slope, self.chunk_kernels)
+            pre = (nb + Z_loc - RR[-1, d:]) * 0.5
+            if L.layer_act is torch.tanh and (self.chunk_kernels is None or self.bn_kernels is not None):
+                return sync_bn_tanh(pre, L.bn, sg.n_global, self.group, self.bn_kernels)
+            return L.layer_act(sync_batch_norm(pre, sg.n_global, L.bn, self.group))
         QZ = all_gather_rows(QZ_loc.contiguous(), self.group, defer=True, wire_dtype=self.wire_dtype)   # [world*n_max, 2d], in flight
         P = torch.mm(x_local, L.w_att[:d_in])
         rel = L.transform_relations(rel_emb)
         RR = L._rel_mm(rel, wqz)
         a = L.a_att.reshape(-1).float()
         _AllGatherRows.pending_wait()
-        slope = L.atv_mlp.negative_slope
         if self.local_aggregate is None:
             pre = hip_local_layer(P.contiguous(), QZ, RR, a, sg, slope)
         else:

@@ -165,6 +165,79 @@ def rel_attn_aggregate(PQZ: torch.Tensor, RR: torch.Tensor, a: torch.Tensor, gra
     return _RelAttnAggregate.apply(PQZ, RR, a, graph, float(slope), int(loop_rel), float(out_scale), int(bwd_mode))
 
 
+def rel_attn_split_fwd_raw(P, QZ, RR, a, graph: RelGraph, slope: float, out_scale: float, loop_rel: int, self_off: int):
+    """jmac_rel_attn_aggregate_fwd_f32 with P [N_dst, d] and QZ [N_src, 2d] as separate tables (no autograd): out [N, d] and
+    the per-destination softmax (max, denominator)."""
+    N, d = P.shape
+    if graph.N != N or graph.num_src != QZ.shape[0] or QZ.shape[1] != 2 * d:
+        raise ValueError("graph / table shapes disagree")
+    L = lib()
+    dev = P.device
+    out = torch.empty((N, d), dtype=torch.float32, device=dev)
+    seg_max = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+    seg_den = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+    s = graph.by_dst
+    ws_bytes = int(L.jmac_rel_attn_fwd_workspace_bytes(s.n_parts_max, d))
+    ws = _ws(ws_bytes, dev)
+    ev0 = _ev() if PROFILE is not None else None
+    check(L.jmac_rel_attn_aggregate_fwd_f32(
+        ptr(P), d, ptr(QZ), 2 * d, ptr(RR), RR.shape[1], ptr(a),
+        ptr(graph.col), ptr(graph.etype), C.byref(s.view()), N, d, float(slope), int(loop_rel), int(self_off), float(out_scale),
+        ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(ws), ws_bytes, stream()), "jmac_rel_attn_aggregate_fwd_f32")
+    if ev0 is not None:
+        PROFILE.append(("rel_attn_fwd", ev0, _ev()))
+    return out, seg_max, seg_den
+
+
+def rel_attn_split_bwd_raw(P, QZ, RR, a, graph: RelGraph, slope: float, out_scale: float, loop_rel: int, self_off: int,
+                           out, seg_max, seg_den, G):
+    """jmac_rel_attn_aggregate_bwd_f32 (deterministic form) for the split tables: dP, dQZ, dRR, da."""
+    L = lib()
+    dev = P.device
+    N, d = P.shape
+    nsrc, nrel = QZ.shape[0], RR.shape[0]
+    G = _f32c(G).contiguous()
+    graph.ensure_backward_views()
+    dP, dQZ, dRR, da = torch.empty_like(P), torch.empty_like(QZ), torch.empty_like(RR), torch.empty_like(a)
+    vd, vs, vr = graph.by_dst_bwd.view(), graph.by_src.view(), graph.by_rel.view()
+    ws_bytes = int(L.jmac_rel_attn_bwd_workspace_bytes(N, graph.E, nrel, d, graph.by_dst_bwd.n_parts_max,
+                                                       graph.by_src.n_parts_max, graph.by_rel.n_parts_max, 1))
+    ws = _ws(ws_bytes, dev)
+    ev0 = _ev() if PROFILE is not None else None
+    check(L.jmac_rel_attn_aggregate_bwd_f32(
+        ptr(P), d, ptr(QZ), 2 * d, ptr(RR), RR.shape[1], ptr(a),
+        ptr(graph.col), ptr(graph.etype), ptr(graph.dst_of_slot), C.byref(vd), C.byref(vs), C.byref(vr),
+        N, nsrc, graph.E, nrel, d, float(slope), int(loop_rel), int(self_off), float(out_scale),
+        ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(G), d,
+        ptr(dP), d, ptr(dQZ), 2 * d, ptr(dRR), dRR.shape[1], ptr(da), 1, ptr(ws), ws_bytes, stream()),
+        "jmac_rel_attn_aggregate_bwd_f32")
+    if ev0 is not None:
+        PROFILE.append(("rel_attn_bwd", ev0, _ev()))
+    return dP, dQZ, dRR, da
+
+
+def softmax_parts_merge(parts, N: int, d: int, device):
+    """jmac_softmax_parts_merge_f32: parts = [(out_c [N,d], seg_max_c [N], seg_den_c [N], rowptr_c [N+1] int32), ...] of the
+    same destinations over disjoint edge sets -> (nb [N,d], seg_max [N], seg_den [N]) of their union."""
+    L = lib()
+    n = len(parts)
+    nb = torch.empty((N, d), dtype=torch.float32, device=device)
+    seg_max = torch.empty(max(N, 1), dtype=torch.float32, device=device)
+    seg_den = torch.empty(max(N, 1), dtype=torch.float32, device=device)
+    arr = lambda k: (C.c_void_p * max(n, 1))(*[ptr(p[k]) for p in parts])
+    for o, m, l, rp in parts:
+        require_device(o, m, l, rp)
+        if o.shape != (N, d) or not o.is_contiguous() or rp.dtype != torch.int32 or rp.numel() != N + 1:
+            raise ValueError("softmax_parts_merge: part shapes disagree")
+    check(L.jmac_softmax_parts_merge_f32(arr(0), d, arr(1), arr(2), arr(3), n, N, d, ptr(nb), d, ptr(seg_max), ptr(seg_den),
+                                         stream()), "jmac_softmax_parts_merge_f32")
+    if n == 0:                       # no edges at all: the kernel is not given anything to read
+        nb.zero_()
+        seg_max.fill_(float("-inf"))
+        seg_den.zero_()
+    return nb, seg_max, seg_den
+
+
 class _RelAttnAggregateSplit(torch.autograd.Function):
     """Same op with P [N_dst, d] and QZ [N_src, 2d] as separate tables (destination-sharded multi-GPU: P holds
     the rank's rows, QZ the all-gathered table).  The fused self term reads QZ[self_off + i] (loop_rel < 0: none)."""
@@ -173,24 +246,7 @@ class _RelAttnAggregateSplit(torch.autograd.Function):
     def forward(ctx, P, QZ, RR, a, graph: RelGraph, slope: float, out_scale: float, loop_rel: int, self_off: int):
         require_device(P, QZ, RR, a)
         P, QZ, RR, a = _f32c(P).contiguous(), _f32c(QZ).contiguous(), _f32c(RR).contiguous(), _f32c(a).contiguous()
-        N, d = P.shape
-        if graph.N != N or graph.num_src != QZ.shape[0] or QZ.shape[1] != 2 * d:
-            raise ValueError("graph / table shapes disagree")
-        L = lib()
-        dev = P.device
-        out = torch.empty((N, d), dtype=torch.float32, device=dev)
-        seg_max = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
-        seg_den = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
-        s = graph.by_dst
-        ws_bytes = int(L.jmac_rel_attn_fwd_workspace_bytes(s.n_parts_max, d))
-        ws = _ws(ws_bytes, dev)
-        ev0 = _ev() if PROFILE is not None else None
-        check(L.jmac_rel_attn_aggregate_fwd_f32(
-            ptr(P), d, ptr(QZ), 2 * d, ptr(RR), RR.shape[1], ptr(a),
-            ptr(graph.col), ptr(graph.etype), C.byref(s.view()), N, d, float(slope), int(loop_rel), int(self_off), float(out_scale),
-            ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(ws), ws_bytes, stream()), "jmac_rel_attn_aggregate_fwd_f32")
-        if ev0 is not None:
-            PROFILE.append(("rel_attn_fwd", ev0, _ev()))
+        out, seg_max, seg_den = rel_attn_split_fwd_raw(P, QZ, RR, a, graph, slope, out_scale, loop_rel, self_off)
         ctx.save_for_backward(P, QZ, RR, a, out, seg_max, seg_den)
         ctx.graph, ctx.slope, ctx.out_scale, ctx.loop_rel, ctx.self_off = graph, slope, out_scale, int(loop_rel), int(self_off)
         return out
@@ -198,28 +254,8 @@ class _RelAttnAggregateSplit(torch.autograd.Function):
     @staticmethod
     def backward(ctx, G):
         P, QZ, RR, a, out, seg_max, seg_den = ctx.saved_tensors
-        graph: RelGraph = ctx.graph
-        L = lib()
-        dev = P.device
-        N, d = P.shape
-        nsrc, nrel = QZ.shape[0], RR.shape[0]
-        G = _f32c(G).contiguous()
-        graph.ensure_backward_views()
-        dP, dQZ, dRR, da = torch.empty_like(P), torch.empty_like(QZ), torch.empty_like(RR), torch.empty_like(a)
-        vd, vs, vr = graph.by_dst_bwd.view(), graph.by_src.view(), graph.by_rel.view()
-        ws_bytes = int(L.jmac_rel_attn_bwd_workspace_bytes(N, graph.E, nrel, d, graph.by_dst_bwd.n_parts_max,
-                                                           graph.by_src.n_parts_max, graph.by_rel.n_parts_max, 1))
-        ws = _ws(ws_bytes, dev)
-        ev0 = _ev() if PROFILE is not None else None
-        check(L.jmac_rel_attn_aggregate_bwd_f32(
-            ptr(P), d, ptr(QZ), 2 * d, ptr(RR), RR.shape[1], ptr(a),
-            ptr(graph.col), ptr(graph.etype), ptr(graph.dst_of_slot), C.byref(vd), C.byref(vs), C.byref(vr),
-            N, nsrc, graph.E, nrel, d, float(ctx.slope), ctx.loop_rel, ctx.self_off, float(ctx.out_scale),
-            ptr(out), d, ptr(seg_max), ptr(seg_den), ptr(G), d,
-            ptr(dP), d, ptr(dQZ), 2 * d, ptr(dRR), dRR.shape[1], ptr(da), 1, ptr(ws), ws_bytes, stream()),
-            "jmac_rel_attn_aggregate_bwd_f32")
-        if ev0 is not None:
-            PROFILE.append(("rel_attn_bwd", ev0, _ev()))
+        dP, dQZ, dRR, da = rel_attn_split_bwd_raw(P, QZ, RR, a, ctx.graph, ctx.slope, ctx.out_scale, ctx.loop_rel, ctx.self_off,
+                                                  out, seg_max, seg_den, G)
         return dP, dQZ, dRR, da, None, None, None, None, None
 
 

@@ -39,6 +39,54 @@ def _standin_aggregate(P, QZ, RR, a, sg, slope):
     return nb + 0.0 * (QZ.sum() + P.sum() + RR.sum() + a.sum())
 
 
+class _StandinChunked:
+    """Test double for the pipelined path's three kernels (jmac_amd.dist._HipChunked): the partial aggregation of one source
+    chunk's edges, the per-destination merge of the partials, the whole-graph backward -- torch on the CPU."""
+
+    @staticmethod
+    def partial(P, table, RR, a, sg, chunk, slope):
+        d = P.shape[1]
+        sel = sg.src_chunk == chunk
+        dst, src, typ = (torch.from_numpy(x[sel]) for x in (sg.dst_local, sg.src_padded, sg.edge_type))
+        # only rows of THIS chunk's slice of the chunk-major table may be read: the later chunks have not arrived yet
+        lo, hi = sg.world * int(sg.chunk_bounds[chunk]), sg.world * int(sg.chunk_bounds[chunk + 1])
+        assert ((src >= lo) & (src < hi)).all()
+        diff = table[src] - RR[typ]
+        s = (torch.nn.functional.leaky_relu(P[dst] + diff[:, :d], slope) @ a.view(-1, 1)).view(-1)
+        n = sg.n_local
+        m = torch.full((n,), float("-inf")).scatter_reduce(0, dst, s, "amax", include_self=True)
+        w = torch.exp(s - m[dst])
+        l = torch.zeros(n).index_add_(0, dst, w)
+        deg = torch.bincount(dst, minlength=n)
+        o = torch.zeros(n, d).index_add_(0, dst, w.view(-1, 1) * diff[:, d:])
+        out = o * (deg.float().sqrt() / l.clamp_min(1e-30)).view(-1, 1)
+        rowptr = torch.cat([torch.zeros(1, dtype=torch.int64), deg.cumsum(0)]).to(torch.int32)
+        return out, m, l, rowptr
+
+    @staticmethod
+    def merge(parts, n, d, device):
+        if not parts or n == 0:
+            return torch.zeros(n, d), torch.full((max(n, 1),), float("-inf")), torch.zeros(max(n, 1))
+        deg = torch.stack([(rp[1:] - rp[:-1]).float() for _, _, _, rp in parts])                 # [C, n]
+        m = torch.stack([p[1] for p in parts])
+        l = torch.stack([p[2] for p in parts])
+        M = torch.where(deg > 0, m, torch.full_like(m, float("-inf"))).max(0).values
+        f = torch.where(deg > 0, torch.exp(m - M) * l, torch.zeros_like(l))
+        L = f.sum(0)
+        w = torch.where((deg > 0) & (L > 0), f / L.clamp_min(1e-30) * (deg.sum(0).sqrt() / deg.clamp_min(1).sqrt()), torch.zeros_like(f))
+        nb = sum(w[c].view(-1, 1) * parts[c][0] for c in range(len(parts)))
+        return nb, M, L
+
+    @staticmethod
+    def backward(P, table, RR, a, sg, slope, nb, seg_max, seg_den, G):
+        with torch.enable_grad():
+            xs = [t.detach().clone().requires_grad_(True) for t in (P, table, RR, a)]
+            out = _standin_aggregate(*xs, sg, slope)
+            # the merged forward result must BE the whole-graph aggregate (this is what the HIP backward is handed as ``out``)
+            assert torch.allclose(out.detach(), nb, atol=2e-5), float((out.detach() - nb).abs().max())
+            return torch.autograd.grad(out, xs, G)
+
+
 class _StandinBN:
     """Test double for the phased BN + tanh kernels (include/jmac_hip.h): same contract, torch on the CPU."""
 
@@ -84,10 +132,11 @@ def _worker(rank, world, port, ret):
         bounds = partition_rows(np.bincount(ei[0], minlength=n), world)
         if os.environ.get("JMAC_TEST_BOUNDS"):          # hand-made ranges: uneven, and a rank that owns no row at all
             bounds = np.array([int(x) for x in os.environ["JMAC_TEST_BOUNDS"].split(",")], dtype=np.int64)
-        sg = ShardedGraph(ei, et, bounds, rank)
+        chunks = int(os.environ.get("JMAC_TEST_CHUNKS", "1"))
+        sg = ShardedGraph(ei, et, bounds, rank, chunks=chunks)
         torch.manual_seed(11)
         base = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())
-        lay = ShardedRelationAwareLayer(base, local_aggregate=_standin_aggregate,
+        lay = ShardedRelationAwareLayer(base, local_aggregate=_standin_aggregate, chunk_kernels=_StandinChunked,
                                         bn_kernels=_StandinBN if os.environ.get("JMAC_TEST_FUSED_BN") else None,
                                         wire_dtype=torch.bfloat16 if os.environ.get("JMAC_TEST_WIRE_BF16") else None).train()
         x = X[sg.lo:sg.hi].clone().requires_grad_(True)
@@ -105,17 +154,22 @@ def _worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("fused_bn,world,bounds", [(False, 2, None), (True, 2, None), (True, 4, "0,25,25,60,90"),
-                                                   (False, 4, "0,1,40,41,90")])
-def test_sharded_layer_equals_single_process_oracle(fused_bn, world, bounds, monkeypatch):
+@pytest.mark.parametrize("fused_bn,world,bounds,chunks", [(False, 2, None, 1), (True, 2, None, 1), (True, 4, "0,25,25,60,90", 1),
+                                                          (False, 4, "0,1,40,41,90", 1), (True, 2, None, 3),
+                                                          (True, 4, "0,25,25,60,90", 4), (False, 4, "0,1,40,41,90", 2)])
+def test_sharded_layer_equals_single_process_oracle(fused_bn, world, bounds, chunks, monkeypatch):
     """fused_bn: BatchNorm + tanh through sync_bn_tanh (per-rank moments, all-gather, Chan combination, all-reduced
     backward sums) with the kernels' torch stand-in; otherwise the plain torch formulation.  world 4 with hand-made row
     ranges: uneven shards, single-row shards and a rank that owns NO row (its table slab is all padding, its BN moments
-    carry weight zero in the Chan combination, its reduce-scatter slice is empty)."""
+    carry weight zero in the Chan combination, its reduce-scatter slice is empty).  chunks > 1: the same through the
+    slab-pipelined exchange (uneven chunk heights, chunks without edges, a rank without rows)."""
     if bounds:
         monkeypatch.setenv("JMAC_TEST_BOUNDS", bounds)
     else:
         monkeypatch.delenv("JMAC_TEST_BOUNDS", raising=False)
+    # chunks > 1: the slab-pipelined exchange -- chunk-major table, one all-gather per row chunk, per-chunk partial
+    # aggregations merged per destination, one reduce-scatter per chunk slice in the backward
+    monkeypatch.setenv("JMAC_TEST_CHUNKS", str(chunks))
     if fused_bn:
         monkeypatch.setenv("JMAC_TEST_FUSED_BN", "1")
     else:
@@ -164,6 +218,22 @@ def test_partition_rows_balances_edges():
     owner = (ei[1][(ei[0] >= 30)] >= 30).astype(int)
     src = ei[1][ei[0] >= 30]
     assert (sg.src_padded == owner * 70 + (src - b[owner])).all()
+    # chunk-major layout of the pipelined exchange: a bijection of (owner, local row) onto [0, world * n_max), chunk c of every
+    # rank inside the slice [world * cb[c], world * cb[c+1]) -- the slice ONE all-gather of that row chunk fills
+    for chunks in (2, 3, 7, 1000):
+        sgc = ShardedGraph(ei, rng.integers(0, 5, 400), b, 1, chunks=chunks)
+        cb = sgc.chunk_bounds
+        assert cb[0] == 0 and cb[-1] == sgc.n_max and (np.diff(cb) >= 0).all() and sgc.chunks == min(chunks, sgc.n_max)
+        pos = {}
+        for ow in range(2):
+            for loc in range(int(b[ow + 1] - b[ow])):
+                c = int(np.searchsorted(cb, loc, side="right") - 1)
+                q = 2 * cb[c] + ow * (cb[c + 1] - cb[c]) + (loc - cb[c])
+                assert 2 * cb[c] <= q < 2 * cb[c + 1]
+                pos[(ow, loc)] = int(q)
+        assert len(set(pos.values())) == len(pos) and max(pos.values()) < 2 * sgc.n_max
+        assert all(pos[(int(o), int(s_ - b[o]))] == int(q) for o, s_, q in zip(owner, src, sgc.src_padded))
+        assert sum(sgc.chunk_edges(c) for c in range(sgc.chunks)) == sgc.E_local
 
 
 @pytest.mark.timeout(300)

@@ -45,7 +45,7 @@ def _worker(rank, world, port, ret):
         bounds = partition_rows(np.bincount(ei[0], minlength=n), world)
         if os.environ.get("JMAC_TEST_BOUNDS"):          # hand-made ranges: uneven, and a rank that owns no row at all
             bounds = np.array([int(x) for x in os.environ["JMAC_TEST_BOUNDS"].split(",")], dtype=np.int64)
-        sg = ShardedGraph(ei, et, bounds, rank)
+        sg = ShardedGraph(ei, et, bounds, rank, chunks=int(os.environ.get("JMAC_TEST_CHUNKS", "1")))
         torch.manual_seed(11)
         base = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args()).to(dev)
         lay = ShardedRelationAwareLayer(base).train()                   # default local op = HIP kernels
@@ -62,10 +62,14 @@ def _worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,bounds", [(2, None), (3, "0,250,250,700")], ids=["two-ranks", "three-ranks-one-empty"])
-def test_sharded_hip_layer_two_ranks(world, bounds, monkeypatch):
+@pytest.mark.parametrize("world,bounds,chunks", [(2, None, 1), (3, "0,250,250,700", 1), (2, None, 4), (3, "0,250,250,700", 3)],
+                         ids=["two-ranks", "three-ranks-one-empty", "two-ranks-pipelined", "three-ranks-one-empty-pipelined"])
+def test_sharded_hip_layer_two_ranks(world, bounds, chunks, monkeypatch):
     """``three-ranks-one-empty``: rank 1 owns no row -- its kernels see N = 0, its table slab is padding, and it must still
-    take part in every collective of the forward and the backward."""
+    take part in every collective of the forward and the backward.  ``pipelined``: the slab-pipelined exchange (chunk-major
+    table, per-chunk partial aggregations on the HIP forward kernel, jmac_softmax_parts_merge_f32, whole-graph HIP backward,
+    one reduce-scatter per chunk)."""
+    monkeypatch.setenv("JMAC_TEST_CHUNKS", str(chunks))
     if bounds:
         monkeypatch.setenv("JMAC_TEST_BOUNDS", bounds)
     else:
@@ -105,7 +109,8 @@ def _rccl_worker(rank, world, port, ret):
         jd.FORCE_COLLECTIVES = True                                      # real RCCL calls although world == 1
         dev = torch.device("cuda", 0)
         ei, et, X, R, G, n, nr, d = _case()
-        sg = jd.ShardedGraph(ei, et, jd.partition_rows(np.bincount(ei[0], minlength=n), 1), 0)
+        sg = jd.ShardedGraph(ei, et, jd.partition_rows(np.bincount(ei[0], minlength=n), 1), 0,
+                             chunks=int(os.environ.get("JMAC_TEST_CHUNKS", "1")))
         torch.manual_seed(11)
         base = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args()).to(dev)
         lay = jd.ShardedRelationAwareLayer(base).train()
@@ -121,8 +126,11 @@ def _rccl_worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(600)
-def test_rccl_entry_points_world1():
-    """all_gather_into_tensor / reduce_scatter_tensor / all_reduce through RCCL on device tensors."""
+@pytest.mark.parametrize("chunks", [1, 5], ids=["one-piece", "pipelined"])
+def test_rccl_entry_points_world1(chunks, monkeypatch):
+    """all_gather_into_tensor / reduce_scatter_tensor / all_reduce through RCCL on device tensors; ``pipelined``: the chunked
+    exchange's async all-gathers (queued at once, waited for one by one) and per-chunk reduce-scatters."""
+    monkeypatch.setenv("JMAC_TEST_CHUNKS", str(chunks))
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     mp.spawn(_rccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
@@ -139,6 +147,40 @@ def test_rccl_entry_points_world1():
     assert_close(ret[0]["out"], ref, 1e-4, 1e-6, "out")
     assert_close(ret[0]["gx"], Xc.grad, 1e-4, 1e-6, "grad_X")
     assert_close(ret[0]["gw"], p["w_att"].grad, 1e-4, 1e-6, "grad w_att")
+
+
+def test_parts_merge_equals_whole_graph_forward():
+    """jmac_softmax_parts_merge_f32: the forward kernel on the sub-graphs of a 5-way split of the SOURCES, merged, equals the
+    forward kernel on the whole graph (output and the (max, denominator) the backward reads) -- hubs of 900 in-edges,
+    destinations with no edge in some or all parts, an empty part."""
+    from jmac_amd import ops
+    from jmac_amd.graph import RelGraph
+    dev = torch.device("cuda", 0)
+    ei, et, X, R, G, n, nr, d = _case()
+    gen = torch.Generator().manual_seed(2)
+    P, QZ = (torch.randn(n, d, generator=gen) * 0.3).to(dev), (torch.randn(n, 2 * d, generator=gen) * 0.3).to(dev)
+    RR, a = (torch.randn(nr + 1, 2 * d, generator=gen) * 0.3).to(dev), (torch.randn(d, generator=gen) * 0.3).to(dev)
+    eit, ett = torch.from_numpy(ei).to(dev), torch.from_numpy(et).to(dev)
+    whole = RelGraph(eit, ett, n, nr + 1, None)
+    want, wm, wl = ops.rel_attn_split_fwd_raw(P, QZ, RR, a, whole, 0.05, 1.0, -1, 0)
+    cut = [0, 90, 90, 300, 301, n]                                    # source ranges; the second one is empty
+    parts = []
+    for c in range(5):
+        sel = (eit[1] >= cut[c]) & (eit[1] < cut[c + 1])
+        if int(sel.sum()) == 0:
+            continue
+        g = RelGraph(eit[:, sel].contiguous(), ett[sel].contiguous(), n, nr + 1, None)
+        o, m, l = ops.rel_attn_split_fwd_raw(P, QZ, RR, a, g, 0.05, 1.0, -1, 0)
+        parts.append((o, m, l, g.rowptr))
+    assert len(parts) == 4
+    nb, M, L = ops.softmax_parts_merge(parts, n, d, dev)
+    deg = np.bincount(ei[0], minlength=n)
+    has = torch.from_numpy(deg > 0).to(dev)
+    assert_close(nb.cpu(), want.cpu().double(), 1e-5, 1e-6, "merged output")
+    assert torch.equal(M[has], wm[has]) and bool((M[~has] == float("-inf")).all())
+    assert_close(L[has].cpu(), wl[has].cpu().double(), 1e-5, 1e-7, "merged denominator")
+    nb0, M0, L0 = ops.softmax_parts_merge([], n, d, dev)              # no part at all: zeros / -inf / 0
+    assert float(nb0.abs().max()) == 0.0 and bool((M0 == float("-inf")).all()) and float(L0.abs().max()) == 0.0
 
 
 # ---- config 5 (OpenEA 15K shape, alignment only, 2 ranks): query-sharded scoring on the HIP kernels ------------
