@@ -110,6 +110,9 @@ def parse():
                          "PER GPU; strong = ONE global graph of 200k entities / 20M triples x synth-scale (north_star's 8-GPU "
                          "configuration: --scaling strong --synth-scale 10 = 2M / 200M), the same graph at every N")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the first pass")
+    ap.add_argument("--pipeline-chunks", type=int, default=0,
+                    help="sharded workload: cut the [Q|Z] exchange into this many row chunks and aggregate chunk c while chunk c+1 is "
+                         "on the links (jmac_amd.dist slab-pipelined exchange); 0 = one-piece all-gather (default)")
     ap.add_argument("--wire-bf16", action="store_true",
                     help="sharded workload: the [Q|Z] all-gather travels as bf16 (not the reference's fp32 result: see DESIGN.md)")
     ap.add_argument("--dry-launch", action="store_true",

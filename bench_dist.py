@@ -69,7 +69,8 @@ def run_sharded(a, rank, world, device):
         n_loc, e_loc = int(1_000_000 * a.synth_scale), int(20_000_000 * a.synth_scale)
         ei, et = _local_graph(rank, world, n_loc, e_loc, nr)
     bounds = np.arange(world + 1, dtype=np.int64) * n_loc
-    sg = ShardedGraph(ei, et, bounds, rank, already_local=True)
+    chunks = max(int(getattr(a, "pipeline_chunks", 0) or 0), 1)      # > 1: the slab-pipelined exchange (jmac_amd.dist)
+    sg = ShardedGraph(ei, et, bounds, rank, already_local=True, chunks=chunks)
     del ei, et
     torch.manual_seed(7)                                              # identical replicated parameters on every rank
     largs = types.SimpleNamespace(leaky_relu_w=0.05, comp_op="sub")
@@ -130,11 +131,17 @@ def run_sharded(a, rank, world, device):
     bwd = [e0.elapsed_time(e1) for n, e0, e1 in rec if n == "rel_attn_bwd"]
     fb = synth.fwd_algorithmic_bytes(n_loc, e_loc, d)
     bb = synth.bwd_algorithmic_bytes(n_loc, e_loc, d)
-    fms, bms = float(np.mean(fwd)), float(np.mean(bwd))
+    # per LAYER: the pipelined exchange runs the forward kernel once per chunk (partial passes over disjoint edge sets)
+    fms, bms = float(np.sum(fwd)) / (nprof * len(layers)), float(np.mean(bwd))
     comm = {"rccl_world": world, "layers": len(layers)}
+    per_layer = nprof * len(layers)
     for cname in ("all_gather_qz", "reduce_scatter_dqz"):
         ts = [e0.elapsed_time(e1) for n, e0, e1, _ in crec if n == cname]
         by = [b for n, _, _, b in crec if n == cname]
+        if sg.chunks > 1:                                            # pipelined: one record per chunk -> per-layer sums
+            tc = [e0.elapsed_time(e1) for n, e0, e1, _ in crec if n == cname + "_chunk"]
+            bc = [b for n, _, _, b in crec if n == cname + "_chunk"]
+            ts, by = ([sum(tc) / per_layer] if tc else []), ([sum(bc) / per_layer] if bc else [])
         # the all-gather is started before the P-side GEMM and the relation transforms and waited for after them: its
         # figure is launch-to-arrival on the compute stream, i.e. includes the work it overlaps
         comm[cname + "_ms_per_layer"] = float(np.mean(ts)) if ts else 0.0
@@ -151,31 +158,41 @@ def run_sharded(a, rank, world, device):
                                           "destination-sharded, all-gather of [Q|Z] per layer" % d,
                        "global_entities": n_loc * world, "global_triples": e_total, "parallelism": "dst-shard x%d" % world,
                        "wire": "bf16 [Q|Z] all-gather (flag)" if wire is not None else "fp32",
+                       "exchange": ("slab-pipelined: %d row chunks, chunk c aggregated while c+1 is on the links" % sg.chunks)
+                                   if sg.chunks > 1 else "one-piece all-gather (started before the P projection / relation transforms)",
                        "edges_counted_per_step": 2 * e_total},
             "roofline": {"bound": "hbm", "kernel": "rel_attn_fwd_hw_kernel (half-wave lane map, persistent form; rank 0, local rows)", "achieved": fb / (fms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": fb, "avg_launch_ms": fms, "launches": len(fwd)},
+                         "algorithmic_bytes_per_launch": fb, "avg_launch_ms": fms, "launches": len(fwd),
+                         "launches_per_layer": sg.chunks,
+                         "note": ("avg_launch_ms is the SUM of the %d partial launches of one layer (disjoint edge sets, whole-graph bytes)"
+                                  % sg.chunks) if sg.chunks > 1 else None},
             "roofline_bwd": {"bound": "hbm", "achieved": bb / (bms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": bb / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": bms,
                              "bytes": "SURVEY 8d backward formula"},
             "comm": comm, "rccl_world": world, "cpu_baseline": None}
     if rank == 0:
         line["scaling_model"] = scaling_model(el / a.steps * 1e3, fms, bms, len(layers), n_loc * world, e_total, d, world, strong,
-                                              wire_bytes=2 if wire is not None else 4)
+                                              wire_bytes=2 if wire is not None else 4, chunks=sg.chunks)
     return line
 
 
 XGMI_LINK_GBS, XGMI_EFF = 153.0, 0.8     # one xGMI link per peer pair (MI355X: 7 links x ~153 GB/s per GPU), sustained fraction assumed
 
 
-def scaling_model(step_ms, agg_fwd_ms, agg_bwd_ms, n_layers, n_glob, e_glob, d, world, strong, wire_bytes=4):
+def scaling_model(step_ms, agg_fwd_ms, agg_bwd_ms, n_layers, n_glob, e_glob, d, world, strong, wire_bytes=4, chunks=1):
     """What this run's own measurements predict for 2 / 4 / 8 GPUs -- an explicit model, NOT a measurement (no multi-GPU node has
     run this code).  Per layer and GPU at world W (destination sharding):
       aggregation   = the measured kernel time x (edges per GPU at W / edges per GPU in this run)       (HBM-bound in E)
       other compute = (step - aggregation) of this run x (rows per GPU at W / rows per GPU in this run)  (N-row GEMMs, BN, Adam)
       all-gather    = every peer sends its (N / W) x 2d x wire-bytes slab over ITS OWN link: (N / W) 2d s / (153 GB/s x 0.8)
       reduce-scatter= the same bytes the other way (fp32)
-    no overlap of exchange and compute is assumed beyond what the single-rank step already contains."""
+    no overlap of exchange and compute is assumed beyond what the single-rank step already contains.
+    ``pipelined_step_ms``: the same with the slab-pipelined exchange (--pipeline-chunks C, default shown for C = 4 when the run
+    itself was one-piece): the forward aggregation hides behind the all-gather except for the first chunk's arrival,
+    min(agg_fwd, all-gather x (C-1)/C) per layer, and pays the partial passes' extra traffic, the merge pass and the own-rows
+    copy: 7.5 ms per layer and 1M rows / 20M edges per GPU, MEASURED at one rank (profiles/r4_pipeline.txt: 104.4 -> 119.4 ms per
+    two-layer step); a run that was itself pipelined already contains that cost."""
     agg = n_layers * (agg_fwd_ms + agg_bwd_ms)
     other = max(step_ms - agg, 0.0)
     n_run, e_run = n_glob / world, e_glob / world                     # per GPU in THIS run
@@ -190,8 +207,13 @@ def scaling_model(step_ms, agg_fwd_ms, agg_bwd_ms, n_layers, n_glob, e_glob, d, 
         ag = (slab * wire_bytes) / (XGMI_LINK_GBS * XGMI_EFF * 1e9) * 1e3 if W > 1 else 0.0
         rs = (slab * 4) / (XGMI_LINK_GBS * XGMI_EFF * 1e9) * 1e3 if W > 1 else 0.0
         t = comp + n_layers * (ag + rs)
+        C = chunks if chunks > 1 else 4
+        fwd_w = agg_fwd_ms * (e_w / e_run)                          # forward aggregation per layer at W (of a pipelined run: its partial passes)
+        hidden = min(fwd_w, ag * (C - 1) / C) if W > 1 else 0.0
+        over = 7.5 * (0.5 * n_w / 1e6 + 0.5 * e_w / 2e7) if chunks == 1 else 0.0        # a pipelined run already paid it
+        tp = t - n_layers * (hidden - (over if W > 1 else 0.0))
         out["predicted"][str(W)] = {"step_ms": t, "edges_per_s": n_layers * e_tot / (t * 1e-3), "compute_ms": comp,
-                                    "exchange_ms": n_layers * (ag + rs)}
+                                    "exchange_ms": n_layers * (ag + rs), "pipelined_step_ms": tp, "pipeline_chunks": C}
     base = out["predicted"]["1"]["edges_per_s"]
     for W in ("2", "4", "8"):
         out["predicted"][W]["speedup_vs_1"] = out["predicted"][W]["edges_per_s"] / base

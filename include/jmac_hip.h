@@ -178,13 +178,15 @@ int jmac_rel_attn_aggregate_fwd_bf16_padded(const uint16_t* P, int64_t ldp, cons
  * (jmac_amd/dist.py; the reference has one process and no exchange: modules/helper/message_passing.py:24,28 are the
  * per-destination softmax / sum that make the partials mergeable).  Part c = the forward above on the edges whose SOURCE is
  * in chunk c (loop_rel < 0, out_scale 1): out_c [N,d], its seg_max_c / seg_den_c [N], and the chunk graph's rowptr_c [N+1]
- * (in-degree within the chunk).  Writes nb [N,d] = sqrt(deg) * sum_e softmax(e) x_e over ALL edges and the whole graph's
+ * (in-degree within the chunk).  Writes out [N,d] = out_scale * (nb + self), nb = sqrt(deg) * sum_e softmax(e) x_e over ALL
+ * edges, self = Zself[i] - rz_loop (the fused self loop, src/jmac_model.py:49-50; Zself NULL: none), and the whole graph's
  * seg_max / seg_den (what jmac_rel_attn_aggregate_bwd_f32 on the whole graph expects).  h_* are HOST arrays of n_parts
  * device pointers (n_parts <= JMAC_MERGE_MAX_PARTS); parts are combined in index order (bitwise reproducible). */
 #define JMAC_MERGE_MAX_PARTS 16
 int jmac_softmax_parts_merge_f32(const float* const* h_out, int64_t ldo, const float* const* h_seg_max,
                                  const float* const* h_seg_den, const int32_t* const* h_rowptr, int32_t n_parts,
-                                 int64_t N, int64_t d, float* nb, int64_t ldn, float* seg_max, float* seg_den,
+                                 int64_t N, int64_t d, const float* Zself, int64_t ldz, const float* rz_loop,
+                                 float out_scale, float* out, int64_t ldo2, float* seg_max, float* seg_den,
                                  jmac_stream_t stream);
 
 /* Backward of the op above (replaces autograd through the same reference lines).

@@ -64,7 +64,7 @@ _SIGS = {
                                                    i64, i64, f32, i32, i64, f32, vp, i64, vp, vp, vp, sz, vp]),
     "jmac_rel_attn_aggregate_fwd_bf16_padded": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, vp, vp, vp, C.POINTER(View),
                                                           i64, i64, f32, i32, i64, f32, vp, i64, vp, vp, vp, sz, vp]),
-    "jmac_softmax_parts_merge_f32": (C.c_int, [vp, i64, vp, vp, vp, i32, i64, i64, vp, i64, vp, vp, vp]),
+    "jmac_softmax_parts_merge_f32": (C.c_int, [vp, i64, vp, vp, vp, i32, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, vp]),
     "jmac_rel_attn_bwd_workspace_bytes": (sz, [i64, i64, i64, i64, i64, i64, i64, i32]),
     "jmac_rel_attn_aggregate_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp,
                                                   C.POINTER(View), C.POINTER(View), C.POINTER(View),

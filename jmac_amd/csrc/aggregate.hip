@@ -1852,7 +1852,8 @@ int jmac_rel_attn_aggregate_fwd_bf16_padded(const uint16_t* P, int64_t ldp, cons
 // Part c is the forward above run on the edges whose SOURCE lies in chunk c (no self loop, out_scale 1): out_c[i] =
 // sqrt(deg_c) * sum_e softmax_c(e) x_e with the chunk's own (max m_c, denominator l_c).  Over all edges of destination i:
 //   M = max_c m_c,  L = sum_c exp(m_c - M) l_c,  nb[i] = sqrt(deg) * sum_c (exp(m_c - M) l_c / L) * out_c[i] / sqrt(deg_c)
-// (M, L) are what the backward of the whole graph expects as seg_max / seg_den.
+// (M, L) are what the backward of the whole graph expects as seg_max / seg_den.  With a self table the layer's fused epilogue
+// is applied here: out[i] = out_scale * (nb[i] + Zself[i] - rz_loop)  (src/jmac_model.py:49-50), else out_scale * nb[i].
 struct MergeArgs {
     const float* out[JMAC_MERGE_MAX_PARTS];
     const float* smax[JMAC_MERGE_MAX_PARTS];
@@ -1864,6 +1865,10 @@ struct MergeArgs {
     float* nb;
     float* seg_max;
     float* seg_den;
+    const float* zself;
+    const float* rz_loop;
+    int64_t ldz;
+    float out_scale;
 };
 
 __global__ __launch_bounds__(kBlock) void softmax_parts_merge_kernel(MergeArgs a) {
@@ -1902,7 +1907,8 @@ __global__ __launch_bounds__(kBlock) void softmax_parts_merge_kernel(MergeArgs a
 #pragma unroll
         for (int c = 0; c < JMAC_MERGE_MAX_PARTS; ++c)
             if (c < a.n_parts && deg[c] > 0) acc = fma4(ld4(a.out[c] + i * a.ldo + 4 * q), f[c], acc);
-        st4(a.nb + i * a.ldn + 4 * q, acc);
+        if (a.zself) acc = add4(acc, sub4(ld4(a.zself + i * a.ldz + 4 * q), ld4(a.rz_loop + 4 * q)));
+        st4(a.nb + i * a.ldn + 4 * q, mul4(acc, a.out_scale));
     }
     if (lane == 0) {
         a.seg_max[i] = dtot > 0 ? M : -INFINITY;
@@ -1911,10 +1917,12 @@ __global__ __launch_bounds__(kBlock) void softmax_parts_merge_kernel(MergeArgs a
 }
 
 int jmac_softmax_parts_merge_f32(const float* const* h_out, int64_t ldo, const float* const* h_seg_max, const float* const* h_seg_den,
-                                 const int32_t* const* h_rowptr, int32_t n_parts, int64_t N, int64_t d, float* nb, int64_t ldn,
-                                 float* seg_max, float* seg_den, jmac_stream_t stream) {
+                                 const int32_t* const* h_rowptr, int32_t n_parts, int64_t N, int64_t d, const float* Zself,
+                                 int64_t ldz, const float* rz_loop, float out_scale, float* nb, int64_t ldn, float* seg_max,
+                                 float* seg_den, jmac_stream_t stream) {
     if (n_parts < 0 || n_parts > JMAC_MERGE_MAX_PARTS) return JMAC_EINVAL;
     if (d <= 0 || d % 4 || ldo % 4 || ldn % 4 || d > ldo || d > ldn) return JMAC_EDIM;
+    if (Zself && (!rz_loop || ldz % 4 || d > ldz)) return JMAC_EINVAL;
     if (N < 0 || (N > 0 && (!nb || !seg_max || !seg_den)) || (n_parts > 0 && (!h_out || !h_seg_max || !h_seg_den || !h_rowptr)))
         return JMAC_EINVAL;
     if (N == 0) return JMAC_OK;
@@ -1934,6 +1942,10 @@ int jmac_softmax_parts_merge_f32(const float* const* h_out, int64_t ldo, const f
     a.nb = nb;
     a.seg_max = seg_max;
     a.seg_den = seg_den;
+    a.zself = Zself;
+    a.rz_loop = rz_loop;
+    a.ldz = ldz;
+    a.out_scale = out_scale;
     hipLaunchKernelGGL(softmax_parts_merge_kernel, dim3((unsigned)((N + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
                        (hipStream_t)stream, a);
     return (int)hipGetLastError();

@@ -56,7 +56,9 @@ class ShardedGraph:
     [cb[c], cb[c+1]); the table is laid out CHUNK-major -- position = world * cb[c] + owner * rows_c + (local - cb[c]) --
     so that the all-gather of chunk c (every rank contributes its rows of that range: all xGMI links busy, like the
     one-piece all-gather) fills ONE contiguous slice of the table, and the rank's edges are split by the chunk of their
-    SOURCE into ``chunks`` sub-graphs over the same destinations (``chunk_graph``)."""
+    SOURCE into ``chunks`` sub-graphs over the same destinations (``chunk_graph``).  The rank's OWN rows are not contiguous in
+    that layout, so the table carries a copy of them behind the gathered part (rows [world*n_max, (world+1)*n_max):
+    ``self_off``) for the fused self loop of the backward kernel."""
 
     def __init__(self, edge_index: np.ndarray, edge_type: np.ndarray, bounds: Sequence[int], rank: int,
                  already_local: bool = False, chunks: int = 1):
@@ -85,6 +87,10 @@ class ShardedGraph:
             self.src_padded = (self.world * cb[ch] + owner * (cb[ch + 1] - cb[ch]) + (local - cb[ch])).astype(np.int64)
         self.edge_type = np.asarray(edge_type).astype(np.int64)
         self.E_local = int(self.dst_local.shape[0])
+        self._chunk_edges = np.bincount(self.src_chunk, minlength=self.chunks)
+        # rows of the table the kernels index / where the rank's own rows sit in it
+        self.table_rows = self.world * self.n_max + (self.n_max if self.chunks > 1 else 0)
+        self.self_off = self.world * self.n_max if self.chunks > 1 else self.rank * self.n_max
         self._rel_graph = None
         self._chunk_graphs: dict = {}
 
@@ -97,14 +103,14 @@ class ShardedGraph:
         return torch.from_numpy(np.stack([d, s])).to(device), torch.from_numpy(t).to(device)
 
     def chunk_edges(self, chunk: int) -> int:
-        return int((self.src_chunk == chunk).sum())
+        return int(self._chunk_edges[chunk])
 
     def rel_graph(self, device, num_rel: int):
         """CSR + schedules on the HIP device (cached)."""
         if self._rel_graph is None:
             from .graph import RelGraph
             ei, et = self.coo(device)
-            self._rel_graph = RelGraph(ei, et, self.n_local, num_rel, None, num_src=self.world * self.n_max)
+            self._rel_graph = RelGraph(ei, et, self.n_local, num_rel, None, num_src=self.table_rows)
         return self._rel_graph
 
     def chunk_graph(self, chunk: int, device, num_rel: int):
@@ -112,7 +118,7 @@ class ShardedGraph:
         if chunk not in self._chunk_graphs:
             from .graph import RelGraph
             ei, et = self.coo(device, chunk)
-            self._chunk_graphs[chunk] = RelGraph(ei, et, self.n_local, num_rel, None, num_src=self.world * self.n_max)
+            self._chunk_graphs[chunk] = RelGraph(ei, et, self.n_local, num_rel, None, num_src=self.table_rows)
         return self._chunk_graphs[chunk]
 
 
@@ -446,15 +452,15 @@ class _HipChunked:
         return out, m, l, g.rowptr
 
     @staticmethod
-    def merge(parts, n: int, d: int, device):
+    def merge(parts, n: int, d: int, device, zself, rz_loop, out_scale: float):
         from . import ops
-        return ops.softmax_parts_merge(parts, n, d, device)
+        return ops.softmax_parts_merge(parts, n, d, device, zself, rz_loop, out_scale)
 
     @staticmethod
-    def backward(P, table, RR, a, sg: "ShardedGraph", slope: float, nb, seg_max, seg_den, G):
+    def backward(P, table, RR, a, sg: "ShardedGraph", slope: float, pre, seg_max, seg_den, G):
         from . import ops
-        return ops.rel_attn_split_bwd_raw(P, table, RR, a, sg.rel_graph(P.device, RR.shape[0]), slope, 1.0, -1, 0, nb, seg_max,
-                                          seg_den, G)
+        return ops.rel_attn_split_bwd_raw(P, table, RR, a, sg.rel_graph(P.device, RR.shape[0]), slope, 0.5, RR.shape[0] - 1,
+                                          sg.self_off, pre, seg_max, seg_den, G)
 
 
 class _ChunkedAllGather(torch.autograd.Function):
@@ -474,9 +480,11 @@ class _ChunkedAllGather(torch.autograd.Function):
             raise ValueError("the rank's table must be padded to n_max rows")
         works = [None] * sg.chunks
         _ChunkedAllGather.pending = works
+        table = torch.empty((sg.table_rows,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        table[world * sg.n_max:].copy_(x)                    # the rank's own rows once more, contiguous (fused self loop)
         if _skip(group):
-            return x.clone()                                 # one rank: the chunk-major table is the input
-        table = torch.empty((world * sg.n_max,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            table[:sg.n_max].copy_(x)                        # one rank: the chunk-major table is the input
+            return table
         gloo = dist.get_backend(group) == "gloo"
         for c in range(sg.chunks):                           # every chunk's collective is queued now, in order
             dst, src = table[world * cb[c]:world * cb[c + 1]], x[cb[c]:cb[c + 1]]
@@ -507,9 +515,10 @@ class _ChunkedAllGather(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         sg, group = ctx.sg, ctx.group
-        if _skip(group):
-            return g, None, None
         world = _world(group)
+        own = g[world * sg.n_max:]                           # gradient of the own-rows copy (the self loop's dZ)
+        if _skip(group):
+            return g[:sg.n_max] + own, None, None
         cb = sg.chunk_bounds
         g = g.contiguous()
         out = torch.empty((sg.n_max,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
@@ -528,15 +537,17 @@ class _ChunkedAllGather(torch.autograd.Function):
                 e0 = _cev(gc)
                 dist.reduce_scatter_tensor(out[cb[c]:cb[c + 1]], gc, group=group)
                 _cdone("reduce_scatter_dqz_chunk", e0, gc)
+        out += own
         return out, None, None
 
 
 class _ChunkedAggregate(torch.autograd.Function):
-    """nb[i] = sqrt(deg_i) * sum_e alpha_e (Z[j] - Rz[t]) over the rank's rows from a table whose chunks are still arriving:
-    the compute stream waits for chunk c only, aggregates the sub-graph of sources in chunk c into a partial (out_c, max_c,
-    den_c) and goes on to c+1 while that chunk is on the links; one merge pass combines the partials per destination
-    (jmac_softmax_parts_merge_f32) and yields the whole graph's (max, den) -- so the BACKWARD is the ordinary one on the whole
-    graph and the whole table.  Price: ``chunks`` partial [n, d] outputs written and read once more (the merge)."""
+    """pre[i] = (sqrt(deg_i) * sum_e alpha_e (Z[j] - Rz[t]) + Z[i] - Rz[loop]) / 2 over the rank's rows from a table whose chunks
+    are still arriving: the compute stream waits for chunk c only, aggregates the sub-graph of sources in chunk c into a partial
+    (out_c, max_c, den_c) and goes on to c+1 while that chunk is on the links; one merge pass combines the partials per
+    destination, adds the self loop and halves (jmac_softmax_parts_merge_f32), and yields the whole graph's (max, den) -- so the
+    BACKWARD is the ordinary fused one on the whole graph and the whole table.  Price: ``chunks`` partial [n, d] outputs written
+    and read once more (the merge)."""
 
     @staticmethod
     def forward(ctx, P, table, RR, a, sg: ShardedGraph, slope: float, kernels):
@@ -548,15 +559,16 @@ class _ChunkedAggregate(torch.autograd.Function):
             if n > 0 and sg.chunk_edges(c) > 0:
                 parts.append(kernels.partial(P, table, RR, a, sg, c, slope))
         _ChunkedAllGather.pending = None
-        nb, seg_max, seg_den = kernels.merge(parts, n, d, P.device)
-        ctx.save_for_backward(P, table, RR, a, nb, seg_max, seg_den)
+        zself = table[sg.self_off:sg.self_off + n, d:]
+        pre, seg_max, seg_den = kernels.merge(parts, n, d, P.device, zself, RR[-1, d:].contiguous(), 0.5)
+        ctx.save_for_backward(P, table, RR, a, pre, seg_max, seg_den)
         ctx.sg, ctx.slope, ctx.kernels = sg, slope, kernels
-        return nb
+        return pre
 
     @staticmethod
     def backward(ctx, G):
-        P, table, RR, a, nb, seg_max, seg_den = ctx.saved_tensors
-        dP, dT, dRR, da = ctx.kernels.backward(P, table, RR, a, ctx.sg, ctx.slope, nb, seg_max, seg_den, G.contiguous())
+        P, table, RR, a, pre, seg_max, seg_den = ctx.saved_tensors
+        dP, dT, dRR, da = ctx.kernels.backward(P, table, RR, a, ctx.sg, ctx.slope, pre, seg_max, seg_den, G.contiguous())
         return dP, dT, dRR, da, None, None, None
 
 
@@ -629,7 +641,7 @@ class ShardedRelationAwareLayer(nn.Module):
         slope = L.atv_mlp.negative_slope
         if sg.chunks > 1:
             # slab-pipelined exchange: the table crosses in sg.chunks row chunks, chunk c is aggregated while c+1 is on the
-            # links (_ChunkedGatherAggregate); the self term and the /2 are then separate (own Z rows: no exchange)
+            # links (_ChunkedAllGather + _ChunkedAggregate)
             if self.wire_dtype is not None and self.wire_dtype != QZ_loc.dtype:
                 raise NotImplementedError("the pipelined exchange carries the fp32 wire only")
             table = chunked_all_gather(QZ_loc, sg, self.group)       # all chunks queued; nothing waits yet
@@ -637,8 +649,7 @@ class ShardedRelationAwareLayer(nn.Module):
             rel = L.transform_relations(rel_emb)
             RR = L._rel_mm(rel, wqz)
             a = L.a_att.reshape(-1).float()
-            nb = chunked_aggregate(P, table, RR, a, sg, slope, self.chunk_kernels)
-            pre = (nb + Z_loc - RR[-1, d:]) * 0.5
+            pre = chunked_aggregate(P, table, RR, a, sg, slope, self.chunk_kernels)     # self loop and /2 fused in the merge
             if L.layer_act is torch.tanh and (self.chunk_kernels is None or self.bn_kernels is not None):
                 return sync_bn_tanh(pre, L.bn, sg.n_global, self.group, self.bn_kernels)
             return L.layer_act(sync_batch_norm(pre, sg.n_global, L.bn, self.group))

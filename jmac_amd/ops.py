@@ -216,12 +216,13 @@ def rel_attn_split_bwd_raw(P, QZ, RR, a, graph: RelGraph, slope: float, out_scal
     return dP, dQZ, dRR, da
 
 
-def softmax_parts_merge(parts, N: int, d: int, device):
+def softmax_parts_merge(parts, N: int, d: int, device, zself=None, rz_loop=None, out_scale: float = 1.0):
     """jmac_softmax_parts_merge_f32: parts = [(out_c [N,d], seg_max_c [N], seg_den_c [N], rowptr_c [N+1] int32), ...] of the
-    same destinations over disjoint edge sets -> (nb [N,d], seg_max [N], seg_den [N]) of their union."""
+    same destinations over disjoint edge sets -> (out [N,d], seg_max [N], seg_den [N]) of their union; out = out_scale * (nb +
+    zself[i] - rz_loop) with a self table (zself: [N, d] rows with any 4-aligned stride, rz_loop [d]), else out_scale * nb."""
     L = lib()
     n = len(parts)
-    nb = torch.empty((N, d), dtype=torch.float32, device=device)
+    out = torch.empty((N, d), dtype=torch.float32, device=device)
     seg_max = torch.empty(max(N, 1), dtype=torch.float32, device=device)
     seg_den = torch.empty(max(N, 1), dtype=torch.float32, device=device)
     arr = lambda k: (C.c_void_p * max(n, 1))(*[ptr(p[k]) for p in parts])
@@ -229,13 +230,21 @@ def softmax_parts_merge(parts, N: int, d: int, device):
         require_device(o, m, l, rp)
         if o.shape != (N, d) or not o.is_contiguous() or rp.dtype != torch.int32 or rp.numel() != N + 1:
             raise ValueError("softmax_parts_merge: part shapes disagree")
-    check(L.jmac_softmax_parts_merge_f32(arr(0), d, arr(1), arr(2), arr(3), n, N, d, ptr(nb), d, ptr(seg_max), ptr(seg_den),
-                                         stream()), "jmac_softmax_parts_merge_f32")
+    if zself is not None:
+        require_device(zself, rz_loop)
+        if zself.shape != (N, d) or zself.stride(1) != 1 or rz_loop.numel() != d or not rz_loop.is_contiguous():
+            raise ValueError("softmax_parts_merge: self table shapes disagree")
     if n == 0:                       # no edges at all: the kernel is not given anything to read
-        nb.zero_()
         seg_max.fill_(float("-inf"))
         seg_den.zero_()
-    return nb, seg_max, seg_den
+        if zself is None or N == 0:
+            out.zero_()
+            return out, seg_max, seg_den
+    check(L.jmac_softmax_parts_merge_f32(arr(0), d, arr(1), arr(2), arr(3), n, N, d,
+                                         ptr(zself) if zself is not None else None, zself.stride(0) if zself is not None else 0,
+                                         ptr(rz_loop) if zself is not None else None, float(out_scale), ptr(out), d, ptr(seg_max),
+                                         ptr(seg_den), stream()), "jmac_softmax_parts_merge_f32")
+    return out, seg_max, seg_den
 
 
 class _RelAttnAggregateSplit(torch.autograd.Function):

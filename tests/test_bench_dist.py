@@ -34,3 +34,8 @@ def test_scaling_model_is_consistent():
     assert abs(q8["compute_ms"] - 110.0 / 8) < 1e-9                                                      # strong: 1/8 of the rows and edges
     assert abs(q8["exchange_ms"] - 2 * 2 * (250_000 * 600 * 4 / (153e9 * 0.8) * 1e3)) < 1e-9
     assert s["predicted"]["2"]["speedup_vs_1"] < 2 and q8["speedup_vs_1"] < 8
+    # the pipelined figure hides min(forward aggregation, all-gather x 3/4) per layer and pays the merge pass; nothing at one rank
+    assert abs(p1["pipelined_step_ms"] - p1["step_ms"]) < 1e-9 and p8["pipeline_chunks"] == 4
+    over_ms = 7.5                                                   # measured cost per layer at 1M rows / 20M edges per GPU
+    assert abs((p8["step_ms"] - p8["pipelined_step_ms"]) - 2 * (min(10.5, slab_ms * 0.75) - over_ms)) < 1e-9
+    assert p8["pipelined_step_ms"] < p8["step_ms"]

@@ -64,9 +64,10 @@ class _StandinChunked:
         return out, m, l, rowptr
 
     @staticmethod
-    def merge(parts, n, d, device):
+    def merge(parts, n, d, device, zself, rz_loop, out_scale):
+        self_term = (zself - rz_loop) if zself is not None else torch.zeros(n, d)
         if not parts or n == 0:
-            return torch.zeros(n, d), torch.full((max(n, 1),), float("-inf")), torch.zeros(max(n, 1))
+            return out_scale * self_term, torch.full((max(n, 1),), float("-inf")), torch.zeros(max(n, 1))
         deg = torch.stack([(rp[1:] - rp[:-1]).float() for _, _, _, rp in parts])                 # [C, n]
         m = torch.stack([p[1] for p in parts])
         l = torch.stack([p[2] for p in parts])
@@ -75,15 +76,17 @@ class _StandinChunked:
         L = f.sum(0)
         w = torch.where((deg > 0) & (L > 0), f / L.clamp_min(1e-30) * (deg.sum(0).sqrt() / deg.clamp_min(1).sqrt()), torch.zeros_like(f))
         nb = sum(w[c].view(-1, 1) * parts[c][0] for c in range(len(parts)))
-        return nb, M, L
+        return out_scale * (nb + self_term), M, L
 
     @staticmethod
-    def backward(P, table, RR, a, sg, slope, nb, seg_max, seg_den, G):
+    def backward(P, table, RR, a, sg, slope, pre, seg_max, seg_den, G):
+        d = P.shape[1]
         with torch.enable_grad():
             xs = [t.detach().clone().requires_grad_(True) for t in (P, table, RR, a)]
-            out = _standin_aggregate(*xs, sg, slope)
-            # the merged forward result must BE the whole-graph aggregate (this is what the HIP backward is handed as ``out``)
-            assert torch.allclose(out.detach(), nb, atol=2e-5), float((out.detach() - nb).abs().max())
+            nb = _standin_aggregate(*xs, sg, slope)
+            out = (nb + xs[1][sg.self_off:sg.self_off + sg.n_local, d:] - xs[2][-1, d:]) * 0.5
+            # the merged forward result must BE the whole-graph layer pre-activation (what the HIP backward is handed as ``out``)
+            assert torch.allclose(out.detach(), pre, atol=2e-5), float((out.detach() - pre).abs().max())
             return torch.autograd.grad(out, xs, G)
 
 

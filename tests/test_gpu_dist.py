@@ -179,6 +179,13 @@ def test_parts_merge_equals_whole_graph_forward():
     assert_close(nb.cpu(), want.cpu().double(), 1e-5, 1e-6, "merged output")
     assert torch.equal(M[has], wm[has]) and bool((M[~has] == float("-inf")).all())
     assert_close(L[has].cpu(), wl[has].cpu().double(), 1e-5, 1e-7, "merged denominator")
+    # with the self table: the layer's fused epilogue out_scale * (nb + Z[i] - Rz[loop]) = the forward kernel's own fused form
+    fused, _, _ = ops.rel_attn_split_fwd_raw(P, QZ, RR, a, whole, 0.05, 0.5, nr, 0)
+    pre, M2, L2 = ops.softmax_parts_merge(parts, n, d, dev, QZ[:, d:], RR[-1, d:].contiguous(), 0.5)
+    assert_close(pre.cpu(), fused.cpu().double(), 1e-5, 1e-6, "merged fused output")
+    assert torch.equal(M2, M) and torch.equal(L2, L)
+    only_self, _, _ = ops.softmax_parts_merge([], n, d, dev, QZ[:, d:], RR[-1, d:].contiguous(), 0.5)
+    assert_close(only_self.cpu(), (0.5 * (QZ[:, d:] - RR[-1, d:])).cpu().double(), 1e-6, 1e-7, "self term alone")
     nb0, M0, L0 = ops.softmax_parts_merge([], n, d, dev)              # no part at all: zeros / -inf / 0
     assert float(nb0.abs().max()) == 0.0 and bool((M0 == float("-inf")).all()) and float(L0.abs().max()) == 0.0
 
