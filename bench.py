@@ -1466,7 +1466,8 @@ def main():
             sa = argparse.Namespace(**vars(a))
             sa.steps, sa.warmup = 5, 2
             sl = run_sharded(sa, 0, 1, device)
-            line["sharded"] = {k: sl[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "roofline_bwd", "comm")}
+            line["sharded"] = {k: sl[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "roofline_bwd", "comm",
+                                                  "scaling_model", "scaling_model_strong_10x") if k in sl}
         except Exception as ex:                      # pragma: no cover
             line["sharded"] = {"error": str(ex)}
     emit(line)

@@ -174,13 +174,23 @@ def run_sharded(a, rank, world, device):
     if rank == 0:
         line["scaling_model"] = scaling_model(el / a.steps * 1e3, fms, bms, len(layers), n_loc * world, e_total, d, world, strong,
                                               wire_bytes=2 if wire is not None else 4, chunks=sg.chunks)
+        if not strong:
+            # north_star's 8-GPU configuration (a 10x graph, strong-scaled: 2M entities / 200M triples) from THIS run's per-row and
+            # per-edge rates -- the graph itself is run by `--scaling strong --synth-scale 10`
+            m = scaling_model(el / a.steps * 1e3, fms, bms, len(layers), 2_000_000, 200_000_000, d, 1, True,
+                              wire_bytes=2 if wire is not None else 4, chunks=sg.chunks, run_rows=n_loc, run_edges=e_loc)
+            m["assumptions"]["kind"] = ("strong, 2M entities / 200M triples; extrapolated from the measured per-row / per-edge rates of "
+                                        "this run's %d-entity / %d-triple rank" % (n_loc, e_loc))
+            del m["measured_here"]
+            line["scaling_model_strong_10x"] = m
     return line
 
 
 XGMI_LINK_GBS, XGMI_EFF = 153.0, 0.8     # one xGMI link per peer pair (MI355X: 7 links x ~153 GB/s per GPU), sustained fraction assumed
 
 
-def scaling_model(step_ms, agg_fwd_ms, agg_bwd_ms, n_layers, n_glob, e_glob, d, world, strong, wire_bytes=4, chunks=1):
+def scaling_model(step_ms, agg_fwd_ms, agg_bwd_ms, n_layers, n_glob, e_glob, d, world, strong, wire_bytes=4, chunks=1,
+                  run_rows=None, run_edges=None):
     """What this run's own measurements predict for 2 / 4 / 8 GPUs -- an explicit model, NOT a measurement (no multi-GPU node has
     run this code).  Per layer and GPU at world W (destination sharding):
       aggregation   = the measured kernel time x (edges per GPU at W / edges per GPU in this run)       (HBM-bound in E)
@@ -195,7 +205,9 @@ def scaling_model(step_ms, agg_fwd_ms, agg_bwd_ms, n_layers, n_glob, e_glob, d, 
     two-layer step); a run that was itself pipelined already contains that cost."""
     agg = n_layers * (agg_fwd_ms + agg_bwd_ms)
     other = max(step_ms - agg, 0.0)
-    n_run, e_run = n_glob / world, e_glob / world                     # per GPU in THIS run
+    # per GPU in THIS run (run_rows / run_edges: the measured run was a DIFFERENT graph -- its per-row and per-edge rates are
+    # carried over to (n_glob, e_glob))
+    n_run, e_run = (run_rows or n_glob / world), (run_edges or e_glob / world)
     out = {"assumptions": {"xgmi_link_GBps": XGMI_LINK_GBS, "sustained_fraction": XGMI_EFF, "overlap": "none beyond the measured step",
                            "wire_bytes_per_element": wire_bytes, "kind": "strong" if strong else "weak"},
            "measured_here": {"world": world, "step_ms": step_ms, "aggregation_ms": agg, "other_ms": other}, "predicted": {}}
