@@ -1332,6 +1332,9 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a, int
     }
     const bool has_loop = a.loop_rel >= 0;
     const float* rloop = a.RR + (int64_t)(has_loop ? a.loop_rel : 0) * a.ldrr;
+    float4 rl[NCH];                                    // the loop relation's [Rq|Rz] chunks: the same for every destination
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) rl[k] = L.any_v(k) ? ld4(rloop + L.coffc[k]) : f4zero();
 
     // the first header (and the item's first two entries) at a clamped index: they do not wait for the device-side count
     const int it0 = blockIdx.x * kWavesPerBlock + wave;
@@ -1369,30 +1372,44 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a, int
         float4 pv[NCH_H], gv[NCH], accP[NCH_H];
         float tpart = 0.f;
         const float* prow = a.P + (int64_t)i * a.ldp;
-        const float* zrow = a.QZ + ((int64_t)i + a.self_off) * a.ldqz;
+        const float* zrow = has_loop ? a.QZ + ((int64_t)i + a.self_off) * a.ldqz : prow;      // (no loop: any valid row, unused)
         const float* grow = a.G + (int64_t)i * a.ldg;
         const float* orow = a.out + (int64_t)i * a.ldo;
+        // EVERY load of the destination's own data goes out before the first use: written chunk by chunk (load G, out; then,
+        // behind `if (has_loop)`, Z and Rz[loop]; then the scalars behind the wave sum) the compiler kept that order and the
+        // item paid five dependent round trips here instead of one (seen in the ISA: vmcnt(1) / vmcnt(0) pairs per chunk)
+        float4 graw[NCH], oraw[NCH], zraw[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH_H; ++k) pv[k] = ld4(prow + (L.is_h[k] ? L.coff[k] : 0));
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (!L.any_v(k)) continue;
+            const int vo = L.is_v(k) ? L.coff[k] - voff : 0;
+            graw[k] = ld4(grow + vo);
+            oraw[k] = ld4(orow + vo);
+            zraw[k] = ld4(zrow + (has_loop ? L.coffc[k] : 0));
+        }
+        const float m_i = a.seg_max[i];
+        const float l_i = a.seg_den[i];
+        const int rp0 = a.rowptr[i], rp1 = a.rowptr[i + 1];
 #pragma unroll
         for (int k = 0; k < NCH_H; ++k) {
-            pv[k] = sel4(L.is_h[k], ld4(prow + (L.is_h[k] ? L.coff[k] : 0)));
+            pv[k] = sel4(L.is_h[k], pv[k]);
             accP[k] = f4zero();
         }
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             gv[k] = f4zero();
             if (!L.any_v(k)) continue;
-            const int vo = L.is_v(k) ? L.coff[k] - voff : 0;
-            const float4 g = mul4(ld4(grow + vo), kappa);
-            float4 nbv = mul4(ld4(orow + vo), inv_kappa);          // nb_i = out/kappa - (Z[i] - Rz[loop])
-            if (has_loop) nbv = sub4(nbv, sub4(ld4(zrow + L.coffc[k]), ld4(rloop + L.coffc[k])));
+            const float4 g = mul4(graw[k], kappa);
+            float4 nbv = mul4(oraw[k], inv_kappa);                 // nb_i = out/kappa - (Z[i] - Rz[loop])
+            if (has_loop) nbv = sub4(nbv, sub4(zraw[k], rl[k]));
             gv[k] = sel4(L.is_v(k), g);
             tpart += dot4(gv[k], nbv);
         }
         const float t_i = wave_sum(tpart);
-        const float m_i = a.seg_max[i];
-        const float l_i = a.seg_den[i];
         const float inv_l = l_i > 0.f ? 1.f / l_i : 0.f;
-        const float c_i = sqrtf((float)(a.rowptr[i + 1] - a.rowptr[i]));
+        const float c_i = sqrtf((float)(rp1 - rp0));
 
         for (int e0 = item.beg; e0 < item.end; e0 += 64) {
             const int nb = min(64, item.end - e0);
