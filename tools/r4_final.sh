@@ -6,4 +6,4 @@ python3 tools/pmc_profiles_r4.py gpurun_out/pmc_r4
 bash tools/r4_check.sh
 bash tools/step_profile2.sh gpurun_out/r4_step_ja --ja
 bash tools/step_profile2.sh gpurun_out/r4_step_pair --batched 1
-cp profiles/r4_pmc_*.json gpurun_out/
+cp profiles/r4_pmc_*.json gpurun_out/      # (written on the GPU box: copy them back into profiles/ in the tree afterwards)
