@@ -110,7 +110,7 @@ def parse():
                          "PER GPU; strong = ONE global graph of 200k entities / 20M triples x synth-scale (north_star's 8-GPU "
                          "configuration: --scaling strong --synth-scale 10 = 2M / 200M), the same graph at every N")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of the first pass")
-    ap.add_argument("--pipeline-chunks", type=int, default=0,
+    ap.add_argument("--pipeline-chunks", type=int, default=0, choices=range(0, 17), metavar="0..16",
                     help="sharded workload: cut the [Q|Z] exchange into this many row chunks and aggregate chunk c while chunk c+1 is "
                          "on the links (jmac_amd.dist slab-pipelined exchange); 0 = one-piece all-gather (default)")
     ap.add_argument("--wire-bf16", action="store_true",
@@ -1138,6 +1138,62 @@ def synth_cpu_layer(scale, d):
                       "cost is size-independent, so the 20M-edge figure is this rate (linear extrapolation)" % (scale, n, e)}
 
 
+def synth_parity(a, device, tol=1e-4):
+    """The kernels ``synth`` times are the PERSISTENT-GRID forms (more than 65 536 by-destination items, no inline entries:
+    aggregate.hip launch_rel_attn_fwd); before they are timed the same forms run on a down-scale of config 4 that still selects
+    them (80 000 entities / 1 M triples / 1 k relations, same generator) and are held to the oracle in float64
+    (oracle.aggregate_from_tables_sliced: message_passing.py:24-28 on the tables of jmac_model.py:75-88): forward on fp32 tables,
+    forward on the padded bf16 tables (oracle on the same rounded tables), and every gradient of the deterministic backward on the
+    GPU's own side of the LeakyReLU kinks (counted).  tests/test_gpu_persistent_oracle.py is the full version."""
+    import oracle.jmac_oracle as orc
+    from jmac_amd import ops, synth
+    from jmac_amd.graph import RelGraph
+    d = a.dim
+    ei, et, n, nrel = synth.power_law_graph(80_000, 1_000_000, 1000, seed=4321)
+    e = ei.shape[1]
+    eit, ett = torch.from_numpy(ei), torch.from_numpy(et)
+    g = RelGraph(eit.to(device), ett.to(device), n, nrel)
+    persistent = g.by_dst.n_items_max > 65536 and g.by_dst.item_edges is None
+    gen = torch.Generator().manual_seed(11)
+    PQZ, RR = torch.randn(n, 3 * d, generator=gen) * 0.3, torch.randn(nrel, 2 * d, generator=gen) * 0.3
+    av, G = torch.randn(d, generator=gen) * 0.1, torch.randn(n, d, generator=gen)
+    Pg, Rg, ag = (t.to(device).requires_grad_(True) for t in (PQZ, RR, av))
+    out = ops.rel_attn_aggregate(Pg, Rg, ag, g, 0.05, nrel - 1, 0.5, bwd_mode=a.bwd_mode)
+    out.backward(G.to(device))
+    with torch.no_grad():
+        P16, R16 = ops.pad_table(Pg.detach().to(torch.bfloat16), d, 3), ops.pad_table(Rg.detach().to(torch.bfloat16), d, 2)
+        o16 = ops.rel_attn_aggregate(P16, R16, ag.detach(), g, 0.05, nrel - 1, 0.5)
+        mask = torch.empty((e, d), dtype=torch.bool)
+        dst, src, typ = eit[0].to(device), eit[1].to(device), ett.to(device)
+        for lo in range(0, e, 100_000):                  # the kernel's own h_e = P[i] + (Q[j] - Rq[t]) from the same fp32 tables
+            sl = slice(lo, min(lo + 100_000, e))
+            mask[sl] = ((Pg[dst[sl], :d] + (Pg[src[sl], d:2 * d] - Rg[typ[sl], :d])) > 0).cpu()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    P64, R64 = PQZ.double(), RR.double()
+    flips = 0
+    for lo in range(0, e, 100_000):
+        sl = slice(lo, min(lo + 100_000, e))
+        flips += int((((P64[eit[0, sl], :d] + P64[eit[1, sl], d:2 * d] - R64[ett[sl], :d]) > 0) != mask[sl]).sum())
+    o64, (gP, gR, ga) = orc.aggregate_from_tables_sliced(PQZ, RR, av, eit, ett, 0.05, nrel - 1, 0.5, torch.float64, G, mask)
+    o64b = orc.aggregate_from_tables_sliced(PQZ.to(torch.bfloat16).double(), RR.to(torch.bfloat16).double(), av, eit, ett, 0.05,
+                                            nrel - 1, 0.5, torch.float64)
+    cpu_s = time.perf_counter() - t0
+
+    def rel(x, y):
+        x, y = x.detach().double().cpu(), y.double()
+        return float((x - y).abs().max()) / max(float(y.abs().max()), 1e-30)
+    errs = {"fwd_f32_tables": rel(out, o64), "fwd_bf16_tables": rel(o16, o64b), "dP": rel(Pg.grad[:, :d], gP[:, :d]),
+            "dQ": rel(Pg.grad[:, d:2 * d], gP[:, d:2 * d]), "dZ": rel(Pg.grad[:, 2 * d:], gP[:, 2 * d:]),
+            "dRq": rel(Rg.grad[:, :d], gR[:, :d]), "dRz": rel(Rg.grad[:, d:], gR[:, d:]), "da": rel(ag.grad, ga)}
+    return {"ok": bool(persistent and flips <= 64 and all(v <= tol for v in errs.values())), "tolerance": tol,
+            "max_rel_err_vs_float64_oracle": errs, "kink_flips_fp32_vs_float64": flips, "pre_activations": e * d,
+            "persistent_form_selected": bool(persistent), "by_dst_items": int(g.by_dst.n_items_max),
+            "split_destinations": int(g.by_dst.n_splits_max), "N": n, "E": e, "d": d, "oracle_seconds": cpu_s,
+            "workload": "config 4 down-scaled to 80 000 entities / 1 M triples / 1 k relations (power-law, same generator): the "
+                        "persistent-grid forward (fp32 + padded bf16 tables) and the three-pass deterministic backward"}
+
+
 def synth_measure(a, device, cpu=True):
     """Config 4 at HBM scale: the aggregation kernel on 1M entities / 20M triples / 1k relations, d=300."""
     from jmac_amd import synth
@@ -1456,10 +1512,16 @@ def main():
             torch.set_num_threads(ncpu)
         line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
     if not a.no_synth:
+        sp = None
+        if not a.no_parity_check:                 # the persistent-grid kernels meet the oracle before they are timed
+            sp = synth_parity(a, device)
+            if not sp["ok"]:
+                raise SystemExit("bench.py: the persistent-grid aggregation kernels do not match the oracle: %s" % json.dumps(sp))
         try:
             line["synth"] = synth_measure(a, device, cpu=cpu_on)
+            line["synth"]["parity"] = sp
         except Exception as ex:                      # pragma: no cover
-            line["synth"] = {"error": str(ex)}
+            line["synth"] = {"error": str(ex), "parity": sp}
         # the destination-sharded config-4 step at ONE rank (no collective runs): the base of the N > 1 lines' value
         try:
             from bench_dist import run_sharded

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
         float4 pv[NCH], acc[NCH];
         raw_t zs[NCH];
         const TT* prow = tP + (int64_t)i * a.ldp;
-        const TT* zrow = tQZ + ((int64_t)i + a.self_off) * a.ldqz;
+        const TT* zrow = tQZ + ((int64_t)(has_loop ? i : 0) + a.self_off) * a.ldqz;   // no loop: row 0 (valid, unused)
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             pv[k] = L.any_h(k) ? cvt4(ldraw(prow + (L.is_h[k] ? L.coff[k] : 0))) : f4zero();
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
             for (int u = 0; u < kEmptyPack; ++u) seg[u] = a.items[min(n_reg + p * kEmptyPack + u, n_items - 1)].seg;
 #pragma unroll
             for (int u = 0; u < kEmptyPack; ++u) {
-                const TT* zrow = tQZ + ((int64_t)seg[u] + a.self_off) * a.ldqz;
+                const TT* zrow = tQZ + ((int64_t)(has_loop ? seg[u] : 0) + a.self_off) * a.ldqz;
 #pragma unroll
                 for (int k = 0; k < NCH; ++k)
                     if (L.any_v(k)) zs[u][k] = ldraw(zrow + L.coffc[k]);
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
         float4 pv[NCH], acc[NCH];
         raw_t zs[NCH];
         const TT* prow = tP + (int64_t)i * a.ldp;
-        const TT* zrow = tQZ + ((int64_t)i + a.self_off) * a.ldqz;
+        const TT* zrow = tQZ + ((int64_t)(has_loop ? i : 0) + a.self_off) * a.ldqz;   // no loop: row 0 (valid, unused)
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             pv[k] = L.any_h(k) ? cvt4(ldraw(prow + (L.is_h[k] ? L.coff[k] : 0))) : f4zero();
@@ -804,7 +804,7 @@ __device__ __forceinline__ void rel_attn_fwd_hw_body(const FwdArgs& a) {
     };
     // raw Z[i] chunks in the OUTPUT layout (the fused self loop); converted in finish
     auto load_z = [&](int i, uint4 (&zraw)[NP]) {
-        const TT* zrow = tQZ + ((int64_t)i + a.self_off) * a.ldqz;
+        const TT* zrow = tQZ + ((int64_t)(has_loop ? i : 0) + a.self_off) * a.ldqz;   // no loop: row 0 (valid, unused)
 #pragma unroll
         for (int p = 0; p < NP; ++p) zraw[p] = ld16(zrow + (oc[p] >= 0 ? oc[p] : 0) * CH);
     };

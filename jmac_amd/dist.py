@@ -27,6 +27,8 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
+MAX_CHUNKS = 16          # JMAC_MERGE_MAX_PARTS of include/jmac_hip.h: parts one jmac_softmax_parts_merge_f32 call merges
+
 
 # ------------------------------------------------------------------------------------------------
 # partitioning
@@ -75,6 +77,9 @@ class ShardedGraph:
         owner = np.searchsorted(bounds, src, side="right") - 1
         local = src - bounds[owner]
         self.dst_local = (dst - self.lo).astype(np.int64)
+        if int(chunks) > MAX_CHUNKS:       # fail here, not after every chunk's all-gather and partial pass has been queued
+            raise ValueError("ShardedGraph: chunks=%d exceeds the %d parts jmac_softmax_parts_merge_f32 merges (JMAC_MERGE_MAX_PARTS)"
+                             % (int(chunks), MAX_CHUNKS))
         self.chunks = max(1, min(int(chunks), max(self.n_max, 1)))
         cb = np.asarray([(k * self.n_max) // self.chunks for k in range(self.chunks + 1)], dtype=np.int64)
         self.chunk_bounds = cb
@@ -468,7 +473,7 @@ class _ChunkedAllGather(torch.autograd.Function):
     them in order on its own stream, each one on all links).  Returns at once: ``pending[c]`` is chunk c's work handle, which
     ``_ChunkedAggregate`` waits for one by one.  Backward: one reduce-scatter per chunk slice."""
 
-    pending = None          # [(work, profile event, slice) or None] * chunks of the table returned last
+    _handoff = None         # forward -> chunked_all_gather(), within one call: the work handles of the table being returned
 
     @staticmethod
     def forward(ctx, x, sg: ShardedGraph, group):
@@ -479,8 +484,8 @@ class _ChunkedAllGather(torch.autograd.Function):
         if x.shape[0] != sg.n_max:
             raise ValueError("the rank's table must be padded to n_max rows")
         works = [None] * sg.chunks
-        _ChunkedAllGather.pending = works
         table = torch.empty((sg.table_rows,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        _ChunkedAllGather._handoff = works                   # chunked_all_gather() hangs them on the returned table at once
         table[world * sg.n_max:].copy_(x)                    # the rank's own rows once more, contiguous (fused self loop)
         if _skip(group):
             table[:sg.n_max].copy_(x)                        # one rank: the chunk-major table is the input
@@ -503,9 +508,11 @@ class _ChunkedAllGather(torch.autograd.Function):
         return table
 
     @staticmethod
-    def wait(chunk: int) -> None:
-        """Make the compute stream wait for chunk ``chunk`` of the pending table (no host block under RCCL)."""
-        p = _ChunkedAllGather.pending
+    def wait(table, chunk: int) -> None:
+        """Make the compute stream wait for chunk ``chunk`` of ``table`` (no host block under RCCL).  The work handles ride on
+        the table tensor itself (``_jmac_pending``): a forward that raises between the exchange and the aggregation leaves
+        nothing behind for the next forward to overwrite."""
+        p = getattr(table, "_jmac_pending", None)
         if p is not None and p[chunk] is not None:
             work, e0, dst = p[chunk]
             p[chunk] = None
@@ -554,11 +561,15 @@ class _ChunkedAggregate(torch.autograd.Function):
         P, RR, a = P.contiguous(), RR.contiguous(), a.contiguous()
         n, d = sg.n_local, P.shape[1]
         parts = []
-        for c in range(sg.chunks):
-            _ChunkedAllGather.wait(c)
-            if n > 0 and sg.chunk_edges(c) > 0:
-                parts.append(kernels.partial(P, table, RR, a, sg, c, slope))
-        _ChunkedAllGather.pending = None
+        try:
+            for c in range(sg.chunks):
+                _ChunkedAllGather.wait(table, c)
+                if n > 0 and sg.chunk_edges(c) > 0:
+                    parts.append(kernels.partial(P, table, RR, a, sg, c, slope))
+        finally:                                             # whatever happened: no un-waited collective outlives this call
+            for c in range(sg.chunks):
+                _ChunkedAllGather.wait(table, c)
+            table._jmac_pending = None
         zself = table[sg.self_off:sg.self_off + n, d:]
         pre, seg_max, seg_den = kernels.merge(parts, n, d, P.device, zself, RR[-1, d:].contiguous(), 0.5)
         ctx.save_for_backward(P, table, RR, a, pre, seg_max, seg_den)
@@ -573,7 +584,9 @@ class _ChunkedAggregate(torch.autograd.Function):
 
 
 def chunked_all_gather(x: torch.Tensor, sg: ShardedGraph, group=None) -> torch.Tensor:
-    return _ChunkedAllGather.apply(x, sg, group)
+    table = _ChunkedAllGather.apply(x, sg, group)
+    table._jmac_pending, _ChunkedAllGather._handoff = _ChunkedAllGather._handoff, None
+    return table
 
 
 def chunked_aggregate(P, table, RR, a, sg: ShardedGraph, slope: float, kernels=None) -> torch.Tensor:

@@ -311,12 +311,15 @@ class UnionGraphCache:
             require_device(ei, et)
             if ei.shape[1] > 0:                     # per block: an id past its own block must not land in a neighbour's rows
                 check_index_range(ei, int(n), "edge_index (block of %d entities)" % int(n))
-                check_index_range(et, int(nr), "edge_type (block of %d relations)" % int(nr))
+                # like the single-KG path (RelGraph with num_rel = nr + 1) a block may name its loop relation, id nr_k
+                check_index_range(et, int(nr) + 1, "edge_type (block of %d relations + the loop relation)" % int(nr))
             eis.append(ei.to(torch.int64) + row0)
-            ets.append(et.to(torch.int64) + rel0)
+            et64 = et.to(torch.int64)
+            ets.append(torch.where(et64 == int(nr), torch.full_like(et64, -1), et64 + rel0))   # -1: the union's ONE loop row (below)
             row0 += int(n)
             rel0 += int(nr)
         ei_u, et_u = torch.cat(eis, dim=1).contiguous(), torch.cat(ets).contiguous()
+        et_u = torch.where(et_u < 0, torch.full_like(et_u, rel0), et_u)
         _lib.mark_index_range(ei_u, row0)
         _lib.mark_index_range(et_u, rel0 + 1)
         g = RelGraph(ei_u, et_u, row0, rel0 + 1, chunk)

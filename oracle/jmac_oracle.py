@@ -458,22 +458,71 @@ def factorised_pre_bn(p: Dict[str, Tensor], ent_emb: Tensor, rel_emb: Tensor, ed
 
 
 def aggregate_from_tables(PQZ: Tensor, RR: Tensor, a: Tensor, edge_index: Tensor, edge_type: Tensor, slope: float,
-                          loop_rel: int = -1, out_scale: float = 1.0) -> Tensor:
+                          loop_rel: int = -1, out_scale: float = 1.0, kink_mask: Optional[Tensor] = None) -> Tensor:
     """The factorised aggregation (factorised_pre_bn above; message_passing.py:4-29 + jmac_model.py:56-89 after
     hoisting the per-edge GEMMs) on GIVEN tables PQZ [N,3d] = P|Q|Z and RR [nr,2d] = Rq|Rz, in their dtype.
-    Used to check the bf16-table kernel: pass the bf16-rounded tables widened to float64."""
+    Used to check the bf16-table kernel: pass the bf16-rounded tables widened to float64.  ``kink_mask`` ([E, d] bool,
+    tests only): the side of the attention LeakyReLU's kink to take per element (see ``_message_and_aggregate``)."""
     n, d = PQZ.shape[0], PQZ.shape[1] // 3
     P, Q, Z = PQZ[:, :d], PQZ[:, d:2 * d], PQZ[:, 2 * d:]
     Rq, Rz = RR[:, :d], RR[:, d:]
     dst, src = edge_index[0], edge_index[1]
     h = P[dst] + Q[src] - Rq[edge_type]
-    s = F.leaky_relu(h, slope) @ a.reshape(-1, 1).to(h.dtype)
+    s = _leaky(h, slope, kink_mask) @ a.reshape(-1, 1).to(h.dtype)
     alpha = scatter_softmax(s, dst, n)
     deg = scatter_sum(torch.ones(dst.shape[0], dtype=h.dtype), dst, n)
     out = scatter_sum(alpha * (Z[src] - Rz[edge_type]), dst, n) * deg.sqrt().view(-1, 1)
     if loop_rel >= 0:
         out = out + Z - Rz[loop_rel]
     return out * out_scale
+
+
+def _dst_slices(dst: np.ndarray, nslices: int) -> List[np.ndarray]:
+    """Edge subsets by destination range, about equal edge counts, every destination's edges in ONE subset."""
+    order = np.argsort(dst, kind="stable")
+    ds = dst[order]
+    e = order.size
+    cuts = [0]
+    for k in range(1, nslices):
+        c = max(k * e // nslices, cuts[-1])
+        while 0 < c < e and ds[c] == ds[c - 1]:
+            c += 1
+        cuts.append(c)
+    cuts.append(e)
+    return [order[cuts[k]:cuts[k + 1]] for k in range(nslices) if cuts[k + 1] > cuts[k]]
+
+
+def aggregate_from_tables_sliced(PQZ: Tensor, RR: Tensor, a: Tensor, edge_index: Tensor, edge_type: Tensor, slope: float,
+                                 loop_rel: int = -1, out_scale: float = 1.0, dtype=torch.float64, G: Optional[Tensor] = None,
+                                 kink_mask: Optional[Tensor] = None, nslices: int = 8):
+    """``aggregate_from_tables`` in ``dtype`` on graphs of ~10^6 edges x d = 300: the softmax and the sum are per destination
+    (message_passing.py:24,28 both index on edge_index[0]), so the edge list is cut by destination RANGE and every slice is an
+    independent call -- float64 then needs a few GB instead of tens.  With ``G`` [N,d] also returns the gradients
+    (dPQZ, dRR, da) of sum(out * G), accumulated slice by slice.  ``kink_mask`` [E, d] bool in the order of edge_index's
+    columns.  Tests / bench parity legs only."""
+    n, d = PQZ.shape[0], PQZ.shape[1] // 3
+    grad = G is not None
+    P_, R_, a_ = (t.detach().to(dtype).clone().requires_grad_(grad) for t in (PQZ, RR, a))
+    Gd = G.to(dtype) if grad else None
+    out = torch.zeros((n, d), dtype=dtype)
+    with torch.set_grad_enabled(grad):
+        for sl in _dst_slices(edge_index[0].numpy(), nslices):
+            idx = torch.from_numpy(sl)
+            km = kink_mask[idx] if kink_mask is not None else None
+            part = aggregate_from_tables(P_, R_, a_, edge_index[:, idx], edge_type[idx], slope, -1, 1.0, kink_mask=km)
+            if grad:
+                (part * Gd).sum().mul(out_scale).backward()
+            out += part.detach()
+            del part
+        if loop_rel >= 0:                                        # the self-loop propagate, jmac_model.py:44-45,50
+            self_term = P_[:, 2 * d:] - R_[loop_rel, d:]
+            if grad:
+                (self_term * Gd).sum().mul(out_scale).backward()
+            out += self_term.detach()
+    out *= out_scale
+    if grad:
+        return out, (P_.grad, R_.grad, a_.grad)
+    return out
 
 
 # --------------------------------------------------------------------------------------------

@@ -223,7 +223,9 @@ def test_partition_rows_balances_edges():
     assert (sg.src_padded == owner * 70 + (src - b[owner])).all()
     # chunk-major layout of the pipelined exchange: a bijection of (owner, local row) onto [0, world * n_max), chunk c of every
     # rank inside the slice [world * cb[c], world * cb[c+1]) -- the slice ONE all-gather of that row chunk fills
-    for chunks in (2, 3, 7, 1000):
+    with pytest.raises(ValueError):                      # more chunks than one merge call takes (JMAC_MERGE_MAX_PARTS): refused
+        ShardedGraph(ei, rng.integers(0, 5, 400), b, 1, chunks=17)    # at construction, before any collective is queued
+    for chunks in (2, 3, 7, 16):
         sgc = ShardedGraph(ei, rng.integers(0, 5, 400), b, 1, chunks=chunks)
         cb = sgc.chunk_bounds
         assert cb[0] == 0 and cb[-1] == sgc.n_max and (np.diff(cb) >= 0).all() and sgc.chunks == min(chunks, sgc.n_max)

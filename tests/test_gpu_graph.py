@@ -136,3 +136,22 @@ def test_out_of_range_ids_raise_index_error():
     h2[0] = 11
     with pytest.raises(IndexError):
         losses.triple_l1_score(ent, rel, h2, r, t_)
+
+
+def test_union_block_may_name_its_loop_relation():
+    """A KG's edge list may carry the loop relation's id (nr_k): the single-KG path builds RelGraph with num_rel = nr_k + 1 and
+    accepts it; the block-diagonal union (JMAC.forward_stacked) maps every block's loop id onto the union's ONE loop row
+    (it used to raise IndexError there)."""
+    from jmac_amd.graph import UnionGraphCache
+    dev = torch.device("cuda")
+    ei1 = torch.tensor([[0, 1, 2], [1, 2, 0]], device=dev)
+    et1 = torch.tensor([0, 4, 2], device=dev)                         # 4 = block 1's loop id (nr_1 = 4)
+    ei2 = torch.tensor([[0, 1], [1, 0]], device=dev)
+    et2 = torch.tensor([3, 1], device=dev)                            # 3 = block 2's loop id (nr_2 = 3)
+    g = UnionGraphCache().get([(ei1, et1, 3, 4), (ei2, et2, 2, 3)])
+    assert g.N == 5 and g.num_rel == 8                                # 4 + 3 relation rows + the one loop row (id 7)
+    perm = g.perm[:5].long()
+    want = torch.tensor([0, 7, 2, 7, 4 + 1], device=dev)[perm]
+    assert torch.equal(g.etype[:5].long(), want)
+    with pytest.raises((IndexError, RuntimeError, ValueError)):
+        UnionGraphCache().get([(ei1, torch.tensor([0, 5, 2], device=dev), 3, 4)])     # past the loop id: still refused

@@ -234,3 +234,46 @@ def test_comp_op_mult(n, nr, d, e, hub):
         rel = lay.transform_relations(Rg)
         alt = lay._pre_bn_unfactorised(Xg, rel, ei.cuda(), et.cuda())
         assert_close(lay._pre_bn_mult(Xg, rel, ei.cuda(), et.cuda()), alt, RTOL, 1e-6, "fused vs scatter form")
+
+
+@pytest.mark.parametrize("n_dst,n_src,e", [(500, 100, 4000), (70000, 64, 30000)], ids=["small", "persistent-form"])
+def test_split_tables_fewer_source_rows_than_destinations_no_loop(n_dst, n_src, e):
+    """Bipartite / sharded callers of the split-table entry point (include/jmac_hip.h: P [N_dst,d], QZ [N_src,2d]) with
+    FEWER source rows than destinations and no loop relation (loop_rel = -1): the fused self row QZ[self_off + i] must not be
+    read at all (the forward kernels used to load it unconditionally -- out of bounds for i >= N_src).  Result
+    against the oracle on one [N_dst, 3d] table whose Q|Z rows past N_src no edge names."""
+    from jmac_amd import ops
+    from jmac_amd.graph import RelGraph
+    d, nr = 300, 9
+    rng = np.random.default_rng(n_dst + e)
+    ei = np.stack([rng.integers(0, n_dst, e), rng.integers(0, n_src, e)]).astype(np.int64)
+    ei[0, : e // 10] = 7                                              # a hub destination (split items)
+    et = rng.integers(0, nr, e).astype(np.int64)
+    gen = torch.Generator().manual_seed(e)
+    P, QZ = torch.randn(n_dst, d, generator=gen) * 0.3, torch.randn(n_src, 2 * d, generator=gen) * 0.3
+    RR, a = torch.randn(nr, 2 * d, generator=gen) * 0.3, torch.randn(d, generator=gen) * 0.1
+    G = torch.randn(n_dst, d, generator=gen)
+    dev = torch.device("cuda")
+    g = RelGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(et).to(dev), n_dst, nr, num_src=n_src)
+    Pg, QZg, Rg, ag = (t.to(dev).requires_grad_(True) for t in (P, QZ, RR, a))
+    out = ops.rel_attn_aggregate_split(Pg, QZg, Rg, ag, g, 0.05, 1.0, -1, 0)
+    out.backward(G.to(dev))
+    PQZ = torch.zeros(n_dst, 3 * d, dtype=torch.float64)
+    PQZ[:, :d] = P.double()
+    PQZ[:n_src, d:] = QZ.double()
+    PQZ.requires_grad_(True)
+    R64, a64 = RR.double().requires_grad_(True), a.double().requires_grad_(True)
+    ref = orc.aggregate_from_tables(PQZ, R64, a64, torch.from_numpy(ei), torch.from_numpy(et), 0.05, -1, 1.0)
+    (ref * G.double()).sum().backward()
+    assert_close(out, ref, RTOL, 1e-7, "out")
+    with torch.no_grad():
+        eig, etg = torch.from_numpy(ei).to(dev), torch.from_numpy(et).to(dev)
+        h32 = (Pg[eig[0]] + (QZg[eig[1], :d] - Rg[etg, :d])).cpu()
+        h64 = PQZ[ei[0], :d] + PQZ[ei[1], d:2 * d] - R64[et, :d]
+        flips = int(((h32 > 0) != (h64 > 0)).sum())
+    gtol = RTOL if flips == 0 else 5e-2
+    assert flips <= 3, flips
+    assert_close(Pg.grad, PQZ.grad[:, :d], gtol, 1e-9, "dP")
+    assert_close(QZg.grad, PQZ.grad[:n_src, d:], gtol, 1e-9, "dQZ")
+    assert_close(Rg.grad, R64.grad, gtol, 1e-9, "dRR")
+    assert_close(ag.grad, a64.grad, gtol, 1e-9, "da")

@@ -1,0 +1,303 @@
+"""GPU: the PERSISTENT-GRID forms of the aggregation kernels, held directly to the oracle, at d = 300 and d = 256.
+
+``launch_rel_attn_fwd`` (jmac_amd/csrc/aggregate.hip) picks ``rel_attn_fwd_hw_kernel<75|64,12,float>`` /
+``<38|32,12,bf16>`` or the 64-lane ``rel_attn_fwd_kernel<...,U=4>`` only for schedules of more than 16 384 items WITHOUT
+inline entries -- in practice graphs of more than 65 536 by-destination items (jmac_amd/graph.py INLINE_EDGES_MAX_ITEMS).
+Every other oracle test stays below that size, so these kernels -- the ones behind BASELINE config 4 and the HBM-scale roofline
+figure -- used to meet the oracle only transitively.  Here, on one seeded power-law graph (N = 80 000, E = 600 000,
+100 relations, hubs of 10^4 in-edges, three hub sources; tests/persistent_case.py):
+
+  * forward on fp32 tables against the oracle in fp32 and float64, and the full deterministic backward (pass A on the
+    by-destination schedule, passes B / C on by-source / by-relation items, ``bwd_finalize``) -- every gradient against
+    float64 on the GPU's own side of every LeakyReLU kink (the sign pattern of h_e computed from the same fp32 tables is
+    handed to the oracle; the number of elements whose own sign differs is counted and bounded) -- with the automatic
+    schedule (64-entry items) and with config 4's item sizes (256 by destination, 512 by source / relation);
+  * forward on (padded) bf16 tables against the float64 oracle on the same bf16-rounded tables;
+  * the selectable forms (JMAC_FWD_HW=0: 64-lane U=4; JMAC_FWD_HOT=1: LDS-staged relation rows; JMAC_FWD_NT=1: streaming gathers;
+    JMAC_FWD_HW_DEPTH=2: guarded pipeline), each in a subprocess (the knobs are read once per process), each against the ORACLE;
+  * ``jmac_softmax_parts_merge_f32`` over C = 4 source chunks against the oracle on the whole graph;
+  * ``RelationAwareLayer`` itself (projections, relation transform, BatchNorm, tanh around the same kernels) against
+    ``oracle.layer_forward`` -- the un-factorised restatement of src/jmac_model.py:33-53 -- at a persistent-form size.
+
+Reference semantics: src/jmac_model.py:33-53,80-89, modules/helper/message_passing.py:24-28; d = 256 is train.py:73's default,
+d = 300 BASELINE's.  Tolerance: 1e-4 of the tensor's scale (north_star), written below."""
+import functools
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import persistent_case as pc  # noqa: E402
+from util import assert_close, expand_rel_act, make_args, rel_rows  # noqa: E402
+
+RTOL = 1e-4
+BF16_RTOL = 1e-4          # against the float64 oracle on the SAME bf16-rounded tables: fp32 accumulation error only
+
+
+@functools.lru_cache(maxsize=None)
+def _case():
+    return pc.graph()
+
+
+@functools.lru_cache(maxsize=4)
+def _tables(d):
+    _, _, n, nrel = _case()
+    return pc.tables(n, nrel, d)
+
+
+@functools.lru_cache(maxsize=4)
+def _oracle_fwd(d, table):
+    """Oracle forward of the case: table 'f32' -> (fp32 result, float64 result); 'bf16' -> float64 on the rounded tables."""
+    ei, et, n, nrel = _case()
+    PQZ, RR, a, _ = _tables(d)
+    if table == "bf16":
+        P16, R16 = PQZ.to(torch.bfloat16).double(), RR.to(torch.bfloat16).double()
+        return pc.oracle_aggregate(P16, R16, a, ei, et, nrel - 1, torch.float64)
+    return (pc.oracle_aggregate(PQZ, RR, a, ei, et, nrel - 1, torch.float32),
+            pc.oracle_aggregate(PQZ, RR, a, ei, et, nrel - 1, torch.float64))
+
+
+def _split_stats(sched):
+    """(number of split segments, largest number of items one split segment has) of a schedule."""
+    ns = sched.n_splits_max
+    if ns == 0:
+        return 0, 0
+    sp = sched.splits[:ns].cpu().numpy()          # rows {segment, first partial slot, number of parts, ...}: column 2 = parts
+    return ns, int(sp[:, 2].max())
+
+
+def _build_graph(sched, monkeypatch):
+    from jmac_amd import graph as jgraph
+    ei, et, n, nrel = _case()
+    dev = torch.device("cuda")
+    if sched == "config4-items":      # the item sizes auto_chunk() gives config 4's 20 M edges: 256 by destination, 512 by source / relation
+        monkeypatch.setattr(jgraph, "auto_chunk", lambda n_entries, cap=512: int(cap))
+    g = jgraph.RelGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(et).to(dev), n, nrel)
+    # the persistent form: no inline entries, more items than any one-wave-per-item grid
+    assert g.by_dst.n_items_max > 65536 and g.by_dst.item_edges is None
+    return g
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("sched", ["auto-items", "config4-items"])
+@pytest.mark.parametrize("d", [300, 256])
+def test_persistent_forward_backward_vs_oracle(d, sched, monkeypatch):
+    from jmac_amd import ops
+    dev = torch.device("cuda")
+    ei, et, n, nrel = _case()
+    e = ei.shape[1]
+    g = _build_graph(sched, monkeypatch)
+    assert g._chunk_dst == (256 if sched == "config4-items" else 64) and g.chunk == (512 if sched == "config4-items" else 64)
+    PQZ, RR, a, G = _tables(d)
+    Pg = PQZ.to(dev).requires_grad_(True)
+    Rg = RR.to(dev).requires_grad_(True)
+    ag = a.to(dev).requires_grad_(True)
+    out = ops.rel_attn_aggregate(Pg, Rg, ag, g, pc.SLOPE, nrel - 1, pc.OUT_SCALE)
+    # ---- forward: oracle in fp32 and in float64
+    o32, o64 = _oracle_fwd(d, "f32")
+    assert_close(out, o32, RTOL, 1e-7, "forward vs oracle fp32")
+    assert_close(out, o64, RTOL, 1e-7, "forward vs oracle float64")
+    # the schedule really has split destinations of >= 3 items (combine kernel) ...
+    nsd, maxd = _split_stats(g.by_dst)
+    assert nsd >= 20 and maxd >= 3, (nsd, maxd)
+    out.backward(G.to(dev))
+    torch.cuda.synchronize()
+    # ... and split sources / relations of >= 3 items (partial-row merges of passes B / C in bwd_finalize)
+    assert g.by_dst_bwd is g.by_dst                                  # plain (non-cooperative) by-destination schedule for pass A
+    nss, maxs = _split_stats(g.by_src)
+    nsr, maxr = _split_stats(g.by_rel)
+    assert nss >= 2 and maxs >= 3 and nsr >= 20 and maxr >= 3, (nss, maxs, nsr, maxr)
+    # ---- backward: float64 oracle on the GPU's side of every attention kink
+    with torch.no_grad():
+        dst, src, typ = (torch.from_numpy(x).to(dev) for x in (ei[0], ei[1], et))
+        mask = torch.empty((e, d), dtype=torch.bool)
+        for lo in range(0, e, 100000):                               # h_e = P[i] + (Q[j] - Rq[t]): the kernel's own order
+            sl = slice(lo, min(lo + 100000, e))
+            h = Pg[dst[sl], :d] + (Pg[src[sl], d:2 * d] - Rg[typ[sl], :d])
+            mask[sl] = (h > 0).cpu()
+        del h
+    eit, ett = torch.from_numpy(ei), torch.from_numpy(et)
+    P64, R64 = PQZ.double(), RR.double()
+    flips = 0
+    for lo in range(0, e, 100000):
+        sl = slice(lo, min(lo + 100000, e))
+        h64 = P64[eit[0, sl], :d] + P64[eit[1, sl], d:2 * d] - R64[ett[sl], :d]
+        flips += int(((h64 > 0) != mask[sl]).sum())
+    assert flips <= 64, flips                                        # of E * d = 1.8e8 pre-activations
+    _, (gP, gR, ga) = pc.oracle_aggregate(PQZ, RR, a, ei, et, nrel - 1, torch.float64, G=G, kink_mask=mask)
+    got_P, got_R = Pg.grad, Rg.grad
+    for name, got, ref in (("dP", got_P[:, :d], gP[:, :d]), ("dQ", got_P[:, d:2 * d], gP[:, d:2 * d]),
+                           ("dZ", got_P[:, 2 * d:], gP[:, 2 * d:]), ("dRq", got_R[:, :d], gR[:, :d]),
+                           ("dRz", got_R[:, d:], gR[:, d:]), ("da", ag.grad, ga)):
+        assert_close(got, ref, RTOL, 1e-9, "grad " + name)
+    print("persistent d=%d %s: fwd err fp32 %.2e f64 %.2e; kink flips %d of %d; split dst/src/rel %d/%d/%d (max parts %d/%d/%d)"
+          % (d, sched, pc.rel_err(out, o32), pc.rel_err(out, o64), flips, e * d, nsd, nss, nsr, maxd, maxs, maxr))
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("d", [300, 256])
+def test_persistent_bf16_forward_vs_oracle(d, monkeypatch):
+    """Padded bf16 tables (d = 300: halves of 304 elements; d = 256: no pad) through the half-wave kernel's bf16 instantiations
+    (DC = 38 / 32) against the float64 oracle on the same rounded tables."""
+    from jmac_amd import ops
+    dev = torch.device("cuda")
+    _, _, n, nrel = _case()
+    g = _build_graph("auto-items", monkeypatch)
+    PQZ, RR, a, _ = _tables(d)
+    P16 = ops.pad_table(PQZ.to(dev).to(torch.bfloat16), d, 3)
+    R16 = ops.pad_table(RR.to(dev).to(torch.bfloat16), d, 2)
+    assert P16.shape[1] == 3 * ops.bf16_pad(d)
+    with torch.no_grad():
+        o16 = ops.rel_attn_aggregate(P16, R16, a.to(dev), g, pc.SLOPE, nrel - 1, pc.OUT_SCALE)
+    assert_close(o16, _oracle_fwd(d, "bf16"), BF16_RTOL, 1e-7, "bf16-table forward vs float64 oracle on the rounded tables")
+
+
+FORMS = [("lanes64-u4", {"JMAC_FWD_HW": "0"}), ("hot-lds-rows", {"JMAC_FWD_HOT": "1"}), ("nontemporal", {"JMAC_FWD_NT": "1"}),
+         ("guarded-depth2", {"JMAC_FWD_HW_DEPTH": "2"})]
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("form,env", FORMS, ids=[f for f, _ in FORMS])
+@pytest.mark.parametrize("d", [300, 256])
+def test_forward_forms_vs_oracle(d, form, env, tmp_path):
+    """Every selectable forward form against the ORACLE (not against each other)."""
+    out = str(tmp_path / ("%s_%d.npz" % (form, d)))
+    e = dict(os.environ)
+    for k in ("JMAC_FWD_HW", "JMAC_FWD_HOT", "JMAC_FWD_NT", "JMAC_FWD_HW_DEPTH", "JMAC_FWD_U", "JMAC_GRID", "JMAC_SMALL_ITEMS"):
+        e.pop(k, None)
+    e.update(env)
+    subprocess.run([sys.executable, os.path.join(HERE, "persistent_worker.py"), str(d), out], env=e, check=True, timeout=900)
+    v = np.load(out)
+    o32, o64 = _oracle_fwd(d, "f32")
+    assert_close(v["o32"], o32, RTOL, 1e-7, form + ": fp32 tables vs oracle fp32")
+    assert_close(v["o32"], o64, RTOL, 1e-7, form + ": fp32 tables vs oracle float64")
+    assert_close(v["o16"], _oracle_fwd(d, "bf16"), BF16_RTOL, 1e-7, form + ": bf16 tables vs float64 oracle")
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("d", [300, 256])
+def test_parts_merge_vs_oracle(d):
+    """The slab-pipelined exchange's arithmetic (jmac_amd/dist.py): the forward kernel on the sub-graphs of a 4-way split of the
+    SOURCES (no self loop, scale 1), merged by ``jmac_softmax_parts_merge_f32`` with the fused self loop and the 1/2 -- against
+    the oracle on the whole graph; the merged (max, denominator) against the oracle's per-destination softmax statistics."""
+    from jmac_amd import ops
+    from jmac_amd.graph import RelGraph
+    dev = torch.device("cuda")
+    ei, et, n, nrel = _case()
+    PQZ, RR, a, _ = _tables(d)
+    Pd, Rd, ad = PQZ.to(dev), RR.to(dev), a.to(dev)
+    P, QZ = Pd[:, :d].contiguous(), Pd[:, d:].contiguous()
+    eit, ett = torch.from_numpy(ei).to(dev), torch.from_numpy(et).to(dev)
+    cut = [0, n // 5, n // 2, n // 2 + 7, n]                         # uneven source ranges, one of them 7 rows wide
+    parts = []
+    for c in range(4):
+        sel = (eit[1] >= cut[c]) & (eit[1] < cut[c + 1])
+        assert int(sel.sum()) > 0
+        gc = RelGraph(eit[:, sel].contiguous(), ett[sel].contiguous(), n, nrel)
+        o, m, l = ops.rel_attn_split_fwd_raw(P, QZ, Rd, ad, gc, pc.SLOPE, 1.0, -1, 0)
+        parts.append((o, m, l, gc.rowptr))
+    pre, M, L = ops.softmax_parts_merge(parts, n, d, dev, QZ[:, d:], Rd[nrel - 1, d:].contiguous(), pc.OUT_SCALE)
+    o32, o64 = _oracle_fwd(d, "f32")
+    assert_close(pre, o32, RTOL, 1e-7, "merged parts vs oracle fp32")
+    assert_close(pre, o64, RTOL, 1e-7, "merged parts vs oracle float64")
+    # softmax statistics per destination: M = max_e s_e, L = sum_e exp(s_e - M)   (message_passing.py:24)
+    P64, R64 = PQZ.double(), RR.double()
+    dst, src, typ = torch.from_numpy(ei[0]), torch.from_numpy(ei[1]), torch.from_numpy(et)
+    s = torch.empty(ei.shape[1], dtype=torch.float64)
+    for lo in range(0, ei.shape[1], 100000):
+        sl = slice(lo, lo + 100000)
+        h = P64[dst[sl], :d] + P64[src[sl], d:2 * d] - R64[typ[sl], :d]
+        s[sl] = torch.nn.functional.leaky_relu(h, pc.SLOPE) @ a.double()
+    m_ref = torch.full((n,), -float("inf"), dtype=torch.float64).scatter_reduce(0, dst, s, reduce="amax", include_self=True)
+    l_ref = torch.zeros(n, dtype=torch.float64).scatter_add(0, dst, (s - m_ref[dst]).exp())
+    has = m_ref > -float("inf")
+    assert_close(M.cpu()[has], m_ref[has], RTOL, 1e-6, "merged seg_max")
+    assert_close(L.cpu()[has], l_ref[has], RTOL, 1e-6, "merged seg_den")
+    assert bool((M.cpu()[~has] == -float("inf")).all())
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("d", [300, 256])
+def test_layer_at_persistent_size_vs_unfactorised_oracle(d):
+    """``RelationAwareLayer.forward`` (train-mode BatchNorm) on a graph of more than 65 536 items against the oracle's
+    UN-FACTORISED layer (per-edge cat -> mm -> scatter softmax, oracle.layer_forward = src/jmac_model.py:33-53): forward in
+    fp32 and float64, every gradient in float64 on the GPU's side of the kinks."""
+    import oracle.jmac_oracle as orc
+    from jmac_amd import encoder
+    from jmac_amd.graph import graph_cache
+    from jmac_amd.layer import RelationAwareLayer
+    n, e, nr = 70000, 250000, 60
+    ei, et, n, nrel = pc.graph(n, e, nr, seed=502)
+    gen = torch.Generator().manual_seed(d)
+    X = torch.randn(n, d, generator=gen) * (4 / np.sqrt(d))
+    R = torch.randn(nr, d, generator=gen) * (4 / np.sqrt(d))
+    G = torch.randn(n, d, generator=gen)
+    torch.manual_seed(d + 1)
+    lay = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())
+    with torch.no_grad():
+        lay.bn.weight.uniform_(0.5, 1.5)
+        lay.bn.bias.uniform_(-0.2, 0.2)
+    params = {k: v.detach().clone() for k, v in lay.named_parameters()}
+    eit, ett = torch.from_numpy(ei), torch.from_numpy(et)
+    lay = lay.cuda()
+    Xg, Rg = X.cuda().requires_grad_(True), R.cuda().requires_grad_(True)
+    eig, etg = eit.cuda(), ett.cuda()
+    captured = {}
+    encoder.CAPTURE = captured
+    try:
+        out = lay(Xg, Rg, eig, etg)
+    finally:
+        encoder.CAPTURE = None
+    g = graph_cache.get(eig, etg, n, nr + 1, lay.chunk)
+    assert g.by_dst.n_items_max > 65536 and g.by_dst.item_edges is None
+    (out * G.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    # forward, plain oracle in both precisions
+    for dt in (torch.float32, torch.float64):
+        p = {k: v.to(dt) for k, v in params.items()}
+        with torch.no_grad():
+            ref = orc.layer_forward(p, X.to(dt), R.to(dt), eit, ett, 0.05, "sub", "leaky_relu", True,
+                                    torch.zeros(d, dtype=dt), torch.ones(d, dtype=dt))
+        assert_close(out, ref, RTOL, 1e-6, "layer forward vs oracle %s" % dt)
+    # backward: the GPU's side of the attention kinks and of the relation transform's own LeakyReLU
+    with torch.no_grad():
+        if "layer.tables" in captured:
+            PQZ, RR = captured["layer.tables"]
+            rel_mask = expand_rel_act(captured["layer.rel_act"], captured.get("layer.rel_used"), nr)
+            rows = rel_rows(captured.get("layer.rel_used"), nr)
+        else:
+            PQZ, RR, _, _ = lay._tables(Xg, lay.transform_relations(Rg))
+            rel_mask = (torch.mm(torch.cat([Rg, lay.loop_rel], 0), lay.rel_transform_weight1) > 0).cpu()
+            rows = torch.arange(nr + 1)
+        dp = PQZ.shape[1] // 3
+        types = etg if RR.shape[0] == nr + 1 else g.rel_pos[etg].long()      # compact relation rows (ensure_rel_compact)
+        mask = (PQZ[eig[0], :d] + (PQZ[eig[1], dp:dp + d] - RR[types, :d]) > 0).cpu()
+    f64 = torch.float64
+    p = {k: v.to(f64).requires_grad_(True) for k, v in params.items()}
+    Xc, Rc = X.to(f64).requires_grad_(True), R.to(f64).requires_grad_(True)
+    with torch.no_grad():
+        rel64 = orc.transform_relations(p, Rc, 0.05, "leaky_relu")
+        wt, wb = p["w_att"][:d], p["w_att"][d:]
+        h64 = (Xc @ wt)[eit[0]] + (Xc @ wb)[eit[1]] - (rel64 @ wb)[ett]
+        flips = int(((h64 > 0) != mask).sum())
+        pre64 = torch.cat([Rc, p["loop_rel"]], 0) @ p["rel_transform_weight1"]
+        rflips = int(((pre64 > 0) != rel_mask)[rows].sum())
+        del h64
+    assert flips <= 32 and rflips <= 2, (flips, rflips)
+    ref = orc.layer_forward(p, Xc, Rc, eit, ett, 0.05, "sub", "leaky_relu", True, torch.zeros(d, dtype=f64),
+                            torch.ones(d, dtype=f64), kink_mask=mask, rel_kink_mask=rel_mask)
+    (ref * G.to(f64)).sum().backward()
+    assert_close(Xg.grad, Xc.grad, RTOL, 1e-7, "grad_X")
+    assert_close(Rg.grad, Rc.grad, RTOL, 1e-7, "grad_R")
+    gscale = Rc.grad.abs().max().item()
+    for name, prm in lay.named_parameters():
+        atol = 1e-4 * gscale + 1e-6 if name == "loop_rel" else 1e-7
+        assert_close(prm.grad, p[name].grad, RTOL, atol, "grad " + name)
+    print("layer at persistent size d=%d: attention kink flips %d of %d, relation-side %d" % (d, flips, e * d, rflips))

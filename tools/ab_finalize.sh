@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B: which task of bwd_finalize_kernel holds its 10 us at ja size?  variants drop one task each (results wrong: timing only)
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 for v in base noda nosp2 nosp1; do
   cp jmac_amd/csrc/aggregate.hip /tmp/agg_$v.hip

@@ -2,7 +2,7 @@
 # One GPU-box pass that regenerates what profiles/ holds for a round: the -m gpu suite, the default bench line, the same
 # command under rocprofv3 --kernel-trace --stats, and a kernel trace of the step alone for tools/step_breakdown.py.
 #   usage (repo root, GPU box):  bash tools/final_run.sh gpurun_out/<dir>
-R=$GRAFT_REPO_ROOT; OUT=${1:-gpurun_out/final}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; OUT=${1:-gpurun_out/final}
 mkdir -p $R/$OUT; cd $R
 (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5) > $OUT/gpu_tests.log
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B builds of gemm.hip timed by rocprofv3 on tools/gg_probe.py cases
-R=$GRAFT_REPO_ROOT; OUT=gpurun_out/gg_ab; mkdir -p $R/$OUT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; OUT=gpurun_out/gg_ab; mkdir -p $R/$OUT
 export VARIANT_FILE=gemm
 bash $R/tools/build_variant.sh w8 > /dev/null
 bash $R/tools/build_variant.sh w4 -DJMAC_GG_WAVES=4 -DJMAC_GG_KC=152 > /dev/null

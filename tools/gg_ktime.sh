@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel-level durations (rocprofv3 --kernel-trace --stats) of the grouped GEMM by case of tools/gg_probe.py
-R=$GRAFT_REPO_ROOT; OUT=gpurun_out/gg_ktime; mkdir -p $R/$OUT; cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; OUT=gpurun_out/gg_ktime; mkdir -p $R/$OUT; cd /tmp && export TMPDIR=/tmp
 for c in "NN 962x300x300" "NN x4" "NT 962x300x600" "TN 300x300x962" "TN 300x600x962"; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT -o p -- python3 $R/tools/gg_probe.py "$c" > /dev/null 2>&1
   python3 - "$c" <<PY

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 export VARIANT_FILE=gemm
 bash $R/tools/build_variant.sh trace -DJMAC_GG_TRACE > /dev/null
 export JMAC_LIB_PATH=/tmp/jmac_trace.so

@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel-level durations (rocprofv3 --kernel-trace --stats) of the aggregation kernels on the ja shape
-R=$GRAFT_REPO_ROOT; OUT=${1:-gpurun_out/ja_ktime}; shift
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; OUT=${1:-gpurun_out/ja_ktime}; shift
 mkdir -p $R/$OUT; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT -o p -- python3 $R/tools/ja_sweep.py ja "$@" > /dev/null 2>&1
 cd $R; python3 - <<PY

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of a python script: tools/kstats.sh <out dir under gpurun_out> <script> [args]
-R=$GRAFT_REPO_ROOT; OUT=gpurun_out/$1; shift; mkdir -p $R/$OUT; cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; OUT=gpurun_out/$1; shift; mkdir -p $R/$OUT; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT -o p -- python3 $R/"$@" > /dev/null 2> $R/$OUT/err.log
 cd $R; python3 - <<PY
 import csv

@@ -3,7 +3,7 @@
 # WRITE_SIZE do not fit one pass; --pmc only with --kernel-trace-free runs).  usage (repo root, GPU box):
 #   bash tools/pmc_collect_r2.sh <out_dir>
 OUT=${1:-gpurun_out/pmc_r2}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name counters... -- program args

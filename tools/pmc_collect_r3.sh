@@ -3,7 +3,7 @@
 # WRITE_SIZE do not fit one pass; --pmc runs carry no trace options).  usage (repo root, GPU box):
 #   bash tools/pmc_collect_r3.sh <out_dir>      then   python3 tools/pmc_summarize_r2.py <out_dir> > <out_dir>/summary.json
 OUT=${1:-gpurun_out/pmc_r3}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name counters... -- program args

@@ -5,7 +5,7 @@
 # kernels' own access pattern), the REAL 5-KG union fp32 / bf16, the real ja graph.
 #   usage (repo root, GPU box):  bash tools/pmc_collect_r4.sh <out_dir>
 OUT=${1:-gpurun_out/pmc_r4}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name counters -- program args

@@ -2,7 +2,7 @@
 # rocprofv3 MFMA-busy counters of the fp32 MFMA kernels (similarity GEMM, grouped relation-side GEMM), one pass each.
 #   usage (repo root, GPU box): bash tools/pmc_mfma_r3.sh <out_dir>
 OUT=${1:-gpurun_out/pmc_mfma_r3}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/$OUT/sim -o p -- python3 $R/tools/simgemm_probe.py > $R/$OUT/sim.log 2>&1

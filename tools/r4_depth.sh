@@ -1,6 +1,6 @@
 #!/bin/bash
 # config-4 forward: the default (uniform two-deep) against the conditional two-deep form and the experiments
-cd /root/repo
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_layer.py tests/test_gpu_fullsize.py tests/test_gpu_union_real.py -x -q 2>&1 | tail -2
 run() { env "$@" python tools/c4_probe.py 2>/dev/null | python3 -c "
 import sys, json

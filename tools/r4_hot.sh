@@ -1,7 +1,7 @@
 #!/bin/bash
-cd /root/repo
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 for H in 0 1; do JMAC_FWD_HOT=$H python tools/c4_probe.py 2>/dev/null; done
-R=$GRAFT_REPO_ROOT; OUT=gpurun_out/pmc_r4_hot; mkdir -p $R/$OUT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; OUT=gpurun_out/pmc_r4_hot; mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | tr ' ' '+')

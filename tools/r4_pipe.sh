@@ -1,6 +1,6 @@
 #!/bin/bash
 # sharded config-4 step at ONE rank: one-piece against the slab-pipelined path (what the partial passes + merge cost by themselves)
-cd /root/repo
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 python bench.py --workload synth-1m --steps 3 --warmup 1 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('one-piece  ', d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline_bwd']['avg_launch_ms'], d['config'].get('exchange'))"

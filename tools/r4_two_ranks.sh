@@ -1,7 +1,7 @@
 #!/bin/bash
 # N > 1 lines at HEAD with two ranks SHARING the one GPU of the box (gloo, host-staged exchange: a correctness record of the lines'
 # content, not a timing): the default weak-scaled line, the strong-scaled one, the slab-pipelined one
-cd /root/repo
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 export JMAC_BENCH_SHARE_GPU=1
 python bench.py --gpus 2 --steps 2 --warmup 1 --synth-scale 0.05 2>/dev/null | tail -1 > gpurun_out/r4_2ranks_weak.json
 python bench.py --gpus 2 --steps 2 --warmup 1 --synth-scale 0.05 --scaling strong 2>/dev/null | tail -1 > gpurun_out/r4_2ranks_strong.json

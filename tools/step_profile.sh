@@ -1,7 +1,7 @@
 #!/bin/bash
 # Kernel trace of the headline step alone -> tools/step_breakdown.py (per-step busy time by kernel family).
 #   usage (repo root, GPU box):  bash tools/step_profile.sh gpurun_out/<dir> [bench.py args]
-R=$GRAFT_REPO_ROOT; OUT=${1:-gpurun_out/step}; shift
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; OUT=${1:-gpurun_out/step}; shift
 mkdir -p $R/$OUT; cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/prof -o p -- python3 $R/bench.py --no-synth --no-cpu-baseline "$@" > $R/$OUT/bench_under_rocprof.json 2> $R/$OUT/prof.err
 cd $R
