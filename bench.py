@@ -251,12 +251,15 @@ class JaWorkload:
         on_device = l1 is None
         l1, cos = l1 or self.l1, cos or self.cos
         B = self.a.batch
+        if on_device:                                                    # as JMAC.completion_loss composes it: one node per layer's
+            from jmac_amd import losses                                  # term, the terms chained through add_to (no element-wise glue)
+            loss = None
+            for ent, rl in zip(comp, rel):                               # src/jmac_model.py:331-378
+                loss = losses.completion_layer_loss(ent, rl, h, r, t, B, margin, add_to=loss)
+            p0, p1 = self.pair_cols if pairs is self.pairs else (pairs[:, 0], pairs[:, 1])
+            return losses.pair_cosine_mean(align_out, p0, align_out, p1, add_to=loss)        # :271-273
         loss = 0
         for ent, rl in zip(comp, rel):                                   # src/jmac_model.py:331-378
-            if on_device:                                                # as JMAC.completion_loss composes it
-                from jmac_amd import losses
-                loss = loss + losses.triple_l1_margin_loss(ent, rl, h, r, t, B, margin)
-                continue
             score = l1(ent, rl, h, r, t)
             pos = score[:B].view(-1, B).permute(1, 0)
             neg = score[B:].view(-1, B).permute(1, 0)
@@ -1529,7 +1532,7 @@ def main():
             sa.steps, sa.warmup = 5, 2
             sl = run_sharded(sa, 0, 1, device)
             line["sharded"] = {k: sl[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "roofline_bwd", "comm",
-                                                  "scaling_model", "scaling_model_strong_10x") if k in sl}
+                                                  "scaling_model", "scaling_model_strong_10x", "scaling_model_strong_10x_10M_entities") if k in sl}
         except Exception as ex:                      # pragma: no cover
             line["sharded"] = {"error": str(ex)}
     emit(line)

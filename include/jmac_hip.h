@@ -560,6 +560,34 @@ int jmac_pair_cosine_bwd_sorted_f32(const float* e1, int64_t ld1, const float* e
                                     const float* gdist, const float* stats, const int32_t* rec, float* de1, int64_t ldd1,
                                     float* de2, int64_t ldd2, jmac_stream_t stream);
 
+/* Round 5 -- the same two adjoints as FIRST WRITERS of their gradient tables (no zero fill by the caller, no add of the step's
+ * gradient contributions afterwards; src/jmac_model.py:237-249, 345-378):
+ *  - jmac_pair_cosine_bwd_rows_f32: one wave per gradient ROW over [0, n1 + n2) (rows [0,n1) of de1, then n2 rows of de2; n2 = 0
+ *    when both sides share one table), rowptr [n1+n2+1] = first sorted position (into rec) of every row's run; rows without
+ *    incidences are written as zeros; sums in sorted order (the bits of the sorted form).  The incoming gradient is gdist [L], or
+ *    the scalar gscalar[0] / gscale for every pair (the .mean() over the pairs of alignment_loss_simple, :249).
+ *  - jmac_triple_l1_margin_bwd_exact2_f32: the exact-integer atomics go into PERSISTENT count tables cnt_ent [rows_ent, d] /
+ *    cnt_rel [rows_rel, d] (dense, 16-byte aligned, ZERO on entry and left at zero again) at the windows [ent_off ..), [rel_off ..)
+ *    the ids are local to; the scaling pass writes dent / drel (dense, all rows) = cnt * gloss / (2 B K), on top of their
+ *    contents where acc_ent / acc_rel != 0 (e.g. the rows jmac_pair_cosine_bwd_rows_f32 wrote).  d % 4 == 0; 4 B K >= 2^24:
+ *    JMAC_ERANGE (use jmac_triple_l1_margin_bwd_f32).
+ *  - jmac_vec_mean_acc_f32: out[0] = mean(x[0..n)) + (add_to ? add_to[0] : 0), fixed summation order;
+ *    jmac_margin_loss_fwd_acc_f32: jmac_margin_loss_fwd_f32 + add_to[0] -- a step's loss terms chain through add_to instead of
+ *    through element-wise adds. */
+int jmac_pair_cosine_bwd_rows_f32(const float* e1, int64_t ld1, const float* e2, int64_t ld2, int64_t L, int64_t d,
+                                  const float* gdist, const float* gscalar, float gscale, const float* stats,
+                                  const int32_t* rec, const int32_t* rowptr, int64_t n1, int64_t n2, float* de1,
+                                  int64_t ldd1, float* de2, int64_t ldd2, jmac_stream_t stream);
+int jmac_triple_l1_margin_bwd_exact2_f32(const float* ent, int64_t lde, const float* rel, int64_t ldr, const int64_t* h,
+                                         const int64_t* r, const int64_t* t, int64_t B, int64_t K, int64_t d,
+                                         const float* score, const float* gamma, const float* gloss, int64_t ent_off,
+                                         int64_t rel_off, float* cnt_ent, float* cnt_rel, float* dent, int64_t rows_ent,
+                                         int32_t acc_ent, float* drel, int64_t rows_rel, int32_t acc_rel,
+                                         jmac_stream_t stream);
+int jmac_vec_mean_acc_f32(const float* x, int64_t n, const float* add_to, float* out, jmac_stream_t stream);
+int jmac_margin_loss_fwd_acc_f32(const float* score, int64_t B, int64_t K, const float* gamma, const float* add_to,
+                                 float* loss, jmac_stream_t stream);
+
 /* dist[x] = 1 - <u, v>, u = e1[i1[x]] / max(||.||, 1e-12), v = e2[i2[x]] / max(||.||, 1e-12)
  * (replaces F.normalize(E[idx]) x2 + sum of alignment_loss / alignment_loss_simple,
  * src/jmac_model.py:245-247, 271-291). */

@@ -128,6 +128,11 @@ _SIGS = {
     "jmac_pair_cosine_bwd_sorted_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, vp, vp, vp, vp, i64, vp, i64, vp]),
     "jmac_pair_cosine_fwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp]),
     "jmac_pair_cosine_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp]),
+    "jmac_pair_cosine_bwd_rows_f32": (C.c_int, [vp, i64, vp, i64, i64, i64, vp, vp, f32, vp, vp, vp, i64, i64, vp, i64, vp, i64, vp]),
+    "jmac_triple_l1_margin_bwd_exact2_f32": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp, vp, i64, i64, vp, vp,
+                                                       vp, i64, i32, vp, i64, i32, vp]),
+    "jmac_vec_mean_acc_f32": (C.c_int, [vp, i64, vp, vp, vp]),
+    "jmac_margin_loss_fwd_acc_f32": (C.c_int, [vp, i64, i64, vp, vp, vp, vp]),
     "jmac_margin_loss_fwd_f32": (C.c_int, [vp, i64, i64, vp, vp, vp]),
     "jmac_margin_loss_bwd_f32": (C.c_int, [vp, i64, i64, vp, vp, vp, vp]),
     "jmac_scatter_sum_f32": (C.c_int, [vp, vp, i64, i64, i64, vp, vp]),

@@ -380,6 +380,92 @@ __global__ __launch_bounds__(kBlock) void pair_cosine_bwd_sorted_kernel(const fl
     }
 }
 
+// The same reduction ROW by ROW (first writer of the whole gradient table: no zero fill by the caller): one wave per gradient row
+// over [0, n1 + n2) -- rows [0, n1) live in de1, rows [n1, n1 + n2) in de2 (n2 = 0 when both sides share one table) --, rowptr
+// [n1 + n2 + 1] = first sorted position of every row's run.  A row no pair touches is written as zeros.  The incoming gradient is a
+// vector gdist [L] or (gscalar != nullptr) the scalar gscalar[0] / gscale for every pair: the mean over the pairs, no expand / div
+// launch (alignment_loss_simple's .mean(), src/jmac_model.py:249).
+__global__ __launch_bounds__(kBlock) void pair_cosine_bwd_rows_kernel(const float* __restrict__ e1, int64_t ld1,
+                                                                      const float* __restrict__ e2, int64_t ld2, int d,
+                                                                      const float* __restrict__ gdist, const float* __restrict__ gscalar,
+                                                                      float gscale, const float* __restrict__ stats,
+                                                                      const int4* __restrict__ rec, const int32_t* __restrict__ rowptr,
+                                                                      int64_t n1, int64_t n2, float* __restrict__ de1, int64_t ldd1,
+                                                                      float* __restrict__ de2, int64_t ldd2) {
+    const int lane = lane_id();
+    const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * kWavesPerBlock;
+    const float gs = gscalar ? gscalar[0] / gscale : 0.f;          // (a division, like the mean's own backward: the same bits)
+    constexpr int NKM = 8;                                             // d <= 512
+    for (int64_t row = w0; row < n1 + n2; row += nw) {
+        const int p0 = rowptr[row], p1 = rowptr[row + 1];
+        float* dst = row < n1 ? de1 + row * ldd1 : de2 + (row - n1) * ldd2;
+        float acc[NKM];
+#pragma unroll
+        for (int k = 0; k < NKM; ++k) acc[k] = 0.f;
+        if (p1 > p0) {                                                 // wave-uniform
+            int4 rc = rec[p0];
+            const float* own = ((unsigned)rc.w & kRecSide) ? e2 + (int64_t)rc.y * ld2 : e1 + (int64_t)rc.y * ld1;
+            float ow[NKM];
+#pragma unroll
+            for (int k = 0; k < NKM; ++k) {
+                const int c = lane + 64 * k;
+                ow[k] = c < d ? own[c] : 0.f;
+            }
+            for (int q = p0; q < p1; ++q) {                            // the run in sorted order: the sums of the sorted form, bit for bit
+                const int4 nx = rec[q + 1 < p1 ? q + 1 : q];
+                const bool side = ((unsigned)rc.w & kRecSide) != 0;
+                const float* partner = side ? e1 + (int64_t)rc.z * ld1 : e2 + (int64_t)rc.z * ld2;
+                const float4 st = *reinterpret_cast<const float4*>(stats + 4 * (int64_t)rc.x);
+                const float g = -(gscalar ? gs : gdist[rc.x]);
+                float pr[NKM];
+#pragma unroll
+                for (int k = 0; k < NKM; ++k) {
+                    const int c = lane + 64 * k;
+                    pr[k] = c < d ? partner[c] : 0.f;
+                }
+                const float ra = sqrtf(st.y), rb = sqrtf(st.z);
+                const float na = fmaxf(ra, kNormEps), nb = fmaxf(rb, kNormEps);
+                const float inv = 1.f / (na * nb);
+                const float c_ = st.x * inv;
+                const float kself = side ? (rb > kNormEps ? c_ / (nb * nb) : 0.f) : (ra > kNormEps ? c_ / (na * na) : 0.f);
+#pragma unroll
+                for (int k = 0; k < NKM; ++k) acc[k] += g * (pr[k] * inv - kself * ow[k]);
+                rc = nx;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NKM; ++k) {
+            const int c = lane + 64 * k;
+            if (c < d) dst[c] = acc[k];
+        }
+    }
+}
+
+// EXACT margin backward on PERSISTENT count tables (jmac_triple_l1_margin_bwd_exact2_f32): out (+)= cnt * u, cnt = 0.  The count
+// tables start at zero and every call leaves them at zero again, so no caller ever zero-fills a gradient table for the atomics:
+// the pass that scales the integers anyway also writes the output (first writer, or on top of what `accumulate` says is there)
+__global__ __launch_bounds__(kBlock) void scale_clear_flat2_kernel(float4* __restrict__ cnt_a, float4* __restrict__ out_a, int64_t na4,
+                                                                   float4* __restrict__ cnt_b, float4* __restrict__ out_b, int64_t nb4,
+                                                                   const float* __restrict__ gloss, float inv_2bk, int acc_a, int acc_b) {
+    const float u = gloss[0] * inv_2bk;
+    const int64_t total = na4 + nb4;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const bool in_a = i < na4;
+        float4* pc = in_a ? cnt_a + i : cnt_b + (i - na4);
+        float4* po = in_a ? out_a + i : out_b + (i - na4);
+        const float4 c = *pc;
+        float4 v = make_float4(c.x * u, c.y * u, c.z * u, c.w * u);
+        if (in_a ? acc_a : acc_b) {                 // two roundings (no fma contraction): the bits of "scale, then add the tables"
+            const float4 o = *po;
+            v.x = __fadd_rn(__fmul_rn(c.x, u), o.x); v.y = __fadd_rn(__fmul_rn(c.y, u), o.y);
+            v.z = __fadd_rn(__fmul_rn(c.z, u), o.z); v.w = __fadd_rn(__fmul_rn(c.w, u), o.w);
+        }
+        *po = v;
+        if (c.x != 0.f || c.y != 0.f || c.z != 0.f || c.w != 0.f) *pc = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 inline unsigned wave_grid(int64_t units) {
     int64_t b = (units + kWavesPerBlock - 1) / kWavesPerBlock;
     if (b < 1) b = 1;
@@ -412,7 +498,8 @@ inline bool vec_ok(int64_t d, std::initializer_list<int64_t> lds, std::initializ
 // in a fixed order (bitwise reproducible).  torch.max(a, b) hands a tie half of the gradient: kept.
 constexpr int kMarginBlock = 1024;
 __global__ __launch_bounds__(kMarginBlock) void margin_loss_fwd_kernel(const float* __restrict__ score, int B, int K,
-                                                                        const float* __restrict__ gamma_p, float* __restrict__ loss) {
+                                                                        const float* __restrict__ gamma_p, const float* __restrict__ add_to,
+                                                                        float* __restrict__ loss) {
     __shared__ float red[kMarginBlock];
     const float gamma = gamma_p[0];
     float acc = 0.f;
@@ -438,7 +525,28 @@ __global__ __launch_bounds__(kMarginBlock) void margin_loss_fwd_kernel(const flo
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = red[0] / (float)total + gamma;
+    if (threadIdx.x == 0) loss[0] = (red[0] / (float)total + gamma) + (add_to ? add_to[0] : 0.f);   // add_to: the running loss of the step
+}
+
+// out[0] = mean(x[0 .. n)) (+ add_to[0]): the mean over the pairs of alignment_loss_simple (src/jmac_model.py:249) and the sum
+// with the step's running loss in one launch, fixed summation order (one block; n ~ 10^3)
+__global__ __launch_bounds__(kMarginBlock) void vec_mean_acc_kernel(const float* __restrict__ x, int64_t n, const float* __restrict__ add_to,
+                                                                     float* __restrict__ out) {
+    __shared__ float red[kMarginBlock];
+    float acc = 0.f;
+    int64_t i = threadIdx.x;
+    for (; i + 3 * kMarginBlock < n; i += 4 * kMarginBlock) {
+        const float a = x[i], b = x[i + kMarginBlock], c = x[i + 2 * kMarginBlock], e = x[i + 3 * kMarginBlock];
+        acc += a; acc += b; acc += c; acc += e;
+    }
+    for (; i < n; i += kMarginBlock) acc += x[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kMarginBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] / (float)n + (add_to ? add_to[0] : 0.f);
 }
 
 // dscore[b] = g/(BK) sum_k w_{b,k};  dscore[B + k*B + b] = -g/(BK) w_{b,k};  w = 1 (diff > -gamma), 1/2 (tie), 0
@@ -627,10 +735,65 @@ int jmac_pair_cosine_bwd_f32(const float* e1, int64_t ld1, const float* e2, int6
     return (int)hipGetLastError();
 }
 
-int jmac_margin_loss_fwd_f32(const float* score, int64_t B, int64_t K, const float* gamma, float* loss, jmac_stream_t stream) {
+int jmac_margin_loss_fwd_acc_f32(const float* score, int64_t B, int64_t K, const float* gamma, const float* add_to, float* loss,
+                                 jmac_stream_t stream) {
     if (B <= 0 || K <= 0 || B >= INT32_MAX || K >= INT32_MAX) return JMAC_EINVAL;
     if (!score || !gamma || !loss) return JMAC_EINVAL;
-    hipLaunchKernelGGL(margin_loss_fwd_kernel, dim3(1), dim3(kMarginBlock), 0, (hipStream_t)stream, score, (int)B, (int)K, gamma, loss);
+    hipLaunchKernelGGL(margin_loss_fwd_kernel, dim3(1), dim3(kMarginBlock), 0, (hipStream_t)stream, score, (int)B, (int)K, gamma, add_to,
+                       loss);
+    return (int)hipGetLastError();
+}
+
+int jmac_margin_loss_fwd_f32(const float* score, int64_t B, int64_t K, const float* gamma, float* loss, jmac_stream_t stream) {
+    return jmac_margin_loss_fwd_acc_f32(score, B, K, gamma, nullptr, loss, stream);
+}
+
+int jmac_vec_mean_acc_f32(const float* x, int64_t n, const float* add_to, float* out, jmac_stream_t stream) {
+    if (n <= 0 || !x || !out) return JMAC_EINVAL;
+    hipLaunchKernelGGL(vec_mean_acc_kernel, dim3(1), dim3(kMarginBlock), 0, (hipStream_t)stream, x, n, add_to, out);
+    return (int)hipGetLastError();
+}
+
+int jmac_pair_cosine_bwd_rows_f32(const float* e1, int64_t ld1, const float* e2, int64_t ld2, int64_t L, int64_t d, const float* gdist,
+                                  const float* gscalar, float gscale, const float* stats, const int32_t* rec, const int32_t* rowptr,
+                                  int64_t n1, int64_t n2, float* de1, int64_t ldd1, float* de2, int64_t ldd2, jmac_stream_t stream) {
+    if (L < 0 || d <= 0 || n1 < 0 || n2 < 0) return JMAC_EINVAL;
+    if (d > 512) return JMAC_EDIM;
+    if (n1 + n2 == 0) return JMAC_OK;
+    if (2 * L >= INT32_MAX) return JMAC_ERANGE;
+    if (!e1 || !e2 || (!gdist && !gscalar) || !rowptr || !de1 || (n2 > 0 && !de2)) return JMAC_EINVAL;
+    if (L > 0 && (!stats || !rec || ((uintptr_t)rec & 15) || ((uintptr_t)stats & 15))) return JMAC_EINVAL;
+    hipLaunchKernelGGL(pair_cosine_bwd_rows_kernel, dim3(wave_grid(n1 + n2)), dim3(kBlock), 0, (hipStream_t)stream, e1, ld1, e2, ld2, (int)d,
+                       gdist, gscalar, gscale, stats, reinterpret_cast<const int4*>(rec), rowptr, n1, n2, de1, ldd1, de2 ? de2 : de1, ldd2);
+    return (int)hipGetLastError();
+}
+
+int jmac_triple_l1_margin_bwd_exact2_f32(const float* ent, int64_t lde, const float* rel, int64_t ldr, const int64_t* h, const int64_t* r,
+                                         const int64_t* t, int64_t B, int64_t K, int64_t d, const float* score, const float* gamma,
+                                         const float* gloss, int64_t ent_off, int64_t rel_off, float* cnt_ent, float* cnt_rel,
+                                         float* dent, int64_t rows_ent, int32_t acc_ent, float* drel, int64_t rows_rel, int32_t acc_rel,
+                                         jmac_stream_t stream) {
+    if (B <= 0 || K <= 0 || d <= 0 || B >= INT32_MAX || K >= INT32_MAX || rows_ent <= 0 || rows_rel <= 0 || ent_off < 0 || rel_off < 0 ||
+        ent_off >= rows_ent || rel_off >= rows_rel)
+        return JMAC_EINVAL;
+    if (d > 512 || d % 4) return JMAC_EDIM;
+    if (!ent || !rel || !h || !r || !t || !score || !gamma || !gloss || !cnt_ent || !cnt_rel || !dent || !drel) return JMAC_EINVAL;
+    if ((((uintptr_t)cnt_ent | (uintptr_t)cnt_rel | (uintptr_t)dent | (uintptr_t)drel) & 15) != 0) return JMAC_EINVAL;
+    if (4 * B * K >= (1LL << 24)) return JMAC_ERANGE;       // a row's integer sum could leave fp32's exact range (callers: the plain form)
+    const int64_t T = B * (K + 1), period = B;
+    hipStream_t st = (hipStream_t)stream;
+    const int nk = (int)((d + 63) / 64);
+    const int parts = run_parts(T, period);
+    // the integer contributions go into the count tables (dense, pitch d) at the window the ids are local to
+    JMAC_DISPATCH_NK(nk, hipLaunchKernelGGL((triple_l1_bwd_kernel<NK, true, true>), dim3(wave_grid(period * parts)), dim3(kBlock), 0, st,
+                                            ent, lde, rel, ldr, h, r, t, T, period, parts, (int)d, score, cnt_ent + ent_off * d, d,
+                                            cnt_rel + rel_off * d, d, MarginArgs{gamma, gloss, B, K}));
+    const int64_t na4 = rows_ent * d / 4, nb4 = rows_rel * d / 4;
+    int64_t blocks = (na4 + nb4 + kBlock - 1) / kBlock;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(scale_clear_flat2_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, reinterpret_cast<float4*>(cnt_ent),
+                       reinterpret_cast<float4*>(dent), na4, reinterpret_cast<float4*>(cnt_rel), reinterpret_cast<float4*>(drel), nb4, gloss,
+                       1.f / (2.f * (float)B * (float)K), (int)acc_ent, (int)acc_rel);
     return (int)hipGetLastError();
 }
 

@@ -295,6 +295,33 @@ def _norm_drop_bwd(x, inv, drop, g, gx, accumulate):
 
 _TRACKERS = None      # list while an encoder node's forward runs: the num_batches_tracked buffers to bump at its end
 
+# The encoder nodes hand their table inputs (comp_att, rel_comp) back as OUTPUTS (aliases: layer 0 of the completion layers, src/
+# jmac_model.py:176,187), so that what the losses differentiate with respect to layer 0 arrives at the node's backward instead of
+# at the leaf -- and the node adds its own input gradient onto that buffer in the kernels that produce it (addmm_ / accumulate
+# epilogues) instead of autograd adding two [N, d] tensors afterwards.  Only a buffer one of this library's loss ops has just
+# allocated and marked (jmac_amd.losses: ``_jmac_fresh_grad``) is written in place; any other incoming gradient (a sum the engine
+# formed, a user's tensor) is left alone and returned beside the node's own, as before.
+INPLACE_GRADS = True
+INPLACE_COUNT = 0         # tests: how many incoming gradient buffers a backward took over
+
+
+def _take_grad(g, shape):
+    """``g`` if this backward may accumulate onto it in place, else None."""
+    global INPLACE_COUNT
+    if (INPLACE_GRADS and g is not None and getattr(g, "_jmac_fresh_grad", False) and g.dtype == torch.float32 and g.is_contiguous()
+            and tuple(g.shape) == tuple(shape)):
+        g._jmac_fresh_grad = False
+        INPLACE_COUNT += 1
+        return g
+    return None
+
+
+def _plus(own, extra):
+    """own + extra for a gradient the node could not take over (None-aware)."""
+    if extra is None:
+        return own
+    return extra if own is None else own + extra
+
 
 def _bump_trackers(trackers) -> None:
     if trackers:
@@ -794,10 +821,10 @@ class _EncoderName(torch.autograd.Function):
         rel_c1, t.mlc.out, t.sc.y = t.mlc.out, None, None
         ctx.t, ctx.cfg, ctx.dims = t, cfg, (N, d, di)
         ctx.save_for_backward(E, Rc, Ra, NL, U11, U21, Wall, L11, L12, L11u, L12u, c1)
-        return align_out, c1, rel_c1
+        return align_out, c1, rel_c1, E, Rc            # E, Rc: layer 0 of the completion layers, as aliases (see INPLACE_GRADS)
 
     @staticmethod
-    def backward(ctx, g_align, g_c1, g_relc1):
+    def backward(ctx, g_align, g_c1, g_relc1, g_E0, g_Rc0):
         t, cfg = ctx.t, ctx.cfg
         N, d, di = ctx.dims
         E, Rc, Ra, NL, U11, U21, Wall, L11, L12, L11u, L12u, c1 = ctx.saved_tensors
@@ -840,8 +867,12 @@ class _EncoderName(torch.autograd.Function):
                 gy2 = g_c1.contiguous() if g_c1 is not None else None
             else:
                 gy = g_c1.contiguous()
-            dE = _empty(dev, N, d)
-            dRRc, dwcc, dac, gbwc = _layer_bwd(sc, graph, gy, gy2, dE, False)
+            taken = _take_grad(g_E0, (N, d))           # the layer-0 loss gradient: this node's input gradient goes on top of it
+            if taken is not None:
+                dE, g_E0 = taken, None
+            else:
+                dE = _empty(dev, N, d)
+            dRRc, dwcc, dac, gbwc = _layer_bwd(sc, graph, gy, gy2, dE, taken is not None)
         if have_align:
             # conv1_alignment: its output fed cat1 and catA -> two gradient sources; its input is align0 = catA[:, :d]
             d_align0 = dcatA[:, :d]
@@ -857,18 +888,24 @@ class _EncoderName(torch.autograd.Function):
             levels[0].extend([gemm_task(dw[d:], U11[d:], dNL, tb=True, defer=True), gemm_task(NL, dw[d:], dU11[d:], ta=True, defer=True)])
         # ---- relation side.  The chains' relation gradients land in COMPACT buffers (the rows the edges name) and are put back
         # into full tables by one expand launch; rel_c1's MLP (an output: all rows) writes the full d rel_comp directly
+        wrote_c, dRc_full = False, None
         if have_align or g_relc1 is not None or have_c:
             rc = t.rc
             dRa_u = _empty(dev, rc.n, d) if have_align else None
-            dRc_full = _empty(dev, *Rc.shape) if (g_relc1 is not None or (have_c and not rc.on)) else None
+            # d rel_comp: the layer-0 loss gradient's buffer where this backward may take it over (every writer below then adds)
+            dRc_full = _take_grad(g_Rc0, Rc.shape)
+            wrote_c = dRc_full is not None                                        # "the full buffer holds a contribution"
+            if wrote_c:
+                g_Rc0 = None
+            elif g_relc1 is not None or (have_c and not rc.on):
+                dRc_full = _empty(dev, *Rc.shape)
             dRc_u = (_empty(dev, rc.n, d) if rc.on else dRc_full) if have_c else None
             if have_align:
                 cga = add(0, t.cha.bwd_tasks(dRRa, dwca, dRa_u, False))          # levels 0-1 -> d rel_align (first writer)
                 lv2, cg2, (gL11u, gL12u) = t.ch2.bwd_tasks(dRR2, dwc2, dRa_u, True)     # levels 0-2; d rel_align += at level 2
                 add(0, (lv2, None))
-            wrote_c = False
             if g_relc1 is not None:                                               # rel_c1 = MLP(rel_comp) needs only the loss' gradient:
-                gL11, gL12 = add(0, t.mlc.bwd_tasks(g_relc1.contiguous(), dRc_full, False))   # levels 0-1 -> d rel_comp (first writer)
+                gL11, gL12 = add(0, t.mlc.bwd_tasks(g_relc1.contiguous(), dRc_full, wrote_c))  # levels 0-1 -> d rel_comp
                 wrote_c = True
             if have_c:
                 if rc.on:                            # own buffer: no ordering against the MLP's write
@@ -892,6 +929,9 @@ class _EncoderName(torch.autograd.Function):
         if have_c:
             gc = _layer_grads(cgc, cut[-1], dac, gbwc, d)
         t.cat0_lease.release()
+        if dRc is None and wrote_c:                    # nothing but the taken-over layer-0 gradient
+            dRc = dRc_full
+        dE, dRc = _plus(dE, g_E0), _plus(dRc, g_Rc0)   # layer-0 gradients this backward could not take over: added here
         return (None, dE, dRc, dRa, None, dNL, dU11, dU21, dWall, gL11, gL12, gL11u, gL12u, *ga, *gc, *g2)
 
 
@@ -924,10 +964,10 @@ class _EncoderNoName(torch.autograd.Function):
         rel_c1, t.mlc.out, t.sc.y = t.mlc.out, None, None
         ctx.t, ctx.cfg, ctx.dims = t, cfg, (N, d)
         ctx.save_for_backward(E, Rc, L11, L12, c1)
-        return c1, rel_c1
+        return c1, rel_c1, E, Rc                         # E, Rc: layer 0 of the completion layers, as aliases (see INPLACE_GRADS)
 
     @staticmethod
-    def backward(ctx, g_c1, g_relc1):
+    def backward(ctx, g_c1, g_relc1, g_E0, g_Rc0):
         t, cfg = ctx.t, ctx.cfg
         N, d = ctx.dims
         E, Rc, L11, L12, c1 = ctx.saved_tensors
@@ -938,23 +978,33 @@ class _EncoderNoName(torch.autograd.Function):
         gc = [None] * 8
         levels: List[List[GemmTask]] = [[] for _ in range(5)]
         rc = t.rc
-        dRc_full = _empty(dev, *Rc.shape) if (g_relc1 is not None or not rc.on) else None
+        # d rel_comp: the layer-0 loss gradient's buffer where this backward may take it over (every writer below then adds)
+        dRc_full = _take_grad(g_Rc0, Rc.shape)
+        took_rc = dRc_full is not None
+        if took_rc:
+            g_Rc0 = None
+        elif g_relc1 is not None or not rc.on:
+            dRc_full = _empty(dev, *Rc.shape)
         dRc_u = _empty(dev, rc.n, d) if rc.on else dRc_full
-        wrote = False
+        wrote = False                                        # the chain wrote dRc_u
         if g_c1 is not None:
-            dE = _empty(dev, N, d)
-            dRRc, dwcc, dac, gbwc = _layer_bwd(sc, cfg.graph, g_c1.contiguous(), None, dE, False)
-            lv, cgc = t.chc.bwd_tasks(dRRc, dwcc, dRc_u, False)
+            taken = _take_grad(g_E0, (N, d))
+            if taken is not None:
+                dE, g_E0 = taken, None
+            else:
+                dE = _empty(dev, N, d)
+            dRRc, dwcc, dac, gbwc = _layer_bwd(sc, cfg.graph, g_c1.contiguous(), None, dE, taken is not None)
+            lv, cgc = t.chc.bwd_tasks(dRRc, dwcc, dRc_u, took_rc and not rc.on)
             for i, l in enumerate(lv):
                 levels[i].extend(l)
             wrote = True
         gL11 = gL12 = None
-        wrote_full = False
+        wrote_full = took_rc                                 # the full buffer holds a contribution
         if g_relc1 is not None:
-            first = rc.on or not wrote                       # compact: the MLP has the full buffer to itself
+            first = (rc.on or not wrote) and not took_rc     # compact: the MLP has the full buffer to itself
             lv, (gL11, gL12) = t.mlc.bwd_tasks(g_relc1.contiguous(), dRc_full, not first)
             for i, l in enumerate(lv):
-                levels[(0 if first else 2) + i].extend(l)
+                levels[(0 if (rc.on or not wrote) else 2) + i].extend(l)
             wrote_full = True
         run_levels(levels)
         if rc.on and wrote:
@@ -965,7 +1015,7 @@ class _EncoderNoName(torch.autograd.Function):
         if g_c1 is not None:
             gc = _layer_grads(cgc, _wcat_unpack([dwcc], d)[0], dac, gbwc, d)
         dRc = dRc_buf if wrote else None
-        return (None, dE, dRc, gL11, gL12, *gc)
+        return (None, _plus(dE, g_E0), _plus(dRc, g_Rc0), gL11, gL12, *gc)
 
 
 def _cfg(model, layers, graph):
@@ -978,7 +1028,7 @@ def _cfg(model, layers, graph):
 
 def forward_name(model, comp_att, rel_comp, rel_align, info, graph: RelGraph, seg: Optional[RowBlocks] = None,
                  info_persistent: bool = False):
-    """(align_out, c1, rel_c1) of JMAC.forward_name on the fused node.  ``seg``: the rows are a stack of KGs (``graph`` their
+    """(align_out, c1, rel_c1, comp0, rel0) of JMAC.forward_name on the fused node.  ``seg``: the rows are a stack of KGs (``graph`` their
     block-diagonal union, the relation tables stacked likewise): BatchNorm statistics per block.  ``info_persistent``: the
     caller keeps ``info`` (a device tensor) alive and unchanged between calls -- its cat buffer may be cached."""
     la, lc, l2 = model.conv1_alignment, model.conv1_completion, model.conv2_alignment
@@ -986,6 +1036,8 @@ def forward_name(model, comp_att, rel_comp, rel_align, info, graph: RelGraph, se
     cfg.training = la.training                                           # BatchNorm follows the layers' own mode
     cfg.cache = model.__dict__.setdefault("_encoder_cache", {})          # buffers that outlive a step (see _Cat0Slot)
     cfg.seg, cfg.info_persistent = seg, bool(info_persistent)
+    # -> (align_out, c1, rel_c1, comp0, rel0): comp0 / rel0 alias comp_att / rel_comp -- hand THEM on as layer 0 of the completion
+    # layers, so that the layer-0 loss gradient reaches this node's backward (see INPLACE_GRADS)
     return _EncoderName.apply(cfg, comp_att, rel_comp, rel_align, info, model.name_linear, model.uni_linear1_1,
                               model.uni_linear2_1, model.all_linear_completion, model.rel_linear11, model.rel_linear12,
                               model.rel_linear11_uni, model.rel_linear12_uni, *_layer_inputs(la), *_layer_inputs(lc),
@@ -993,7 +1045,7 @@ def forward_name(model, comp_att, rel_comp, rel_align, info, graph: RelGraph, se
 
 
 def forward_no_name(model, comp_att, rel_comp, graph: RelGraph, seg: Optional[RowBlocks] = None):
-    """(c1, rel_c1) of JMAC.forward_no_name on the fused node."""
+    """(c1, rel_c1, comp0, rel0) of JMAC.forward_no_name on the fused node (comp0 / rel0: aliases of the inputs, as above)."""
     lc = model.conv1_completion
     cfg = _cfg(model, (lc,), graph)
     cfg.training = lc.training

@@ -12,6 +12,14 @@ import torch
 from ._lib import check, check_index_range, lib, ptr, require_device, stream
 
 
+def _fresh(*grads) -> None:
+    """Mark gradient buffers this op has just allocated and hands to autograd: the encoder nodes (jmac_amd.encoder._take_grad) may
+    add their own contribution to such a buffer in place instead of letting autograd add two [N, d] tensors."""
+    for g in grads:
+        if g is not None:
+            g._jmac_fresh_grad = True
+
+
 def _rows(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise TypeError("jmac_amd losses compute in fp32 (got %s)" % t.dtype)
@@ -69,19 +77,23 @@ def triple_l1_score(ent: torch.Tensor, rel: torch.Tensor, h: torch.Tensor, r: to
 
 _PAIR_INDEX: dict = {}
 _PAIR_INDEX_CAP = 64
+_PAIR_PINNED: dict = {}        # entries a stream capture used (strong references; never evicted)
 
 
-def _pair_index(i1: torch.Tensor, i2: torch.Tensor, off1: int, off2: int, same: bool):
-    """rec int32 [2L, 4] of jmac_pair_cosine_bwd_sorted_f32: the (pair, side) incidences sorted by the gradient row they touch,
+def _pair_index(i1: torch.Tensor, i2: torch.Tensor, off1: int, off2: int, same: bool, n1: int = 0, n2: int = 0):
+    """(rec, rowptr).  rec int32 [2L, 4] of jmac_pair_cosine_bwd_{sorted,rows}_f32: the (pair, side) incidences sorted by the gradient row they touch,
     built ONCE per pair of index tensors (identity + version, weak references) -- the seed links of a KG pair are the same
     tensors for every batch of an epoch (train.py:347-352), the mined negatives until the next refresh -- like the CSR of a
     graph.  ``off1`` / ``off2``: first row of the windows the ids are local to; ``same``: both sides share one gradient table.
     Inside a stream capture an unseen pair is sorted inside the capture (and not remembered: those tensors belong to the
-    graph's pool)."""
+    graph's pool).  rowptr int32 [n1 + n2 + 1] (the rows form: n1 rows of the first gradient table, n2 of the second, 0 when both
+    sides share one): first sorted position of every gradient row's run."""
     import weakref
-    key = (id(i1), id(i2), int(off1), int(off2), bool(same))
+    key = (id(i1), id(i2), int(off1), int(off2), bool(same), int(n1), int(n2))
     hit = _PAIR_INDEX.get(key)
     if hit is not None and hit[0]() is i1 and hit[1]() is i2 and hit[2] == (i1._version, i2._version):
+        if torch.cuda.is_current_stream_capturing():           # a captured graph bakes these pointers in: the entry (and the index
+            _PAIR_PINNED[key] = (i1, i2, hit[3])               # tensors its key names) must outlive every eviction
         return hit[3]
     L = i1.numel()
     big = 1 << 40                                               # side-1 rows of a second table sort behind every side-0 row
@@ -98,6 +110,13 @@ def _pair_index(i1: torch.Tensor, i2: torch.Tensor, off1: int, off2: int, same: 
     rec = torch.stack((x, own, partner, flags), dim=1)
     rec = (rec & 0xFFFFFFFF).to(torch.int64)
     rec = torch.where(rec >= (1 << 31), rec - (1 << 32), rec).to(torch.int32).contiguous()      # two's-complement int32 words
+    rowptr = None
+    if n1 + n2 > 0:                                            # sorted positions are ordered by (table, row): a CSR pointer over them
+        tkey = row if same else torch.where(side, row + n1, row)
+        rowptr = torch.zeros(n1 + n2 + 1, dtype=torch.int64, device=rec.device)
+        rowptr[1:] = torch.cumsum(torch.bincount(tkey, minlength=n1 + n2), 0)
+        rowptr = rowptr.to(torch.int32)
+    rec = (rec, rowptr)
     if not torch.cuda.is_current_stream_capturing():
         if int(row.max()) >= (1 << 29):
             raise ValueError("pair cosine backward: gradient rows beyond 2^29")
@@ -140,21 +159,87 @@ class _PairCosine(torch.autograd.Function):
         off1, off2 = ctx.offs
         L, d = i1.numel(), e1.shape[1]
         g = g.contiguous()
-        de1 = torch.zeros((e1.shape[0], d), dtype=torch.float32, device=e1.device)
         # both sides gathered from ONE table (pairs inside a KG, or two blocks of one stacked table): one gradient buffer --
-        # no second zero-fill, no add of the two halves afterwards
+        # no add of the two halves afterwards
         same = ctx.same_table and e1.data_ptr() == e2.data_ptr()
-        de2 = de1 if same else torch.zeros((e2.shape[0], d), dtype=torch.float32, device=e1.device)
         if ctx.stats is not None and L > 0:
-            # deterministic: incidences sorted by gradient row (once per index tensor pair), every touched row written once
-            rec = _pair_index(i1, i2, off1, off2, same)
-            check(lib().jmac_pair_cosine_bwd_sorted_f32(_wptr(e1, off1), e1.stride(0), _wptr(e2, off2), e2.stride(0), L, d, ptr(g),
-                                                        ptr(ctx.stats), ptr(rec), ptr(de1), d, ptr(de2), d, stream()),
-                  "jmac_pair_cosine_bwd_sorted_f32")
-        else:                                          # d > 512: the atomic form (order-dependent sums)
+            # deterministic: incidences sorted by gradient row (once per index tensor pair); one wave per gradient ROW writes it
+            # once (zeros where no pair touches it): no zero fill of the tables
+            de1, de2 = _pair_cosine_rows_bwd(e1, e2, i1, i2, off1, off2, same, ctx.stats, g, None, 0.0)
+            return de1, (None if same else de2), None, None, None, None
+        de1 = torch.zeros((e1.shape[0], d), dtype=torch.float32, device=e1.device)
+        de2 = de1 if same else torch.zeros((e2.shape[0], d), dtype=torch.float32, device=e1.device)
+        if L > 0:                                      # d > 512: the atomic form (order-dependent sums)
             check(lib().jmac_pair_cosine_bwd_f32(_wptr(e1, off1), e1.stride(0), _wptr(e2, off2), e2.stride(0), ptr(i1), ptr(i2), L, d,
                                                  ptr(g), _wptr(de1, off1), d, _wptr(de2, off2), d, stream()), "jmac_pair_cosine_bwd_f32")
         return de1, (None if same else de2), None, None, None, None
+
+
+def _pair_cosine_rows_bwd(e1, e2, i1, i2, off1, off2, same, stats, gvec, gscalar, gscale, de1=None):
+    """jmac_pair_cosine_bwd_rows_f32 -> (de1, de2): every row of the gradient table(s) written exactly once."""
+    L, d = i1.numel(), e1.shape[1]
+    n1, n2 = int(e1.shape[0]), (0 if same else int(e2.shape[0]))
+    rec, rowptr = _pair_index(i1, i2, off1, off2, same, n1, n2)
+    if de1 is None:
+        de1 = torch.empty((n1, d), dtype=torch.float32, device=e1.device)
+    de2 = de1 if same else torch.empty((n2, d), dtype=torch.float32, device=e1.device)
+    check(lib().jmac_pair_cosine_bwd_rows_f32(_wptr(e1, off1), e1.stride(0), _wptr(e2, off2), e2.stride(0), L, d, ptr(gvec), ptr(gscalar),
+                                              float(gscale), ptr(stats), ptr(rec), ptr(rowptr), n1, n2, ptr(de1), d,
+                                              ptr(de2) if not same else None, d, stream()), "jmac_pair_cosine_bwd_rows_f32")
+    return de1, de2
+
+
+class _PairCosineMean(torch.autograd.Function):
+    """mean_x (1 - cos(e1[i1[x]], e2[i2[x]])) (+ add_to) -> [1]: alignment_loss_simple (src/jmac_model.py:237-249) with the mean
+    and the sum with the step's running loss inside the op (no mean / add launch forward, no expand / div backward)."""
+
+    @staticmethod
+    def forward(ctx, e1, e2, i1, i2, off1, off2, add_to):
+        require_device(e1, e2, i1, i2)
+        ctx.same_table = e1 is e2
+        e1, e2 = _rows(e1), _rows(e2)
+        L, d = i1.numel(), e1.shape[1]
+        if e2.shape[1] != d or i2.numel() != L or L == 0 or d > 512:
+            raise ValueError("pair_cosine_mean: shapes disagree (or L == 0, d > 512)")
+        dev = e1.device
+        dist = torch.empty(L, dtype=torch.float32, device=dev)
+        stats = torch.empty((L, 4), dtype=torch.float32, device=dev)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        check(lib().jmac_pair_cosine_fwd_stats_f32(_wptr(e1, off1), e1.stride(0), _wptr(e2, off2), e2.stride(0), ptr(i1), ptr(i2), L,
+                                                   d, ptr(dist), ptr(stats), stream()), "jmac_pair_cosine_fwd_stats_f32")
+        check(lib().jmac_vec_mean_acc_f32(ptr(dist), L, ptr(add_to), ptr(out), stream()), "jmac_vec_mean_acc_f32")
+        ctx.save_for_backward(e1, e2, i1, i2, stats)
+        ctx.offs, ctx.has_add = (off1, off2), add_to is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        e1, e2, i1, i2, stats = ctx.saved_tensors
+        off1, off2 = ctx.offs
+        g = g.contiguous()
+        same = ctx.same_table and e1.data_ptr() == e2.data_ptr()
+        need = ctx.needs_input_grad
+        de1 = de2 = None
+        if need[0] or need[1]:
+            de1, de2 = _pair_cosine_rows_bwd(e1, e2, i1, i2, off1, off2, same, stats, None, g, float(i1.numel()))
+            _fresh(de1, None if same else de2)
+        return de1, (None if same else de2), None, None, None, None, (g if ctx.has_add else None)
+
+
+def pair_cosine_mean(e1: torch.Tensor, i1: torch.Tensor, e2: torch.Tensor, i2: torch.Tensor, win1=None, win2=None,
+                     add_to: torch.Tensor = None) -> torch.Tensor:
+    """``pair_cosine_distance(e1, i1, e2, i2, win1, win2).mean() (+ add_to)`` -> [1] as one node (``add_to``: a one-element
+    fp32 device tensor, the step's running loss)."""
+    dev = e1.device
+    off1, n1 = _win(e1, win1)
+    off2, n2 = _win(e2, win2)
+    i1, i2 = _index(i1, n1, dev), _index(i2, n2, dev)
+    if i1.numel() == 0 or e1.shape[1] > 512:
+        out = _PairCosine.apply(e1, e2, i1, i2, off1, off2).mean()
+        return out if add_to is None else out + add_to
+    if add_to is not None:
+        add_to = add_to.reshape(1)
+    return _PairCosineMean.apply(e1, e2, i1, i2, off1, off2, add_to)
 
 
 def pair_cosine_distance(e1: torch.Tensor, i1: torch.Tensor, e2: torch.Tensor, i2: torch.Tensor, win1=None,
@@ -240,6 +325,109 @@ class _TripleL1Margin(torch.autograd.Function):
                                                         _wptr(drel, roff), d, rn, stream()),
               "jmac_triple_l1_margin_bwd_exact_f32")
         return dent, drel, None, None, None, None, None, None, None, None, None, None
+
+
+_CNT: dict = {}               # (device, rows_ent, rows_rel, d) -> persistent count tables of the exact margin adjoint (always zero between calls)
+
+
+def _count_tables(dev, rows_e: int, rows_r: int, d: int):
+    """The zero-at-rest integer tables jmac_triple_l1_margin_bwd_exact2_f32 accumulates into (and clears again): one pair per
+    table shape, shared by every loss op of that shape on the device's stream.  Inside a stream capture an unseen shape gets
+    tables of its own (zero-filled inside the capture, not remembered: they belong to the graph's pool)."""
+    key = (str(dev), int(rows_e), int(rows_r), int(d))
+    hit = _CNT.get(key)
+    if hit is None:
+        hit = (torch.zeros((rows_e, d), dtype=torch.float32, device=dev), torch.zeros((rows_r, d), dtype=torch.float32, device=dev))
+        if not torch.cuda.is_current_stream_capturing():
+            _CNT[key] = hit
+    return hit
+
+
+class _LayerLoss(torch.autograd.Function):
+    """One layer's term of completion_loss (src/jmac_model.py:331-380) as ONE node:
+        loss = add_to + margin_loss(||ent[h] + rel[r] - ent[t]||_1) [+ mean_x (1 - cos(ent[c0[x]], ent[c1[x]]))]
+    (the bracket: alignment_loss_simple on the seed links, both sides windows of the same stacked table).  The backward writes
+    ONE gradient per table, each row exactly once: the cosine adjoint row by row (first writer, zeros where no link touches a
+    row), then the exact-integer L1 adjoint from its persistent count tables on top -- no zero fill, no add of two gradient
+    contributions, no scalar arithmetic launches."""
+
+    @staticmethod
+    def forward(ctx, ent, rel, h, r, t, margin, add_to, c0, c1, B, K, eoff, roff, coff0, coff1):
+        require_device(ent, rel, h, r, t, margin)
+        ent, rel = _rows(ent), _rows(rel)
+        T, d = h.numel(), ent.shape[1]
+        dev = ent.device
+        score = torch.empty(T, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        check(lib().jmac_triple_l1_fwd_f32(_wptr(ent, eoff), ent.stride(0), _wptr(rel, roff), rel.stride(0), ptr(h), ptr(r), ptr(t),
+                                           T, B, d, ptr(score), stream()), "jmac_triple_l1_fwd_f32")
+        check(lib().jmac_margin_loss_fwd_acc_f32(ptr(score), B, K, ptr(margin), ptr(add_to), ptr(loss), stream()),
+              "jmac_margin_loss_fwd_acc_f32")
+        stats = None
+        if c0 is not None:
+            L = c0.numel()
+            dist = torch.empty(L, dtype=torch.float32, device=dev)
+            stats = torch.empty((L, 4), dtype=torch.float32, device=dev)
+            total = torch.empty(1, dtype=torch.float32, device=dev)
+            check(lib().jmac_pair_cosine_fwd_stats_f32(_wptr(ent, coff0), ent.stride(0), _wptr(ent, coff1), ent.stride(0), ptr(c0), ptr(c1),
+                                                       L, d, ptr(dist), ptr(stats), stream()), "jmac_pair_cosine_fwd_stats_f32")
+            check(lib().jmac_vec_mean_acc_f32(ptr(dist), L, ptr(loss), ptr(total), stream()), "jmac_vec_mean_acc_f32")
+            loss = total
+        ctx.save_for_backward(ent, rel, h, r, t, score, margin, c0, c1, stats)
+        ctx.cfg = (B, K, eoff, roff, coff0, coff1, add_to is not None)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        ent, rel, h, r, t, score, margin, c0, c1, stats = ctx.saved_tensors
+        B, K, eoff, roff, coff0, coff1, has_add = ctx.cfg
+        d = ent.shape[1]
+        dev = ent.device
+        g = g.contiguous()
+        rows_e, rows_r = int(ent.shape[0]), int(rel.shape[0])
+        dent = torch.empty((rows_e, d), dtype=torch.float32, device=dev)
+        drel = torch.empty((rows_r, d), dtype=torch.float32, device=dev)
+        if c0 is not None:                             # first writer of dent: every row once, zeros where no link touches it
+            _pair_cosine_rows_bwd(ent, ent, c0, c1, coff0, coff1, True, stats, None, g, float(c0.numel()), de1=dent)
+        cnt_e, cnt_r = _count_tables(dev, rows_e, rows_r, d)
+        check(lib().jmac_triple_l1_margin_bwd_exact2_f32(_wptr(ent, eoff), ent.stride(0), _wptr(rel, roff), rel.stride(0), ptr(h), ptr(r),
+                                                         ptr(t), B, K, d, ptr(score), ptr(margin), ptr(g), eoff, roff, ptr(cnt_e),
+                                                         ptr(cnt_r), ptr(dent), rows_e, 1 if c0 is not None else 0, ptr(drel), rows_r, 0,
+                                                         stream()), "jmac_triple_l1_margin_bwd_exact2_f32")
+        _fresh(dent, drel)
+        return (dent, drel, None, None, None, None, (g if has_add else None), None, None, None, None, None, None, None, None)
+
+
+def completion_layer_loss(ent: torch.Tensor, rel: torch.Tensor, h: torch.Tensor, r: torch.Tensor, t: torch.Tensor, batch_size: int,
+                          margin: torch.Tensor, ent_win=None, rel_win=None, links=None, add_to: torch.Tensor = None) -> torch.Tensor:
+    """One layer's term of JMAC.completion_loss (src/jmac_model.py:331-380) -> [1]:
+    ``add_to + triple_l1_margin_loss(ent, rel, h, r, t, B, margin, ent_win, rel_win) [+ pair_cosine_distance(ent, c0, ent, c1,
+    win0, win1).mean()]`` with ``links = (c0, c1, win0, win1)`` (alignment_loss_simple on the seed links: both sides windows of
+    ``ent``), as ONE autograd node where the fused form covers the inputs (dense fp32 tables, d % 4 == 0, d <= 512, a batch of
+    B (K + 1) triples, a margin without gradient); the separate ops otherwise."""
+    dev = ent.device
+    T, B = int(h.numel()), int(batch_size)
+    eoff, en = _win(ent, ent_win)
+    roff, rn = _win(rel, rel_win)
+    d = ent.shape[1]
+    fused = (B > 0 and T > B and (T - B) % B == 0 and margin.numel() == 1 and not margin.requires_grad and d % 4 == 0 and d <= 512
+             and 4 * B * ((T - B) // B) < (1 << 24) and ent.dtype == torch.float32 and rel.dtype == torch.float32
+             and (links is None or links[0].numel() > 0))
+    if not fused:
+        out = triple_l1_margin_loss(ent, rel, h, r, t, B, margin, ent_win, rel_win)
+        if links is not None and links[0].numel() > 0:
+            out = out + pair_cosine_distance(ent, links[0], ent, links[1], links[2], links[3]).mean()
+        return out if add_to is None else out + add_to
+    c0 = c1 = None
+    coff0 = coff1 = 0
+    if links is not None:
+        coff0, n0 = _win(ent, links[2])
+        coff1, n1 = _win(ent, links[3])
+        c0, c1 = _index(links[0], n0, dev), _index(links[1], n1, dev)
+    if add_to is not None:
+        add_to = add_to.reshape(1)
+    return _LayerLoss.apply(ent, rel, _index(h, en, dev, "batch_h"), _index(r, rn, dev, "batch_r"), _index(t, en, dev, "batch_t"),
+                            margin.reshape(1).to(torch.float32), add_to, c0, c1, B, (T - B) // B, eoff, roff, coff0, coff1)
 
 
 def triple_l1_margin_loss(ent: torch.Tensor, rel: torch.Tensor, h: torch.Tensor, r: torch.Tensor, t: torch.Tensor,

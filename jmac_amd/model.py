@@ -159,8 +159,9 @@ class JMAC(nn.Module):
         if self._fused(self.ent_info_att.shape[1]):
             info = self._info_rows(((int(e0), int(e1)),), dev)
             graph = self._graph(edge_index, edge_type, comp_att.shape[0], rel_comp.shape[0])
-            align_out, c1, rel_c1 = encoder.forward_name(self, comp_att, rel_comp, rel_align, info, graph, info_persistent=True)
-            return align_out, [comp_att, c1], [rel_comp, rel_c1]
+            align_out, c1, rel_c1, comp0, rel0 = encoder.forward_name(self, comp_att, rel_comp, rel_align, info, graph,
+                                                                      info_persistent=True)
+            return align_out, [comp0, c1], [rel0, rel_c1]        # comp0 / rel0: comp_att / rel_comp through the node (aliases)
         comp0 = self.completion_dropout(ops.row_normalize(comp_att))
         # :177 + :180  cat(comp0, info @ name_linear) @ W  ==  cat(comp0, info) @ [W_top ; name_linear @ W_bottom]:
         # the [N,300]x[300,300] product of the constant name embeddings (and its [N,300]x[300,300] adjoint) becomes a
@@ -191,8 +192,8 @@ class JMAC(nn.Module):
         rel_comp = _rows(self.rel_init_att_completion, r0, r1)
         if self._fused(None):
             graph = self._graph(edge_index, edge_type, comp_att.shape[0], rel_comp.shape[0])
-            c1, rel_c1 = encoder.forward_no_name(self, comp_att, rel_comp, graph)
-            return c1, [comp_att, c1], [rel_comp, rel_c1]
+            c1, rel_c1, comp0, rel0 = encoder.forward_no_name(self, comp_att, rel_comp, graph)
+            return c1, [comp0, c1], [rel0, rel_c1]
         comp_layers, comp_rel_layers = [comp_att], [rel_comp]
         if self.args.num_gcn_layer == 2:
             comp_layers.append(self.conv1_completion(comp_att, rel_comp, edge_index, edge_type))
@@ -253,11 +254,11 @@ class JMAC(nn.Module):
         if name:
             rel_align = _stack_rows(self.rel_init_att_alignment, rranges)
             info = self._info_rows(tuple(eranges), dev)
-            align_out, c1, rel_c1 = encoder.forward_name(self, comp_att, rel_comp, rel_align, info, graph, seg=seg,
-                                                         info_persistent=True)
-            return Stacked(align_out, [comp_att, c1], [rel_comp, rel_c1], ent_win, rel_win)
-        c1, rel_c1 = encoder.forward_no_name(self, comp_att, rel_comp, graph, seg=seg)
-        return Stacked(c1, [comp_att, c1], [rel_comp, rel_c1], ent_win, rel_win)
+            align_out, c1, rel_c1, comp0, rel0 = encoder.forward_name(self, comp_att, rel_comp, rel_align, info, graph, seg=seg,
+                                                                      info_persistent=True)
+            return Stacked(align_out, [comp0, c1], [rel0, rel_c1], ent_win, rel_win)
+        c1, rel_c1, comp0, rel0 = encoder.forward_no_name(self, comp_att, rel_comp, graph, seg=seg)
+        return Stacked(c1, [comp0, c1], [rel0, rel_c1], ent_win, rel_win)
 
     def forward_blocks(self, blocks):
         """[forward_base(*b) for b in blocks] -- through ONE launch set where forward_stacked covers the configuration."""
@@ -366,24 +367,25 @@ class JMAC(nn.Module):
         links = feeddict["links"]
         st = self.forward_stacked([(edge_index1, edge_type1, feeddict["ent_bases1"], feeddict["rel_bases1"]),
                                    (edge_index2, edge_type2, feeddict["ent_bases2"], feeddict["rel_bases2"])])
-        loss = 0
+        loss = None
         if st is not None:                      # both KGs in one launch set; every gather addresses a window of a stacked table
             k = 0 if source else 1
             dev = st.comp[0].device
             cols = _link_columns(links, dev, st.ent_win[0][1], st.ent_win[1][1]) if len(links) else None
+            lk = (cols[0], cols[1], st.ent_win[0], st.ent_win[1]) if cols is not None else None
             for layer in range(self.args.num_gcn_layer):
-                ent, rel = st.comp[layer], st.rel[layer]
-                loss_res = losses.triple_l1_margin_loss(ent, rel, h, r, t, bs, self.margin_completion, st.ent_win[k], st.rel_win[k])
-                loss_align = (losses.pair_cosine_distance(ent, cols[0], ent, cols[1], st.ent_win[0], st.ent_win[1]).mean()
-                              if cols is not None else 0)                       # alignment_loss_simple (:237-249)
-                loss = loss + loss_res + loss_align
-            return loss
+                # one node per layer: the L1 scores (src/jmac_model.py:345-350), the margin ranking term (:351-378, the reference's
+                # n-major consumption of the b-major negative block kept), alignment_loss_simple on the links (:237-249) and the
+                # sum with the previous layer's term -- one gradient per table, no element-wise glue (losses.completion_layer_loss)
+                loss = losses.completion_layer_loss(st.comp[layer], st.rel[layer], h, r, t, bs, self.margin_completion, st.ent_win[k],
+                                                    st.rel_win[k], links=lk, add_to=loss)
+            return loss if loss is not None else 0
         _, comp1, rel1 = self.forward_base(edge_index1, edge_type1, feeddict["ent_bases1"], feeddict["rel_bases1"])
         _, comp2, rel2 = self.forward_base(edge_index2, edge_type2, feeddict["ent_bases2"], feeddict["rel_bases2"])
+        cols = (_link_columns(links, comp1[0].device, comp1[0].shape[0], comp2[0].shape[0]) if len(links) else None)
         for layer in range(self.args.num_gcn_layer):
             ent, rel = (comp1[layer], rel1[layer]) if source else (comp2[layer], rel2[layer])
-            # the L1 scores (src/jmac_model.py:345-350) and pos / neg views + max + mean (:351-378) as one node; the reference
-            # consumes the b-major negative block as n-major (view(-1, B).permute): kept as is inside the fused op
-            loss_res = losses.triple_l1_margin_loss(ent, rel, h, r, t, bs, self.margin_completion)
-            loss = loss + loss_res + self.alignment_loss_simple(links, comp1[layer], comp2[layer])
-        return loss
+            loss = losses.completion_layer_loss(ent, rel, h, r, t, bs, self.margin_completion, add_to=loss)
+            if cols is not None:                                                 # alignment_loss_simple (:237-249), two tables
+                loss = losses.pair_cosine_mean(comp1[layer], cols[0], comp2[layer], cols[1], add_to=loss)
+        return loss if loss is not None else 0

@@ -91,3 +91,31 @@ def test_loss_adjoints_are_bitwise_reproducible_and_match_autograd():
     assert abs(float(first[0]) - float(ref)) <= 1e-5 * abs(float(ref))
     assert_close(first[1], e64.grad, 1e-5, 1e-9, "d ent")
     assert_close(first[2], r64.grad, 1e-5, 1e-9, "d rel")
+
+
+@pytest.mark.parametrize("kind", ["ja", "pair"])
+def test_layer0_gradients_are_taken_over_in_place_and_equal_the_added_form(kind):
+    """Round 5: the encoder nodes hand comp_att / rel_comp back as layer 0 of the completion layers, so the layer-0 loss gradient
+    arrives at the node's backward and the node adds its own input gradient onto that buffer (jmac_amd.encoder._take_grad) instead
+    of autograd adding two [N, d] tensors.  The step must (a) actually take that path -- INPLACE_COUNT moves by two per step (the
+    entity and the relation table) -- and (b) leave the gradients of the form where nothing is taken over (INPLACE_GRADS = False:
+    autograd's adds), to rounding: the association of the three contributions differs, nothing else."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from jmac_amd import encoder
+    a = argparse.Namespace(dim=300, batch=1000, negatives=25, bwd_mode=1)
+    w = bench.JaWorkload(a, torch.device("cuda"), data="real") if kind == "ja" else bench.PairWorkload(a, torch.device("cuda"))
+    w.model.completion_dropout.p = 0.0
+    res = {}
+    for flag in (True, False):
+        encoder.INPLACE_GRADS = flag
+        try:
+            before = encoder.INPLACE_COUNT
+            _, grads, _, _ = _run(w, 1)
+            res[flag] = (grads, encoder.INPLACE_COUNT - before)
+        finally:
+            encoder.INPLACE_GRADS = True
+    assert res[True][1] == 2 and res[False][1] == 0, (res[True][1], res[False][1])
+    for name, g in res[True][0].items():
+        ref = res[False][0][name]
+        assert float((g - ref).abs().max()) <= 2e-6 * max(float(ref.abs().max()), 1e-30), name

@@ -202,3 +202,104 @@ def test_triple_l1_margin_loss_is_the_two_ops_in_one_node(B, K, d):
     # a batch that is not B (K + 1) long takes the two ops (and the reference's own expression behind them)
     with pytest.raises(RuntimeError):
         losses.triple_l1_margin_loss(ent0, rel0, h[:-1], r[:-1], t[:-1], B, margin)
+
+
+def _layer_loss_case(B, K, d, seed, n=None, nr=17, L=0):
+    gen = torch.Generator().manual_seed(seed)
+    n = n or 5 * B
+    ent = torch.randn(n, d, generator=gen)
+    rel = torch.randn(nr, d, generator=gen)
+    bh = torch.randint(0, n, (B,), generator=gen)
+    br = torch.randint(0, nr, (B,), generator=gen)
+    h, r = bh.repeat(K + 1), br.repeat(K + 1)
+    t = torch.randint(0, n, (B * (K + 1),), generator=gen)
+    links = torch.randint(0, n // 2, (L, 2), generator=gen) if L else None
+    return ent, rel, h, r, t, links
+
+
+@pytest.mark.parametrize("B,K,d,L", [(64, 5, 40, 0), (250, 25, 300, 300), (1000, 25, 256, 2264), (7, 1, 12, 5)])
+def test_completion_layer_loss_is_the_separate_ops_in_one_node(B, K, d, L):
+    """losses.completion_layer_loss (round 5: one node per layer's term of completion_loss, src/jmac_model.py:331-380) against
+    (a) the oracle's float64 restatement -- margin ranking loss of the L1 triple scores + alignment_loss_simple on the links + the
+    running loss -- forward and both table gradients, and (b) the separate ops of this library composed with torch adds: the loss
+    to rounding, the L1 term's gradients BITWISE (the same integers times the same factor), the sum with the cosine rows to the
+    last bit or two.  The persistent count tables are zero again afterwards."""
+    from jmac_amd import losses
+    ent, rel, h, r, t, links = _layer_loss_case(B, K, d, B * K + d, L=L)
+    n = ent.shape[0]
+    margin = torch.nn.Parameter(torch.tensor([float(d) * 0.2]), requires_grad=False)
+    prev = torch.tensor([0.37])
+    w0, w1 = (0, n // 2), (n // 2, n - n // 2)                     # the two sides of a link: two windows of ONE stacked table
+    # (a) the oracle, float64
+    e64, r64 = ent.double().requires_grad_(True), rel.double().requires_grad_(True)
+    score = orc.triple_l1_score(e64, r64, h, r, t)
+    pos = score[:B].view(-1, B).permute(1, 0)
+    neg = score[B:].view(-1, B).permute(1, 0)
+    ref = torch.max(pos - neg, -margin.double()).mean() + margin.double() + prev.double()
+    if L:
+        ref = ref + orc.pair_cosine_distance(e64[w0[0]:w0[0] + w0[1]], links[:, 0], e64[w1[0]:w1[0] + w1[1]], links[:, 1]).mean()
+    (ref * 1.7).sum().backward()
+    dev = torch.device("cuda")
+    hd, rd, td = h.to(dev), r.to(dev), t.to(dev)
+    lk = (links[:, 0].contiguous().to(dev), links[:, 1].contiguous().to(dev), w0, w1) if L else None
+    mg, pv = margin.to(dev), prev.to(dev)
+    res = []
+    for fused in (True, False):
+        eg, rg = ent.to(dev).requires_grad_(True), rel.to(dev).requires_grad_(True)
+        if fused:
+            loss = losses.completion_layer_loss(eg, rg, hd, rd, td, B, mg, links=lk, add_to=pv)
+        else:
+            loss = losses.triple_l1_margin_loss(eg, rg, hd, rd, td, B, mg) + pv
+            if L:
+                loss = loss + losses.pair_cosine_distance(eg, lk[0], eg, lk[1], w0, w1).mean()
+        (loss * 1.7).sum().backward()
+        res.append((loss.detach(), eg.grad, rg.grad))
+    assert tuple(res[0][0].shape) == (1,)
+    assert abs(float(res[0][0]) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert abs(float(res[0][0]) - float(res[1][0])) <= 1e-6 * abs(float(ref))
+    assert_close(res[0][1], e64.grad, 1e-5, 1e-9, "d ent vs oracle")
+    assert_close(res[0][2], r64.grad, 1e-5, 1e-9, "d rel vs oracle")
+    assert torch.equal(res[0][2], res[1][2])                           # d rel: the same integers times the same factor
+    if L == 0:
+        assert torch.equal(res[0][1], res[1][1])                       # d ent, L1 term alone: likewise bitwise
+    else:                                                              # with the links: the mean's 1/L reaches the pairs through another
+        scale = float(res[1][1].abs().max())                           # expression (torch's expand / div): last-bit differences only
+        assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-7 * scale
+    for c in losses._CNT.values():
+        assert float(c[0].abs().max()) == 0.0 and float(c[1].abs().max()) == 0.0
+    # bitwise reproducible
+    eg, rg = ent.to(dev).requires_grad_(True), rel.to(dev).requires_grad_(True)
+    (losses.completion_layer_loss(eg, rg, hd, rd, td, B, mg, links=lk, add_to=pv) * 1.7).sum().backward()
+    assert torch.equal(eg.grad, res[0][1]) and torch.equal(rg.grad, res[0][2])
+
+
+@pytest.mark.parametrize("N1,N2,d,L,same", [(50, 60, 300, 500, False), (300, 300, 256, 5000, True), (9, 9, 5, 17, True), (30, 40, 64, 1, False)])
+def test_pair_cosine_mean_fwd_bwd(N1, N2, d, L, same):
+    """losses.pair_cosine_mean == pair_cosine_distance(...).mean() (+ add_to) against the oracle in float64; gradients bitwise
+    equal to the composed form's where that form is deterministic too; rows no pair touches come out as exact zeros (the rows
+    kernel is the first writer of the whole table)."""
+    from jmac_amd import losses
+    gen = torch.Generator().manual_seed(N1 + L)
+    e1 = torch.randn(N1, d, generator=gen)
+    e2 = e1 if same else torch.randn(N2, d, generator=gen)
+    i1 = torch.randint(0, N1 - 2, (L,), generator=gen)            # the last two rows of e1 are never touched
+    i2 = torch.randint(0, (N1 if same else N2) - 2, (L,), generator=gen)
+    prev = torch.tensor([1.25])
+    a64 = e1.double().requires_grad_(True)
+    b64 = a64 if same else e2.double().requires_grad_(True)
+    ref = orc.pair_cosine_distance(a64, i1, b64, i2).mean() + prev.double()
+    (ref * 0.3).sum().backward()
+    dev = torch.device("cuda")
+    ag = e1.to(dev).requires_grad_(True)
+    bg = ag if same else e2.to(dev).requires_grad_(True)
+    out = losses.pair_cosine_mean(ag, i1.to(dev), bg, i2.to(dev), add_to=prev.to(dev))
+    (out * 0.3).sum().backward()
+    assert tuple(out.shape) == (1,) and abs(float(out) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert_close(ag.grad, a64.grad, 1e-5, 1e-9, "d e1")
+    assert float(ag.grad[-2:].abs().max()) == 0.0
+    if not same:
+        assert_close(bg.grad, b64.grad, 1e-5, 1e-9, "d e2")
+    ag2 = e1.to(dev).requires_grad_(True)
+    bg2 = ag2 if same else e2.to(dev).requires_grad_(True)
+    (losses.pair_cosine_distance(ag2, i1.to(dev), bg2, i2.to(dev)).mean() * 0.3).sum().backward()
+    assert_close(ag.grad, ag2.grad, 1e-6, 1e-9, "rows form (scalar gradient) vs the vector form")
