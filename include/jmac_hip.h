@@ -212,6 +212,28 @@ int jmac_rel_attn_aggregate_bwd_f32(
     float* dP, int64_t lddp, float* dQZ, int64_t lddqz, float* dRR, int64_t lddrr, float* da,
     int32_t mode, void* ws, size_t ws_bytes, jmac_stream_t stream);
 
+/* The deterministic backward above in separately callable PHASES (bit mask; 15 = the whole backward = the call above, mode 1):
+ *   1 = pass A by destination (dP of plain destinations, the per-edge records in ws, da / column-sum partials)
+ *   2 = pass B by source (d[Q|Z], + the merge of its split sources)       4 = pass C by relation (d[Rq|Rz], + its merge)
+ *   8 = the merges that hang on pass A alone: dP of split destinations, da, dRz[loop] (run with or after phase 4)
+ * The same ws (sized for the whole graph's views by jmac_rel_attn_bwd_workspace_bytes) must be passed to every call of one
+ * backward: the records pass A leaves in it are read by passes B and C.
+ * A phase-2 call may cover a SLAB of the source rows, so that a destination-sharded layer can reduce-scatter slab c of d[Q|Z]
+ * over xGMI while pass B works on slab c+1 (jmac_amd.dist; adjoint of the all-gather in front of
+ * modules/helper/message_passing.py:24,28): by_src = a view built by jmac_items_build on the slab's slice of the by-source
+ * segment pointer (segments numbered from the slab's first row; `order` / `entry_dst` the whole graph's), dQZ = the slab's first
+ * row, Nsrc = its rows, self_off = (whole-table self_off) - (slab's first row): negative or past the slab where the rank's own
+ * rows lie elsewhere. */
+int jmac_rel_attn_aggregate_bwd_phases_f32(
+    const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR, int64_t ldrr,
+    const float* a_att, const int32_t* col, const int32_t* etype, const int32_t* dst_of_slot,
+    const jmac_view_t* by_dst, const jmac_view_t* by_src, const jmac_view_t* by_rel,
+    int64_t N, int64_t Nsrc, int64_t E, int64_t nrel, int64_t d, float slope, int32_t loop_rel,
+    int64_t self_off, float out_scale, const float* out, int64_t ldo, const float* seg_max, const float* seg_den,
+    const float* G, int64_t ldg,
+    float* dP, int64_t lddp, float* dQZ, int64_t lddqz, float* dRR, int64_t lddrr, float* da,
+    int32_t phases, void* ws, size_t ws_bytes, jmac_stream_t stream);
+
 /* BatchNorm1d (batch statistics or running statistics) + tanh on [N,d]
  * (replaces: self.layer_act(self.bn(.)), src/jmac_model.py:52).
  * training != 0: mean/var are computed over the N rows (biased var), written to save_mean /

@@ -70,6 +70,10 @@ _SIGS = {
                                                   C.POINTER(View), C.POINTER(View), C.POINTER(View),
                                                   i64, i64, i64, i64, i64, f32, i32, i64, f32, vp, i64, vp, vp, vp, i64,
                                                   vp, i64, vp, i64, vp, i64, vp, i32, vp, sz, vp]),
+    "jmac_rel_attn_aggregate_bwd_phases_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp,
+                                                         C.POINTER(View), C.POINTER(View), C.POINTER(View),
+                                                         i64, i64, i64, i64, i64, f32, i32, i64, f32, vp, i64, vp, vp, vp, i64,
+                                                         vp, i64, vp, i64, vp, i64, vp, i32, vp, sz, vp]),
     "jmac_bn_tanh_workspace_bytes": (sz, [i64, i64]),
     "jmac_bn_tanh_fwd_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, i32, f32, f32, vp, i64, vp, vp,
                                        vp, sz, vp]),

@@ -1976,13 +1976,16 @@ struct BwdWs {
 static BwdWs bwd_ws_layout(int64_t E, int64_t d, int64_t pd, int64_t ps, int64_t pr, int32_t mode) {
     BwdWs w;
     size_t off = 0;
+    // the per-edge records come BEFORE the partial rows and the by-source partials LAST: a caller that runs the passes in
+    // separate calls (jmac_rel_attn_aggregate_bwd_phases_f32: pass B slab by slab, each slab with its own by-source view)
+    // finds the records of pass A at the same offsets whatever that view's partial count is
     w.da_part = off;     off += align_up((size_t)2 * kPersistBlocks * d * 4);   // one partial row per pass-A block (<= 2 x 2048)
     w.colsum_part = off; off += align_up((size_t)kPersistBlocks * d * 4);
-    w.part_dst = off;    off += align_up((size_t)(pd > 0 ? pd : 0) * d * 4);
-    w.part_src = off;    off += mode ? align_up((size_t)(ps > 0 ? ps : 0) * 2 * d * 4) : 0;
-    w.part_rel = off;    off += mode ? align_up((size_t)(pr > 0 ? pr : 0) * 2 * d * 4) : 0;
     w.wds = off;         off += mode ? align_up((size_t)E * 8) : 0;
     w.bits = off;        off += mode ? align_up((size_t)E * 64) : 0;
+    w.part_dst = off;    off += align_up((size_t)(pd > 0 ? pd : 0) * d * 4);
+    w.part_rel = off;    off += mode ? align_up((size_t)(pr > 0 ? pr : 0) * 2 * d * 4) : 0;
+    w.part_src = off;    off += mode ? align_up((size_t)(ps > 0 ? ps : 0) * 2 * d * 4) : 0;
     w.total = off + 256;
     return w;
 }
@@ -1994,17 +1997,26 @@ size_t jmac_rel_attn_bwd_workspace_bytes(int64_t N, int64_t E, int64_t nrel, int
     return bwd_ws_layout(E < 0 ? 0 : E, d, n_parts_max_dst, n_parts_max_src, n_parts_max_rel, mode).total;
 }
 
-int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR,
-                                    int64_t ldrr, const float* a_att, const int32_t* col, const int32_t* etype,
-                                    const int32_t* dst_of_slot, const jmac_view_t* by_dst, const jmac_view_t* by_src,
-                                    const jmac_view_t* by_rel, int64_t N, int64_t Nsrc, int64_t E, int64_t nrel, int64_t d,
-                                    float slope, int32_t loop_rel, int64_t self_off, float out_scale, const float* out, int64_t ldo,
-                                    const float* seg_max, const float* seg_den, const float* G, int64_t ldg, float* dP,
-                                    int64_t lddp, float* dQZ, int64_t lddqz, float* dRR, int64_t lddrr, float* da,
-                                    int32_t mode, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+}  // extern "C"
+
+// phases (deterministic mode): 1 = pass A (+ the column-sum partials of G), 2 = pass B by source + the merge of its split
+// sources, 4 = pass C by relation + its merge, 8 = the merges that hang on pass A alone (split destinations, da, dRz[loop]).
+// 15 = the whole backward.  A call with phase 2 alone may address a SLAB of the source rows (see the header).
+enum { kPhaseA = 1, kPhaseB = 2, kPhaseC = 4, kPhaseM = 8, kPhaseAll = 15 };
+
+static int rel_attn_bwd_impl(const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR,
+                             int64_t ldrr, const float* a_att, const int32_t* col, const int32_t* etype,
+                             const int32_t* dst_of_slot, const jmac_view_t* by_dst, const jmac_view_t* by_src,
+                             const jmac_view_t* by_rel, int64_t N, int64_t Nsrc, int64_t E, int64_t nrel, int64_t d,
+                             float slope, int32_t loop_rel, int64_t self_off, float out_scale, const float* out, int64_t ldo,
+                             const float* seg_max, const float* seg_den, const float* G, int64_t ldg, float* dP,
+                             int64_t lddp, float* dQZ, int64_t lddqz, float* dRR, int64_t lddrr, float* da,
+                             int32_t mode, void* ws, size_t ws_bytes, jmac_stream_t stream, int32_t phases) {
     if (N < 0 || Nsrc < 0 || E < 0 || nrel <= 0) return JMAC_EINVAL;
     if (loop_rel < 0) self_off = 0;
-    if (loop_rel >= 0 && (self_off < 0 || self_off + N > Nsrc)) return JMAC_EINVAL;   // the fused self term reads QZ[self_off + i]
+    // the fused self term reads QZ[self_off + i] (pass A) and adds g_i to d[Q|Z][self_off + i] (pass B).  A pass-B-only call on a
+    // slab of the source rows passes self_off RELATIVE to the slab (possibly negative / past it: rows outside get no self term)
+    if ((phases & kPhaseA) && loop_rel >= 0 && (self_off < 0 || self_off + N > Nsrc)) return JMAC_EINVAL;
     // a rank of the destination-sharded layer may own NO row (N == 0): its row-indexed buffers are empty (null), and the
     // call still has to produce d[Q|Z] (zeros: no edge reads the table from here), dRR and da
     if (!QZ || !RR || !a_att || !by_dst || !seg_max || !seg_den || !dQZ || !dRR || !da) return JMAC_EINVAL;
@@ -2085,8 +2097,10 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
 #endif
     // ---- deterministic mode: three launches ----------------------------------------------------------------------------
     // 1. pass A by destination (+ the column-sum partials of G)
-    JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 1, D4T>), dim3(gridA + gcs), dim3(kBlock), 0, st, a,
-                                              (int)gridA, cs));
+    if (phases & kPhaseA) {
+        JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_dst_kernel<NCH, 2, 1, D4T>), dim3(gridA + gcs), dim3(kBlock), 0, st, a,
+                                                  (int)gridA, cs));
+    }
     // 2. pass B by source and pass C by relation, side by side
     BwdArgs b = a;
     b.items = by_src->items; b.splits = by_src->splits; b.counts = by_src->counts; b.order = by_src->order;
@@ -2100,20 +2114,54 @@ int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ
     c.sign = -1.f; c.add_self = 0;
     c.item_edges = reinterpret_cast<const int4*>(by_rel->item_edges); c.entry_dst = by_rel->entry_dst;
     c.n_items_max = (int32_t)(by_rel->n_items_max > 0 ? by_rel->n_items_max : 1);
-    const unsigned gB = persist_grid(by_src->n_items_max), gC = persist_grid(by_rel->n_items_max);
-    JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_gather_kernel<NCH, 4, D4T>), dim3(gB + gC), dim3(kBlock), 0, st, b, dQZ,
-                                              lddqz, (int)gB, c, dRR, lddrr));
+    const unsigned gB = (phases & kPhaseB) ? persist_grid(by_src->n_items_max) : 0u;
+    const unsigned gC = (phases & kPhaseC) ? persist_grid(by_rel->n_items_max) : 0u;
+    if (gB + gC > 0) {
+        JMAC_DISPATCH_D(D4, nch, hipLaunchKernelGGL((rel_attn_bwd_gather_kernel<NCH, 4, D4T>), dim3(gB + gC), dim3(kBlock), 0, st, b, dQZ,
+                                                  lddqz, (int)gB, c, dRR, lddrr));
+    }
     // 3. every merge: partial rows of the split destinations / sources / relations, da, dRz[loop]
     FinalizeArgs f{};
-    f.sp[0] = sum_task(by_dst, a.part, D4, dP, lddp, 0);
-    f.sp[1] = sum_task(by_src, b.part, 2 * D4, dQZ, lddqz, b.add_self);
-    f.sp[2] = sum_task(by_rel, c.part, 2 * D4, dRR, lddrr, 0);
-    f.rd[0] = reduce_task(a.da_part, (int)gridA, 1.f, da);
-    // pass C wrote zeros into dRz[loop] (the loop relation has no edges): overwrite it
-    f.rd[1] = reduce_task(colsum_part, (int)gcs, -out_scale, dRR + (int64_t)(loop_rel >= 0 ? loop_rel : 0) * lddrr + d);
+    if (phases & kPhaseM) f.sp[0] = sum_task(by_dst, a.part, D4, dP, lddp, 0);
+    if (phases & kPhaseB) f.sp[1] = sum_task(by_src, b.part, 2 * D4, dQZ, lddqz, b.add_self);
+    if (phases & kPhaseC) f.sp[2] = sum_task(by_rel, c.part, 2 * D4, dRR, lddrr, 0);
+    if (phases & kPhaseM) {
+        f.rd[0] = reduce_task(a.da_part, (int)gridA, 1.f, da);
+        // pass C wrote zeros into dRz[loop] (the loop relation has no edges): overwrite it (phase 8 runs with or after phase 4)
+        f.rd[1] = reduce_task(colsum_part, (int)gcs, -out_scale, dRR + (int64_t)(loop_rel >= 0 ? loop_rel : 0) * lddrr + d);
+    }
     const int nb = f.sp[0].nblocks + f.sp[1].nblocks + f.sp[2].nblocks + f.rd[0].nblocks + f.rd[1].nblocks;
     if (nb > 0) hipLaunchKernelGGL(bwd_finalize_kernel, dim3((unsigned)nb), dim3(kBlock), 0, st, f);
     return (int)hipGetLastError();
+}
+
+extern "C" {
+
+int jmac_rel_attn_aggregate_bwd_f32(const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR,
+                                    int64_t ldrr, const float* a_att, const int32_t* col, const int32_t* etype,
+                                    const int32_t* dst_of_slot, const jmac_view_t* by_dst, const jmac_view_t* by_src,
+                                    const jmac_view_t* by_rel, int64_t N, int64_t Nsrc, int64_t E, int64_t nrel, int64_t d,
+                                    float slope, int32_t loop_rel, int64_t self_off, float out_scale, const float* out, int64_t ldo,
+                                    const float* seg_max, const float* seg_den, const float* G, int64_t ldg, float* dP,
+                                    int64_t lddp, float* dQZ, int64_t lddqz, float* dRR, int64_t lddrr, float* da,
+                                    int32_t mode, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    return rel_attn_bwd_impl(P, ldp, QZ, ldqz, RR, ldrr, a_att, col, etype, dst_of_slot, by_dst, by_src, by_rel, N, Nsrc, E, nrel, d, slope,
+                             loop_rel, self_off, out_scale, out, ldo, seg_max, seg_den, G, ldg, dP, lddp, dQZ, lddqz, dRR, lddrr, da, mode,
+                             ws, ws_bytes, stream, kPhaseAll);
+}
+
+int jmac_rel_attn_aggregate_bwd_phases_f32(const float* P, int64_t ldp, const float* QZ, int64_t ldqz, const float* RR,
+                                           int64_t ldrr, const float* a_att, const int32_t* col, const int32_t* etype,
+                                           const int32_t* dst_of_slot, const jmac_view_t* by_dst, const jmac_view_t* by_src,
+                                           const jmac_view_t* by_rel, int64_t N, int64_t Nsrc, int64_t E, int64_t nrel, int64_t d,
+                                           float slope, int32_t loop_rel, int64_t self_off, float out_scale, const float* out,
+                                           int64_t ldo, const float* seg_max, const float* seg_den, const float* G, int64_t ldg,
+                                           float* dP, int64_t lddp, float* dQZ, int64_t lddqz, float* dRR, int64_t lddrr, float* da,
+                                           int32_t phases, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+    if (phases <= 0 || phases > kPhaseAll) return JMAC_EINVAL;
+    return rel_attn_bwd_impl(P, ldp, QZ, ldqz, RR, ldrr, a_att, col, etype, dst_of_slot, by_dst, by_src, by_rel, N, Nsrc, E, nrel, d, slope,
+                             loop_rel, self_off, out_scale, out, ldo, seg_max, seg_den, G, ldg, dP, lddp, dQZ, lddqz, dRR, lddrr, da, 1,
+                             ws, ws_bytes, stream, phases);
 }
 
 }  // extern "C"

@@ -28,6 +28,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 MAX_CHUNKS = 16          # JMAC_MERGE_MAX_PARTS of include/jmac_hip.h: parts one jmac_softmax_parts_merge_f32 call merges
+OVERLAP_BACKWARD = True  # slab-pipelined exchange: queue slab c's reduce-scatter while pass B sums slab c + 1 (False: all after)
+OVERLAP_COUNT = 0        # tests: backwards that took the overlapped form
+HANDOFF_COUNT = 0        # tests: exchanges whose backward found its gradient already reduce-scattered
 
 
 # ------------------------------------------------------------------------------------------------
@@ -467,6 +470,15 @@ class _HipChunked:
         return ops.rel_attn_split_bwd_raw(P, table, RR, a, sg.rel_graph(P.device, RR.shape[0]), slope, 0.5, RR.shape[0] - 1,
                                           sg.self_off, pre, seg_max, seg_den, G)
 
+    @staticmethod
+    def backward_phased(P, table, RR, a, sg: "ShardedGraph", slope: float, pre, seg_max, seg_den, G, slab_bounds):
+        """The same backward as separately launched phases (ops.SplitBackwardPhases): ``begin()`` = pass A, pass C and their
+        merges; ``slab(c)`` = pass B on table rows [slab_bounds[c], slab_bounds[c+1]) -> that slice of d table, final in stream
+        order -- the caller reduce-scatters it while the next slab is summed.  Attributes dP, dQZ, dRR, da."""
+        from . import ops
+        return ops.SplitBackwardPhases(P, table, RR, a, sg.rel_graph(P.device, RR.shape[0]), slope, 0.5, RR.shape[0] - 1, sg.self_off,
+                                       pre, seg_max, seg_den, G, slab_bounds)
+
 
 class _ChunkedAllGather(torch.autograd.Function):
     """[n_max, w] per rank -> the CHUNK-major [world*n_max, w] table, as ``sg.chunks`` all-gathers queued at once (RCCL runs
@@ -523,6 +535,12 @@ class _ChunkedAllGather(torch.autograd.Function):
     def backward(ctx, g):
         sg, group = ctx.sg, ctx.group
         world = _world(group)
+        done = getattr(g, "_jmac_reduced", None)             # _ChunkedAggregate.backward already reduce-scattered it, slab by slab
+        if done is not None:
+            global HANDOFF_COUNT
+            HANDOFF_COUNT += 1
+            g._jmac_reduced = None
+            return done, None, None
         own = g[world * sg.n_max:]                           # gradient of the own-rows copy (the self loop's dZ)
         if _skip(group):
             return g[:sg.n_max] + own, None, None
@@ -574,18 +592,62 @@ class _ChunkedAggregate(torch.autograd.Function):
         pre, seg_max, seg_den = kernels.merge(parts, n, d, P.device, zself, RR[-1, d:].contiguous(), 0.5)
         ctx.save_for_backward(P, table, RR, a, pre, seg_max, seg_den)
         ctx.sg, ctx.slope, ctx.kernels = sg, slope, kernels
+        ctx.group = getattr(table, "_jmac_group", None)      # (group,) when the table came from chunked_all_gather
         return pre
 
     @staticmethod
     def backward(ctx, G):
+        global OVERLAP_COUNT
         P, table, RR, a, pre, seg_max, seg_den = ctx.saved_tensors
-        dP, dT, dRR, da = ctx.kernels.backward(P, table, RR, a, ctx.sg, ctx.slope, pre, seg_max, seg_den, G.contiguous())
-        return dP, dT, dRR, da, None, None, None
+        sg, kernels = ctx.sg, ctx.kernels
+        if not (OVERLAP_BACKWARD and ctx.group is not None and hasattr(kernels, "backward_phased")):
+            dP, dT, dRR, da = kernels.backward(P, table, RR, a, sg, ctx.slope, pre, seg_max, seg_den, G.contiguous())
+            return dP, dT, dRR, da, None, None, None
+        # Overlapped form (adjoint of the slab-pipelined exchange): pass B -- the by-source sums that produce d table -- runs slab by
+        # slab in the table's chunk-major row order, and slab c's reduce-scatter is queued (RCCL: on its own stream, behind the
+        # compute stream's work so far) while pass B goes on with slab c + 1.  The last slab is the rank's own-rows copy (the fused
+        # self loop's dZ): it stays local.
+        (group,) = ctx.group
+        world = _world(group)
+        cb = sg.chunk_bounds
+        bounds = [world * int(b) for b in cb] + [int(table.shape[0])]
+        bp = kernels.backward_phased(P, table, RR, a, sg, ctx.slope, pre, seg_max, seg_den, G.contiguous(), bounds)
+        bp.begin()
+        out = torch.empty((sg.n_max,) + tuple(table.shape[1:]), dtype=table.dtype, device=table.device)
+        skip = _skip(group)
+        gloo = (not skip) and dist.get_backend(group) == "gloo"
+        r = 0 if skip else dist.get_rank(group)
+        works = []
+        for c in range(sg.chunks):
+            gc = bp.slab(c)                                  # rows [world cb[c], world cb[c+1]) of d table: final in stream order
+            rows = int(cb[c + 1] - cb[c])
+            if rows == 0:
+                continue
+            dst = out[cb[c]:cb[c + 1]]
+            if skip:
+                dst.copy_(gc)
+            elif gloo:                                       # gloo has no reduce_scatter (tests): all-reduce + slice, blocking
+                t = gc.cpu() if gc.is_cuda else gc.clone()
+                _all_reduce(t, group)
+                dst.copy_(t[r * rows:(r + 1) * rows])
+            else:
+                e0 = _cev(gc)
+                works.append((dist.reduce_scatter_tensor(dst, gc, group=group, async_op=True), e0, gc))
+        own = bp.slab(sg.chunks)                             # the own-rows copy's gradient (self loop)
+        for w, e0, gc in works:
+            w.wait()                                         # the compute stream waits; no host block
+            _cdone("reduce_scatter_dqz_chunk", e0, gc)
+        out += own
+        dT = bp.dQZ
+        dT._jmac_reduced = out                               # _ChunkedAllGather.backward hands it on instead of reducing again
+        OVERLAP_COUNT += 1
+        return bp.dP, dT, bp.dRR, bp.da, None, None, None
 
 
 def chunked_all_gather(x: torch.Tensor, sg: ShardedGraph, group=None) -> torch.Tensor:
     table = _ChunkedAllGather.apply(x, sg, group)
     table._jmac_pending, _ChunkedAllGather._handoff = _ChunkedAllGather._handoff, None
+    table._jmac_group = (group,)                       # the aggregation's backward queues the reduce-scatters itself (overlap)
     return table
 
 

@@ -243,6 +243,37 @@ class RelGraph:
         self._ei = None
         self._bwd_ready = True
 
+    def src_slab_views(self, bounds) -> list:
+        """By-source schedules of the SLABS [bounds[c], bounds[c+1]) of the source rows (bounds: ascending ints from 0 to
+        num_src): pass B of the backward can then run slab by slab (jmac_rel_attn_aggregate_bwd_phases_f32, phase 2), e.g. so
+        that a destination-sharded layer reduce-scatters slab c of d[Q|Z] while slab c+1 is being summed.  Every view is built on
+        the slab's slice of the by-source segment pointer: its segments are numbered from the slab's first row, ``order`` /
+        ``entry_dst`` are the whole graph's.  Cached per bounds tuple."""
+        self.ensure_backward_views()
+        key = tuple(int(b) for b in bounds)
+        if key[0] != 0 or key[-1] != self.num_src or any(key[i] > key[i + 1] for i in range(len(key) - 1)):
+            raise ValueError("src_slab_views: bounds must ascend from 0 to num_src")
+        hit = getattr(self, "_src_slabs", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        base = self.by_src
+        ptr_host = base.ptr.cpu()                        # one host read at build time (never on the hot path)
+        chunk = min(self.chunk, SMALL_BWD_CHUNK) if base.item_edges is not None else self.chunk
+        views = []
+        for c in range(len(key) - 1):
+            s0, s1 = key[c], key[c + 1]
+            if s1 == s0:
+                views.append(None)
+                continue
+            n_ent = int(ptr_host[s1]) - int(ptr_host[s0])
+            sch = _Schedule(base.ptr[s0:s1 + 1], s1 - s0, n_ent, chunk, base.order)
+            sch.entry_dst = base.entry_dst
+            if base.item_edges is not None:
+                sch.build_item_edges(base.order, base.entry_dst)
+            views.append(sch)
+        self._src_slabs = (key, views)
+        return views
+
     def ensure_backward_views_compact(self) -> None:
         """by_rel_c: the by-relation grouping of the CSR slots in compact relation numbering (pass C of the backward on compact
         relation tables)."""

@@ -216,6 +216,58 @@ def rel_attn_split_bwd_raw(P, QZ, RR, a, graph: RelGraph, slope: float, out_scal
     return dP, dQZ, dRR, da
 
 
+PHASE_A, PHASE_B, PHASE_C, PHASE_M, PHASE_ALL = 1, 2, 4, 8, 15
+
+
+class SplitBackwardPhases:
+    """jmac_rel_attn_aggregate_bwd_phases_f32 on the split tables: the deterministic backward as separately launched phases --
+    pass A (+ pass C and the merges that hang on them) first, then pass B over SLABS of the source rows, each slab's d[Q|Z] rows
+    complete when its call returns to the stream (the caller queues that slab's reduce-scatter and goes on with the next slab).
+    ``slab_bounds``: ascending source-row bounds from 0 to the table's rows.  Results equal rel_attn_split_bwd_raw's bit for bit
+    (the same kernels on the same items in the same order per output row)."""
+
+    def __init__(self, P, QZ, RR, a, graph: RelGraph, slope: float, out_scale: float, loop_rel: int, self_off: int, out, seg_max,
+                 seg_den, G, slab_bounds):
+        self.L = lib()
+        self.P, self.QZ, self.RR, self.a, self.graph = P, QZ, RR, a, graph
+        self.slope, self.out_scale, self.loop_rel, self.self_off = float(slope), float(out_scale), int(loop_rel), int(self_off)
+        self.out, self.seg_max, self.seg_den, self.G = out, seg_max, seg_den, _f32c(G).contiguous()
+        graph.ensure_backward_views()
+        self.bounds = [int(b) for b in slab_bounds]
+        self.slabs = graph.src_slab_views(self.bounds)
+        N, d = P.shape
+        self.N, self.d, self.nsrc, self.nrel = N, d, QZ.shape[0], RR.shape[0]
+        self.dP, self.dQZ, self.dRR, self.da = torch.empty_like(P), torch.empty_like(QZ), torch.empty_like(RR), torch.empty_like(a)
+        ws_bytes = int(self.L.jmac_rel_attn_bwd_workspace_bytes(N, graph.E, self.nrel, d, graph.by_dst_bwd.n_parts_max,
+                                                                graph.by_src.n_parts_max, graph.by_rel.n_parts_max, 1))
+        self.ws, self.ws_bytes = _ws(ws_bytes, P.device), ws_bytes
+
+    def _call(self, phases: int, src_view, row0: int, rows: int) -> None:
+        g, d = self.graph, self.d
+        vd, vr = g.by_dst_bwd.view(), g.by_rel.view()
+        ev0 = _ev() if PROFILE is not None else None
+        check(self.L.jmac_rel_attn_aggregate_bwd_phases_f32(
+            ptr(self.P), d, ptr(self.QZ), 2 * d, ptr(self.RR), self.RR.shape[1], ptr(self.a),
+            ptr(g.col), ptr(g.etype), ptr(g.dst_of_slot), C.byref(vd), C.byref(src_view), C.byref(vr),
+            self.N, rows, g.E, self.nrel, d, self.slope, self.loop_rel, self.self_off - row0, self.out_scale,
+            ptr(self.out), d, ptr(self.seg_max), ptr(self.seg_den), ptr(self.G), d,
+            ptr(self.dP), d, self.dQZ.data_ptr() + row0 * 2 * d * 4, 2 * d, ptr(self.dRR), self.dRR.shape[1], ptr(self.da),
+            int(phases), ptr(self.ws), self.ws_bytes, stream()), "jmac_rel_attn_aggregate_bwd_phases_f32")
+        if ev0 is not None:
+            PROFILE.append(("rel_attn_bwd_phase%d" % phases, ev0, _ev()))
+
+    def begin(self) -> None:
+        """Pass A, pass C and every merge but the by-source one: dP, dRR, da are final afterwards."""
+        self._call(PHASE_A | PHASE_C | PHASE_M, self.graph.by_src.view(), 0, self.nsrc)
+
+    def slab(self, c: int) -> torch.Tensor:
+        """Pass B on source rows [bounds[c], bounds[c+1]): returns that slice of d[Q|Z] (final once the stream reaches here)."""
+        r0, r1 = self.bounds[c], self.bounds[c + 1]
+        if r1 > r0:
+            self._call(PHASE_B, self.slabs[c].view(), r0, r1 - r0)
+        return self.dQZ[r0:r1]
+
+
 def softmax_parts_merge(parts, N: int, d: int, device, zself=None, rz_loop=None, out_scale: float = 1.0):
     """jmac_softmax_parts_merge_f32: parts = [(out_c [N,d], seg_max_c [N], seg_den_c [N], rowptr_c [N+1] int32), ...] of the
     same destinations over disjoint edge sets -> (out [N,d], seg_max [N], seg_den [N]) of their union; out = out_scale * (nb +

@@ -90,6 +90,27 @@ class _StandinChunked:
             return torch.autograd.grad(out, xs, G)
 
 
+    @staticmethod
+    def backward_phased(P, table, RR, a, sg, slope, pre, seg_max, seg_den, G, slab_bounds):
+        """The phased form (dist._HipChunked.backward_phased): begin() = everything but d table, slab(c) = rows
+        [slab_bounds[c], slab_bounds[c+1]) of d table.  A slab may be asked for only after begin(), in order, once."""
+        import types
+        dP, dT, dRR, da = _StandinChunked.backward(P, table, RR, a, sg, slope, pre, seg_max, seg_den, G)
+        st = types.SimpleNamespace(dP=None, dQZ=torch.full_like(dT, float("nan")), dRR=None, da=None, next=0)
+
+        def begin():
+            st.dP, st.dRR, st.da = dP, dRR, da
+
+        def slab(c):
+            assert st.dP is not None and c == st.next
+            st.next += 1
+            r0, r1 = slab_bounds[c], slab_bounds[c + 1]
+            st.dQZ[r0:r1] = dT[r0:r1]                    # rows of later slabs are still NaN: a reduce-scatter that read ahead would show
+            return st.dQZ[r0:r1]
+        st.begin, st.slab = begin, slab
+        return st
+
+
 class _StandinBN:
     """Test double for the phased BN + tanh kernels (include/jmac_hip.h): same contract, torch on the CPU."""
 
@@ -148,7 +169,8 @@ def _worker(rank, world, port, ret):
         (out * G[sg.lo:sg.hi]).sum().backward()
         params = list(base.parameters()) + [r]
         allreduce_grads(params)
-        ret[rank] = dict(lo=sg.lo, hi=sg.hi, out=out.detach(), gx=x.grad, gr=r.grad,
+        import jmac_amd.dist as jd
+        ret[rank] = dict(overlapped=min(jd.OVERLAP_COUNT, jd.HANDOFF_COUNT), lo=sg.lo, hi=sg.hi, out=out.detach(), gx=x.grad, gr=r.grad,
                          grads={k: v.grad.clone() for k, v in base.named_parameters()},
                          rm=base.bn.running_mean.clone(), rv=base.bn.running_var.clone(),
                          e_local=sg.E_local, n_max=sg.n_max)
@@ -196,6 +218,8 @@ def test_sharded_layer_equals_single_process_oracle(fused_bn, world, bounds, chu
     for r in range(world):
         o = ret[r]
         lo, hi = o["lo"], o["hi"]
+        # chunks > 1: the backward took the overlapped form (pass B slab by slab, each slab reduce-scattered as it completes)
+        assert o["overlapped"] == (1 if chunks > 1 else 0), (r, o["overlapped"])
         assert torch.allclose(o["out"], ref[lo:hi].detach(), atol=2e-5), r
         assert torch.allclose(o["gx"], Xc.grad[lo:hi], atol=2e-4, rtol=1e-3), r
         assert torch.allclose(o["gr"], Rc.grad, atol=2e-4, rtol=1e-3)

@@ -55,8 +55,10 @@ def _worker(rank, world, port, ret):
         (out * G[sg.lo:sg.hi].to(dev)).sum().backward()
         allreduce_grads(list(base.parameters()) + [r])
         torch.cuda.synchronize()
+        import jmac_amd.dist as jd
         ret[rank] = dict(lo=sg.lo, hi=sg.hi, out=out.detach().cpu(), gx=x.grad.cpu(), gr=r.grad.cpu(),
-                         grads={k: v.grad.cpu() for k, v in base.named_parameters()})
+                         grads={k: v.grad.cpu() for k, v in base.named_parameters()},
+                         overlapped=min(jd.OVERLAP_COUNT, jd.HANDOFF_COUNT))
     finally:
         dist.destroy_process_group()
 
@@ -91,6 +93,9 @@ def test_sharded_hip_layer_two_ranks(world, bounds, chunks, monkeypatch):
     for r in range(world):
         o = ret[r]
         lo, hi = o["lo"], o["hi"]
+        # pipelined: the backward ran pass B slab by slab (jmac_rel_attn_aggregate_bwd_phases_f32) with each slab's reduce-scatter
+        # queued as it completed, and the exchange's own backward took the reduced gradient as it was
+        assert o["overlapped"] == (1 if chunks > 1 else 0), (r, o["overlapped"])
         assert_close(o["out"], ref[lo:hi], 1e-4, 1e-6, "out")
         assert_close(o["gx"], Xc.grad[lo:hi], 1e-4, 1e-6, "grad_X")
         assert_close(o["gr"], Rc.grad, 1e-4, 1e-6, "grad_R")
@@ -235,3 +240,36 @@ def test_sharded_scoring_two_ranks_config5_shape():
         assert res[0] == want[0] and res[1] == want[1]
         assert abs(res[2] - want[2]) < 1e-9 and abs(res[3] - want[3]) < 1e-12
     assert want[1][0] > 50.0                                         # the planted alignment is recovered
+
+
+@pytest.mark.parametrize("n,e,slabs", [(700, 9000, [0, 100, 100, 333, 700]), (70000, 200000, [0, 1, 35000, 69999, 70000])],
+                         ids=["small-form", "persistent-form"])
+def test_phased_backward_equals_one_call_bitwise(n, e, slabs):
+    """jmac_rel_attn_aggregate_bwd_phases_f32 -- pass A + pass C + their merges in one call, then pass B slab by slab over uneven
+    (and one empty) ranges of the source rows -- leaves the bits of the one-call backward in every output: the same kernels on
+    the same items, each output row summed in the same order."""
+    from jmac_amd import ops
+    from jmac_amd.graph import RelGraph
+    dev = torch.device("cuda")
+    nr, d = 11, 300
+    rng = np.random.default_rng(n)
+    ei, et = random_graph(rng, n, nr, e, hub=900)
+    ei[1, : e // 20] = 5                                               # a hub SOURCE: its d[Q|Z] row is a merge of partial rows
+    gen = torch.Generator().manual_seed(n)
+    P, QZ = (torch.randn(n, d, generator=gen) * 0.3).to(dev), (torch.randn(n, 2 * d, generator=gen) * 0.3).to(dev)
+    RR, a = (torch.randn(nr + 1, 2 * d, generator=gen) * 0.3).to(dev), (torch.randn(d, generator=gen) * 0.1).to(dev)
+    G = torch.randn(n, d, generator=gen).to(dev)
+    g = RelGraph(torch.from_numpy(ei).to(dev), torch.from_numpy(et).to(dev), n, nr + 1)
+    out, m, l = ops.rel_attn_split_fwd_raw(P, QZ, RR, a, g, 0.05, 0.5, nr, 0)
+    want = ops.rel_attn_split_bwd_raw(P, QZ, RR, a, g, 0.05, 0.5, nr, 0, out, m, l, G)
+    bp = ops.SplitBackwardPhases(P, QZ, RR, a, g, 0.05, 0.5, nr, 0, out, m, l, G, slabs)
+    bp.dQZ.fill_(float("nan"))
+    bp.begin()
+    torch.cuda.synchronize()
+    assert torch.equal(bp.dP, want[0]) and torch.equal(bp.dRR, want[2]) and torch.equal(bp.da, want[3])
+    for c in range(len(slabs) - 1):
+        piece = bp.slab(c)
+        torch.cuda.synchronize()
+        assert torch.equal(piece, want[1][slabs[c]:slabs[c + 1]]), c
+        assert bool(torch.isnan(bp.dQZ[slabs[c + 1]:]).all())          # a slab call writes its own rows only
+    assert torch.equal(bp.dQZ, want[1])
