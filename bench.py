@@ -813,8 +813,8 @@ def sim_bench(device, iters=10, cpu=True):
     ent_ms = t(lambda: scoring.align_entropy(big[0], big[1]), 3)
     res = {"workload": "config 5 shape: N=30000 d=300; quality GEMM 12000x12000, get_neg 3000x30000 k=25, CSLS test 10500^2",
            "sim_gemm_ms": gemm_ms, "sim_gemm_tflops": tf, "mfma_frac_of_f32_peak": tf / MFMA_F32_PEAK_TFLOPS,
-           "mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS, "mfma_util_pmc_percent": pmc_mfma_util(),
-           "mfma_util_source": "profiles/r3_pmc_mfma.json (committed rocprofv3 --pmc pass, tools/pmc_mfma_r3.sh; not collected by this run)",
+           "mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS, "mfma_util_pmc_percent": pmc_mfma_util()[0],
+           "mfma_util_source": "%s (committed rocprofv3 --pmc pass, tools/pmc_mfma_r3.sh; not collected by this run)" % pmc_mfma_util()[1],
            "get_neg_ms": neg_ms, "get_neg_pairs_per_s": 3000 * 30000 / (neg_ms * 1e-3),
            "alignment_test_ms": test_ms, "align_entropy_12000sq_ms": ent_ms}
     if cpu:
@@ -942,7 +942,7 @@ def union_bench(a, device, cpu=True):
                                     "algorithmic_bytes_per_launch": fb16, "achieved": fb16 / (agg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": fb16 / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "traffic": (pmc_traffic("union", "rel_attn_fwd_kernel<3, 2, 75, unsigned short>") if (real and d == 300) else None),
-                                    "traffic_source": "profiles/r4_pmc_union.json (committed rocprofv3 --pmc passes on the same real union; "
+                                    "traffic_source": "%s (committed" % pmc_source("union") + "  rocprofv3 --pmc passes on the same real union; "
                                                       "not collected by this run)",
                                     "note": "%.0f MB per launch: Infinity-Cache resident" % (fb16 / 1e6)}}
     if real:
@@ -1236,7 +1236,7 @@ def synth_measure(a, device, cpu=True):
            "fwd_GBps": fb / (r["fwd_ms"] * 1e-3) / 1e9, "fwd_frac_hbm": fb / (r["fwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "fwd_traffic_bytes": pmc_traffic("config4", "rel_attn_fwd") if (a.dim == 300 and a.synth_scale == 1.0) else None,
            "fwd_bf16_traffic_bytes": pmc_traffic("config4", "rel_attn_fwd", section="kernels_bf16") if (a.dim == 300 and a.synth_scale == 1.0) else None,
-           "fwd_traffic_source": "profiles/r4_pmc_config4.json (committed rocprofv3 --pmc passes; not collected by this run)",
+           "fwd_traffic_source": "%s (committed rocprofv3 --pmc passes; not collected by this run)" % pmc_source("config4"),
            "bwd_ms": r["bwd_ms"], "bwd_GBps": bb / (r["bwd_ms"] * 1e-3) / 1e9,
            "bwd_frac_hbm": bb / (r["bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bwd_bytes": "SURVEY 8d backward formula",
            "bwd_edges_per_s": e / (r["bwd_ms"] * 1e-3)}
@@ -1265,11 +1265,11 @@ def complete_sharded_line(line, a):
             line["cpu_baseline"] = {"error": str(ex)}
     if a.dim == 300 and a.synth_scale == 1.0:
         line["roofline"]["traffic"] = pmc_traffic("config4", "rel_attn_fwd")
-        line["roofline"]["traffic_source"] = ("profiles/r4_pmc_config4.json (committed rocprofv3 --pmc passes of the same kernel on "
+        line["roofline"]["traffic_source"] = (pmc_source("config4") + " (committed rocprofv3 --pmc passes of the same kernel on "
                                               "one rank's graph; not collected by this run)")
 
 
-def pmc_traffic(key, kernel_prefix, rounds=("r4", "r3", "r2"), section="kernels"):
+def pmc_traffic(key, kernel_prefix, rounds=("r5", "r4", "r3", "r2"), section="kernels"):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r2_pmc_<key>.json), or None.
     PMC collection needs rocprofv3 around the process, so bench.py reports the committed measurement."""
     for rnd in rounds:
@@ -1283,13 +1283,28 @@ def pmc_traffic(key, kernel_prefix, rounds=("r4", "r3", "r2"), section="kernels"
     return None
 
 
+def pmc_source(key, rounds=("r5", "r4", "r3", "r2")):
+    """The newest committed PMC file for ``key`` (what pmc_traffic reads), for the line's *_source fields."""
+    for rnd in rounds:
+        fn = os.path.join("profiles", "%s_pmc_%s.json" % (rnd, key))
+        if os.path.exists(os.path.join(ROOT, fn)):
+            return fn
+    return None
+
+
 def pmc_mfma_util():
-    """rocprofv3's MfmaUtil for sim_gemm_kernel from the committed PMC pass (profiles/r3_pmc_mfma.json), or None."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_mfma.json")))
-        return d["kernels"]["sim_gemm_kernel"]["MfmaUtil_percent_mean"]
-    except (OSError, KeyError, ValueError):
-        return None
+    """(rocprofv3's MfmaUtil for sim_gemm_kernel from the newest committed PMC pass, that file's name), or (None, None)."""
+    for rnd in ("r5", "r3"):
+        fn = os.path.join("profiles", "%s_pmc_mfma.json" % rnd)
+        try:
+            d = json.load(open(os.path.join(ROOT, fn)))
+            d = d.get("kernels", d)
+            for k, v in d.items():
+                if "sim_gemm" in k:
+                    return v["MfmaUtil_percent_mean"], fn
+        except (OSError, KeyError, ValueError, AttributeError):
+            pass
+    return None, None
 
 
 def main():
@@ -1380,7 +1395,7 @@ def main():
     ms = el / a.steps * 1e3
     layer_calls = 3
     value = world * layer_calls * w.E * a.steps / el
-    roof_src = "profiles/r4_pmc_ja.json (committed rocprofv3 --pmc passes on the same real-graph workload; not collected by this run)"
+    roof_src = "%s (committed rocprofv3 --pmc passes on the same real-graph workload; not collected by this run)" % pmc_source("ja")
     if dist_on:
         # N > 1: the headline is the path that actually shards -- BASELINE config 4 weak-scaled, destination-sharded, RCCL
         # all-gather / reduce-scatter per layer (north_star: "Partition ... across the 8 GPUs ... only when the graph

@@ -128,11 +128,12 @@ def run_sharded(a, rank, world, device):
     rec, ops.PROFILE = ops.PROFILE, None
     crec, jdist.COMM_PROFILE = jdist.COMM_PROFILE, None
     fwd = [e0.elapsed_time(e1) for n, e0, e1 in rec if n == "rel_attn_fwd"]
-    bwd = [e0.elapsed_time(e1) for n, e0, e1 in rec if n == "rel_attn_bwd"]
+    # (the overlapped backward of the pipelined exchange records its phases separately: "rel_attn_bwd_phase13", "..._phase2" per slab)
+    bwd = [e0.elapsed_time(e1) for n, e0, e1 in rec if n.startswith("rel_attn_bwd")]
     fb = synth.fwd_algorithmic_bytes(n_loc, e_loc, d)
     bb = synth.bwd_algorithmic_bytes(n_loc, e_loc, d)
     # per LAYER: the pipelined exchange runs the forward kernel once per chunk (partial passes over disjoint edge sets)
-    fms, bms = float(np.sum(fwd)) / (nprof * len(layers)), float(np.mean(bwd))
+    fms, bms = float(np.sum(fwd)) / (nprof * len(layers)), float(np.sum(bwd)) / (nprof * len(layers))
     # a record that proves itself: which backend carried the collectives and how many ranks it saw (an all-reduce of ones, not
     # the launcher's WORLD_SIZE); a figure the backend cannot time is null, not 0.0
     backend = dist.get_backend() if (world > 1 and dist.is_initialized()) else None

@@ -1405,7 +1405,9 @@ __global__ __launch_bounds__(kBlock) void rel_attn_bwd_dst_kernel(BwdArgs a, int
             float4 nbv = mul4(oraw[k], inv_kappa);                 // nb_i = out/kappa - (Z[i] - Rz[loop])
             if (has_loop) nbv = sub4(nbv, sub4(zraw[k], rl[k]));
             gv[k] = sel4(L.is_v(k), g);
-            tpart += dot4(gv[k], nbv);
+            // (off the v lanes nbv holds whatever the clamped loads fetched -- e.g. the Q half of row i, which callers that
+            // project Q for SOURCE rows only never write: select it away, 0 x garbage is not 0)
+            tpart += dot4(gv[k], sel4(L.is_v(k), nbv));
         }
         const float t_i = wave_sum(tpart);
         const float inv_l = l_i > 0.f ? 1.f / l_i : 0.f;

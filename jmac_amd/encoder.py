@@ -381,6 +381,96 @@ class _RelCompact:
 COMPACT_RELATIONS = True      # tests / A-B: False runs every relation-side product on all nr rows
 
 
+# ---- active rows: the projections on the rows the graph needs ----------------------------------------------------------------
+# P = X Wt is read for DESTINATIONS only, Q = X Wb for SOURCES only (src/jmac_model.py:75-76,85: x_i / x_j of the edges); only
+# Z = X Wg is needed for every row (the self loop, :44-45).  On the real ja train graph that is 5 425 / 4 401 / 11 805 of 11 805
+# rows: 61 % of the projection's flops, forward and in the input gradient.  The library's GEMMs take row RANGES, not row lists
+# (profiles/r5_active_rows.txt: a row-list MFMA kernel of this library runs these shapes at half the library's rate), so the
+# encoder node orders the entities BY CLASS inside itself -- [destination only | destination and source | source only | neither]
+# -- which makes the destinations rows [0, nD) and the sources rows [s0, s1): three row-range products per projection instead of
+# one full one.  The permutation never leaves the node: its inputs are gathered into class order on the way in, its outputs and
+# input gradients gathered back on the way out (jmac_rows_{compact,expand}_f32: one launch each), the graph is re-indexed once
+# per graph (cached on it).  P rows of non-destinations / Q rows of non-sources are never written and never read.
+ACTIVE_ROWS = True            # tests / A-B: False keeps the entity order and the full products
+ACTIVE_ROWS_MAX_FRACTION = 0.85   # taken only where (destinations + sources) / 2N is below this: the copies must pay for themselves
+ACTIVE_ROWS_MIN_N = 4096
+
+
+class _RowOrder:
+    """Class order of one graph's entities + the graph re-indexed in it."""
+
+    def __init__(self, graph: RelGraph):
+        dev, N, E = graph.device, graph.N, graph.E
+        deg = graph.degrees()
+        is_dst = deg > 0
+        is_src = torch.zeros(N, dtype=torch.bool, device=dev)
+        col = graph.col[:E].long()
+        is_src[col] = True
+        cls = torch.where(is_dst & ~is_src, 0, torch.where(is_dst & is_src, 1, torch.where(is_src, 2, 3)))
+        self.old_of_new = torch.sort(cls, stable=True)[1].contiguous()          # int64 [N]: row of the caller's table per node row
+        self.new_of_old = torch.empty_like(self.old_of_new)
+        self.new_of_old[self.old_of_new] = torch.arange(N, device=dev)
+        self.pos32 = self.new_of_old.to(torch.int32).contiguous()               # jmac_rows_expand_f32's position list
+        n = torch.bincount(cls, minlength=4).tolist()                           # one host read per graph (build time)
+        self.nD, self.s0, self.s1 = n[0] + n[1], n[0], n[0] + n[1] + n[2]
+        self.N = N
+        self.fraction = (self.nD + (self.s1 - self.s0)) / (2.0 * max(N, 1))
+        dst = torch.repeat_interleave(torch.arange(N, device=dev), deg.long())
+        ei = torch.stack((self.new_of_old[dst], self.new_of_old[col])).contiguous()
+        et = graph.etype[:E].long().contiguous()
+        from ._lib import mark_index_range
+        mark_index_range(ei, N)
+        mark_index_range(et, graph.num_rel)
+        self.graph = RelGraph(ei, et, N, graph.num_rel, graph.chunk_arg)
+        self.graph._key_refs = (ei, et)
+        self._info = {}
+
+    def info_rows(self, info):
+        """The constant name embeddings in class order (kept: the cat buffer cache keys on the tensor)."""
+        hit = self._info.get(id(info))
+        if hit is None or hit[0] is not info or hit[1] != info._version:
+            if len(self._info) > 8:
+                self._info.clear()
+            hit = (info, info._version, info.index_select(0, self.old_of_new).contiguous())
+            self._info[id(info)] = hit
+        return hit[2]
+
+
+def _row_order(cfg, graph: RelGraph, N: int):
+    """The class order for this call, or None: one KG (no row blocks), enough rows, fp32 tables, and few enough active rows."""
+    if not ACTIVE_ROWS or getattr(cfg, "seg", None) is not None or N < ACTIVE_ROWS_MIN_N or graph.E == 0 or graph.num_src != graph.N:
+        return None
+    if cfg.table_dtype != torch.float32 or torch.cuda.is_current_stream_capturing() and getattr(graph, "_row_order", None) is None:
+        return None
+    ro = getattr(graph, "_row_order", None)
+    if ro is None:
+        ro = graph._row_order = _RowOrder(graph)
+    return ro if ro.fraction <= ACTIVE_ROWS_MAX_FRACTION else None
+
+
+def _gather_rows(tables, index):
+    """[t[index] for t in tables] (fp32 [*, d] with unit inner stride; up to 4 per launch): jmac_rows_compact_f32."""
+    n, d = int(index.numel()), tables[0].shape[1]
+    tables = [t_ if t_.stride(-1) == 1 else t_.contiguous() for t_ in tables]
+    out = [_empty(t_.device, n, d) for t_ in tables]
+    ld = (C.c_int64 * len(tables))(*[t_.stride(0) for t_ in tables])
+    check(lib().jmac_rows_compact_f32(_vp_array(tables), ld, _vp_array(out), len(tables), ptr(index), n, d, stream()),
+          "jmac_rows_compact_f32")
+    return out
+
+
+def _scatter_rows(src, pos32, dst=None):
+    """dst[r] (+)= src[pos32[r]]: jmac_rows_expand_f32 (``dst`` given: accumulate onto it; else a fresh table)."""
+    n, d = int(pos32.numel()), src.shape[1]
+    acc = dst is not None
+    if dst is None:
+        dst = _empty(src.device, n, d)
+    ld = (C.c_int64 * 1)(dst.stride(0))
+    check(lib().jmac_rows_expand_f32(_vp_array([src.contiguous()]), _vp_array([dst]), ld, (C.c_int32 * 1)(1 if acc else 0), 1, ptr(pos32), n,
+                                     d, stream()), "jmac_rows_expand_f32")
+    return dst
+
+
 # ---- layer pieces -------------------------------------------------------------------------------------------------------
 LAYER_PARAMS = ("rel_transform_weight1", "rel_transform_weight2", "loop_rel", "w_att", "a_att", "gcn_weight")
 
@@ -535,7 +625,7 @@ class _MlpChain:
                  gemm_task(self.L12u, dWp, dW1, ta=True, accumulate=True)]], (dW1, dW2, dloop), (dL11u, dL12u)
 
 
-def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch.float32, seg=None, compact=False):
+def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch.float32, seg=None, compact=False, rows=None):
     """Node side of one RelationAwareLayer (src/jmac_model.py:44-52) given its relation tables: state for the backward.
     ``table_dtype`` bf16 (inference form, no backward: BASELINE config 3): the [P|Q|Z] table comes out of a bf16 GEMM and the
     relation table is rounded to bf16; the aggregation gathers half the bytes, its arithmetic and everything after it is fp32."""
@@ -552,13 +642,23 @@ def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch
             RR = RRp
         else:
             RR = RR.to(torch.bfloat16)
+    elif rows is not None:
+        # class-ordered rows (_RowOrder): P for the destinations [0, nD), Q for the sources [s0, s1), Z for every row -- the other
+        # P / Q rows are never read by the aggregation kernels (a destination without in-edges takes the self-loop path only)
+        d = wc.shape[0]
+        PQZ = _empty(X.device, X.shape[0], 3 * d)
+        torch.mm(X, wc[:, 2 * d:], out=PQZ[:, 2 * d:])
+        if rows.nD > 0:
+            torch.mm(X[:rows.nD], wc[:, :d], out=PQZ[:rows.nD, :d])
+        if rows.s1 > rows.s0:
+            torch.mm(X[rows.s0:rows.s1], wc[:, d:2 * d], out=PQZ[rows.s0:rows.s1, d:2 * d])
     else:
         PQZ = torch.mm(X, wc)                                         # [P|Q|Z]: one library GEMM
     slope = float(lay.atv_mlp.negative_slope)
     pre, smax, sden = _agg_fwd(PQZ, RR, a, graph, slope, compact=compact)
     mean, invstd, use_batch = _bn_fwd(pre, lay.bn, training, y, y2, seg)
     return SimpleNamespace(X=X, wc=wc, RR=RR, a=a, PQZ=PQZ, pre=pre, smax=smax, sden=sden, y=y, mean=mean, invstd=invstd,
-                           use_batch=use_batch, slope=slope, bn_weight=lay.bn.weight, seg=seg, compact=compact)
+                           use_batch=use_batch, slope=slope, bn_weight=lay.bn.weight, seg=seg, compact=compact, rows=rows)
 
 
 def _layer_bwd(st, graph, gy, gy2, dX, dX_accumulate):
@@ -566,7 +666,20 @@ def _layer_bwd(st, graph, gy, gy2, dX, dX_accumulate):
     da, gbw."""
     gpre, gbw = _bn_bwd(st.pre, st.y, gy, gy2, st.bn_weight, st.mean, st.invstd, st.use_batch, st.seg)
     dPQZ, dRR, da = _agg_bwd(st.PQZ, st.RR, st.a, graph, st.slope, st.pre, st.smax, st.sden, gpre, compact=st.compact)
-    if dX is not None:
+    rows = getattr(st, "rows", None)
+    if dX is not None and rows is not None:
+        # class-ordered rows: dP is zero outside the destinations, dQ outside the sources -- the three terms of the input gradient
+        # on their row ranges (dZ: every row)
+        d = st.wc.shape[0]
+        if dX_accumulate:
+            dX.addmm_(dPQZ[:, 2 * d:], st.wc[:, 2 * d:].t())
+        else:
+            torch.mm(dPQZ[:, 2 * d:], st.wc[:, 2 * d:].t(), out=dX)
+        if rows.nD > 0:
+            dX[:rows.nD].addmm_(dPQZ[:rows.nD, :d], st.wc[:, :d].t())
+        if rows.s1 > rows.s0:
+            dX[rows.s0:rows.s1].addmm_(dPQZ[rows.s0:rows.s1, d:2 * d], st.wc[:, d:2 * d].t())
+    elif dX is not None:
         if dX_accumulate:
             dX.addmm_(dPQZ, st.wc.t())
         else:
@@ -764,6 +877,14 @@ class _EncoderName(torch.autograd.Function):
         N, d = E.shape
         di = info.shape[1]
         t = SimpleNamespace()
+        # active rows: inside the node the entities are in CLASS order (_RowOrder) -- E_n / info_n are the inputs gathered into it,
+        # the graph is the re-indexed one, the projections run on row ranges; outputs are gathered back at the end
+        t.ro = ro = _row_order(cfg, graph, N)
+        E_n, info_n = E, info
+        if ro is not None:
+            graph = ro.graph
+            (E_n,) = _gather_rows([E], ro.old_of_new)
+            info_n = ro.info_rows(info)
         # :177 + :180  cat(comp0, info @ name_linear) @ U11  ==  cat(comp0, info) @ [U11_top ; name_linear @ U11_bottom]
         t.w = _empty(dev, d + di, d)
         # weights: [Wt|Wb|Wg] per layer; the U11_top block of t.w is copied by the same launch
@@ -784,34 +905,47 @@ class _EncoderName(torch.autograd.Function):
                     [fa[2], fc[2], *f2[1], mc[1]],
                     f2[2]])
         # ---- node side.  cat buffers: cat0 = [comp0 | info] (:180), cat1 = [c1n | a1] (:192), catA = [align0 | a1 | a2] (:203)
-        t.cat0_lease = _cat0_take(getattr(cfg, "cache", None), info, N, d, dev,
+        t.cat0_lease = _cat0_take(getattr(cfg, "cache", None), info_n, N, d, dev,
                                    persistent=getattr(cfg, "info_persistent", False))     # right block = info, already in place
         t.cat0, t.cat1, t.catA = t.cat0_lease.buf, _empty(dev, N, 2 * d), _empty(dev, N, 3 * d)
         # dropout draws: two device-resident seeds from torch's generator (one tiny launch, fresh on every replay of a captured
         # step); the normalise kernels draw from them, forward and backward -- no [N, d] mask is written or read
         seeds = (torch.empty(2, dtype=torch.int64, device=dev).random_() if training and p_drop > 0.0 else None)
         sd = (lambda i: seeds[i:i + 1]) if seeds is not None else (lambda i: None)
-        t.inv0, t.drop0 = _norm_drop_fwd(E, p_drop, training, t.cat0[:, :d], seed=sd(0))                  # :179
+        t.inv0, t.drop0 = _norm_drop_fwd(E_n, p_drop, training, t.cat0[:, :d], seed=sd(0))                # :179
         align0 = t.catA[:, :d]
         torch.mm(t.cat0, t.w, out=align0)                                                       # :180
         a_att = [p[4].reshape(-1) for p in (pa, pc, p2)]
         seg = getattr(cfg, "seg", None)
         t.sa = _layer_fwd(la, align0, t.wc[0], t.cha.RR, a_att[0], graph, training, t.catA[:, d:2 * d], t.cat1[:, d:],
-                          table_dtype=cfg.table_dtype, seg=seg, compact=t.rc.on)                                        # :183
+                          table_dtype=cfg.table_dtype, seg=seg, compact=t.rc.on, rows=ro)                               # :183
         c1 = _empty(dev, N, d)
-        t.sc = _layer_fwd(lc, E, t.wc[1], t.chc.RR, a_att[1], graph, training, c1, table_dtype=cfg.table_dtype, seg=seg,
-                          compact=t.rc.on)                                           # :190
+        t.sc = _layer_fwd(lc, E_n, t.wc[1], t.chc.RR, a_att[1], graph, training, c1, table_dtype=cfg.table_dtype, seg=seg,
+                          compact=t.rc.on, rows=ro)                                  # :190
         t.inv1, t.drop1 = _norm_drop_fwd(c1, p_drop, training, t.cat1[:, :d], seed=sd(1))                 # :191
         t.a_in = torch.mm(t.cat1, U21)                                                          # :192
         t.s2 = _layer_fwd(l2, t.a_in, t.wc[2], t.ch2.RR, a_att[2], graph, training, t.catA[:, 2 * d:],
-                          table_dtype=cfg.table_dtype, seg=seg, compact=t.rc.on)                                        # :197
+                          table_dtype=cfg.table_dtype, seg=seg, compact=t.rc.on, rows=ro)                               # :197
         align_out = torch.mm(t.catA, Wall)                                                      # :203
+        if ro is not None:                                   # back into the caller's entity order (one launch for both outputs)
+            t.E_n, t.c1_n = E_n, c1                          # class-order tensors the backward reads (neither is an output)
+            align_out, c1 = _gather_rows([align_out, c1], ro.new_of_old)
         if CAPTURE is not None:
+            back = (lambda x: x[ro.new_of_old]) if ro is not None else (lambda x: x.clone())
             rel_a_in = torch.mm(F.leaky_relu(torch.mm(Ra.detach(), L11u.detach()), mslope), L12u.detach())   # (:196) on all rows
-            CAPTURE.update(conv1_alignment=(align0.clone(), Ra.detach()), conv1_completion=(E.detach(), Rc.detach()),
-                           conv2_alignment=(t.a_in.clone(), rel_a_in))
+            CAPTURE.update(conv1_alignment=(back(align0), Ra.detach()), conv1_completion=(E.detach(), Rc.detach()),
+                           conv2_alignment=(back(t.a_in), rel_a_in))
             for name, st, ch in (("conv1_alignment", t.sa, t.cha), ("conv1_completion", t.sc, t.chc), ("conv2_alignment", t.s2, t.ch2)):
-                CAPTURE[name + ".tables"] = (st.PQZ, t.rc.full_rows(st.RR))  # the very tables the aggregation kernel gathered
+                # the very tables the aggregation kernel gathered (class order: back in the caller's; P / Q rows no edge names hold
+                # whatever the buffer held -- zero them for the tests' arithmetic)
+                PQZ_c = st.PQZ
+                if ro is not None:
+                    PQZ_c = st.PQZ.clone()
+                    PQZ_c[ro.nD:, :d] = 0
+                    PQZ_c[:ro.s0, d:2 * d] = 0
+                    PQZ_c[ro.s1:, d:2 * d] = 0
+                    PQZ_c = PQZ_c[ro.new_of_old]
+                CAPTURE[name + ".tables"] = (PQZ_c, t.rc.full_rows(st.RR))
                 CAPTURE[name + ".rel_act"] = ch.T                        # the relation transform's activation (its sign = the kink side)
             # rows of the compact relation tables (graph.rel_used, then the loop row), None = all rows
             CAPTURE["rel_used"] = graph.rel_used if t.rc.on else None
@@ -831,12 +965,21 @@ class _EncoderName(torch.autograd.Function):
         # c1 is an OUTPUT of this node (the unpacked tensor carries this node as grad_fn): it must not be stored on ctx.t --
         # that cycle keeps the whole graph (and the parameters' AccumulateGrad nodes, with the stream they were created on)
         # alive past the step, which breaks a later stream capture
+        ro = t.ro
+        E_x, c1_y = (t.E_n, t.c1_n) if ro is not None else (E, c1)       # class order inside the node (forward)
         sc = SimpleNamespace(**vars(t.sc))
-        sc.y = c1
-        graph = cfg.graph
+        sc.y = c1_y
+        graph = ro.graph if ro is not None else cfg.graph
         dev = E.device
         have_align = g_align is not None
         have_c = have_align or g_c1 is not None
+        if ro is not None and have_c:                        # the incoming gradients into class order: one launch
+            gin = [g for g in (g_align, g_c1) if g is not None]
+            gout = _gather_rows(gin, ro.old_of_new)
+            if g_align is not None:
+                g_align = gout[0]
+            if g_c1 is not None:
+                g_c1 = gout[-1]
         dE = None
         dRa = dRc = None
         dWall = dU21 = dU11 = dNL = gL11 = gL12 = gL11u = gL12u = None
@@ -863,11 +1006,12 @@ class _EncoderName(torch.autograd.Function):
             gy, gy2 = None, None
             if have_align:
                 gy = _empty(dev, N, d)
-                _norm_drop_bwd(c1, t.inv1, t.drop1, dcat1[:, :d], gy, False)
+                _norm_drop_bwd(c1_y, t.inv1, t.drop1, dcat1[:, :d], gy, False)
                 gy2 = g_c1.contiguous() if g_c1 is not None else None
             else:
                 gy = g_c1.contiguous()
-            taken = _take_grad(g_E0, (N, d))           # the layer-0 loss gradient: this node's input gradient goes on top of it
+            # the layer-0 loss gradient: this node's input gradient goes on top of it (class order: at the very end, below)
+            taken = _take_grad(g_E0, (N, d)) if ro is None else None
             if taken is not None:
                 dE, g_E0 = taken, None
             else:
@@ -882,7 +1026,7 @@ class _EncoderName(torch.autograd.Function):
             t.cat0_lease.check()
             dw = torch.mm(t.cat0.t(), d_align0)                                  # [d+di, d]
             t.cat0_lease.release()                                               # last reader of cat0
-            _norm_drop_bwd(E, t.inv0, t.drop0, d_comp0, dE, True)
+            _norm_drop_bwd(E_x, t.inv0, t.drop0, d_comp0, dE, True)
             dU11 = _empty(dev, 2 * d, d)                                         # [:d] <- dw[:d] by the unpack launch below
             dNL = _empty(dev, di, d)
             levels[0].extend([gemm_task(dw[d:], U11[d:], dNL, tb=True, defer=True), gemm_task(NL, dw[d:], dU11[d:], ta=True, defer=True)])
@@ -931,6 +1075,11 @@ class _EncoderName(torch.autograd.Function):
         t.cat0_lease.release()
         if dRc is None and wrote_c:                    # nothing but the taken-over layer-0 gradient
             dRc = dRc_full
+        if ro is not None and dE is not None:          # class order -> the caller's, onto the layer-0 loss gradient where it may
+            taken = _take_grad(g_E0, (N, d))
+            dE = _scatter_rows(dE, ro.pos32, dst=taken)
+            if taken is not None:
+                g_E0 = None
         dE, dRc = _plus(dE, g_E0), _plus(dRc, g_Rc0)   # layer-0 gradients this backward could not take over: added here
         return (None, dE, dRc, dRa, None, dNL, dU11, dU21, dWall, gL11, gL12, gL11u, gL12u, *ga, *gc, *g2)
 

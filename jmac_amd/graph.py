@@ -131,6 +131,7 @@ class RelGraph:
     def __init__(self, edge_index: torch.Tensor, edge_type: torch.Tensor, num_nodes: int, num_rel: int,
                  chunk: Optional[int] = DEFAULT_CHUNK, num_src: Optional[int] = None):
         require_device(edge_index, edge_type)
+        self.chunk_arg = chunk                 # as asked for (None = automatic): what a re-indexed copy of this graph is built with
         chunk_dst = chunk
         if chunk is None:
             chunk = auto_chunk(int(edge_index.shape[1]))

@@ -534,3 +534,58 @@ def test_relation_side_on_used_rows_equals_all_rows(no_name):
         unused = np.setdiff1d(np.arange(nr), used)
         if not no_name and g1["rel_init_att_alignment"] is not None:
             assert float(g1["rel_init_att_alignment"][unused].abs().max()) == 0.0       # exactly zero on rows no edge names
+
+
+@pytest.mark.parametrize("use", [("align", "comp", "rel"), ("comp", "rel")])
+def test_active_row_projections_equal_the_full_products(use, monkeypatch):
+    """Round 5: inside the encoder node the entities are in CLASS order (destination only | both | source only | neither) and the
+    projections run on row ranges -- P for the destinations, Q for the sources, Z for every row (encoder._RowOrder;
+    src/jmac_model.py:75-76,85).  Outputs, every gradient and the BatchNorm buffers must equal the full-product form
+    (ACTIVE_ROWS = False) to rounding, on a graph with all four classes; and nothing may ever READ a P / Q row that was not
+    written: the [N, 3d] tables are poisoned with NaN before the products write their row ranges, so one such read that reaches
+    any arithmetic would surface as NaN in an output or a gradient (it found one: pass A of the backward multiplied the clamped
+    loads of the self row's Q half by zero instead of selecting them away)."""
+    from jmac_amd import encoder
+    n, nr, d, di = 6000, 37, 64, 20
+    rng = np.random.default_rng(7)
+    e = 9000
+    dst = rng.choice(n // 2, size=e)                              # half of the entities are never destinations
+    src = rng.choice(np.arange(n // 4, n * 3 // 4), size=e)       # a different half are never sources; a quarter neither
+    dst[:300] = 11                                                # a hub
+    ei = torch.from_numpy(np.stack([dst, src]).astype(np.int64)).to(DEV)
+    et = torch.from_numpy(rng.integers(0, nr, e).astype(np.int64)).to(DEV)
+    m = _model(d, n, nr, di, False, 13)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    G = {k: torch.randn(s, device=DEV, generator=gen) for k, s in
+         (("align", (n, d)), ("c1", (n, d)), ("c0", (n, d)), ("r1", (nr, d)), ("r0", (nr, d)))}
+    m.train()
+    real_empty = encoder._empty
+
+    def poisoned(dev, *shape):                                   # the [P|Q|Z] tables (and their gradients: fully written anyway)
+        t_ = real_empty(dev, *shape)
+        return t_.fill_(float("nan")) if tuple(shape) == (n, 3 * d) else t_
+    monkeypatch.setattr(encoder, "_empty", poisoned)
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(encoder, "ACTIVE_ROWS", flag)
+        res[flag] = _run(m, True, ei, et, n, nr, use, G)
+        if flag:
+            from jmac_amd.graph import graph_cache
+            g = graph_cache.get(ei, et, n, nr + 1, m.conv1_completion.chunk)
+            ro = g._row_order
+            assert 0 < ro.s0 < ro.nD < ro.s1 < n and ro.fraction < 0.6          # all four classes; the path was taken
+    (out_a, g_a, bn_a), (out_f, g_f, bn_f) = res[True], res[False]
+    for a, b, what in zip(out_a, out_f, ("align_out", "c1", "rel_c1")):
+        assert bool(torch.isfinite(a).all()), what
+        assert_close(a, b, 2e-5, 1e-6, what)
+    for k in bn_f:
+        assert_close(bn_a[k], bn_f[k], 1e-5, 1e-7, k)
+    scale = max(float(g.abs().max()) for g in g_f.values() if g is not None)
+    for k, ref in g_f.items():
+        got = g_a[k]
+        if ref is None:
+            assert got is None or float(got.abs().max()) == 0.0, k
+            continue
+        assert got is not None and bool(torch.isfinite(got).all()), k
+        atol = 1e-4 * scale if k.endswith("loop_rel") else 1e-6 * scale
+        assert_close(got, ref, 1e-4, atol, "grad " + k)

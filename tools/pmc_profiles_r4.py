@@ -1,9 +1,10 @@
 """gpurun_out/pmc_r4/summary.json (tools/pmc_collect_r4.sh) -> profiles/r4_pmc_{config4,union,ja}.json: the summary's per-kernel
 counters + the workloads' algorithmic byte counts and the traffic / algorithmic ratios bench.py reads.
-usage: python tools/pmc_profiles_r4.py [gpurun_out/pmc_r4]"""
+usage: python tools/pmc_profiles_r4.py [gpurun_out/pmc_r4] [round tag, default r4]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc_r4")
+RND = sys.argv[2] if len(sys.argv) > 2 else "r4"
 s = json.load(open(os.path.join(src, "summary.json")))
 METHOD = ("rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc TCC_HIT_sum TCC_MISS_sum in separate passes (tools/pmc_collect_r4.sh, "
           "summarised by tools/pmc_summarize_r4.py); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of "
@@ -44,13 +45,13 @@ c4["ratios"] = {"fwd_f32_traffic_over_algorithmic": kf["traffic_bytes_corrected"
                 "fwd_bf16_traffic_over_algorithmic": kb["traffic_bytes_corrected"] / a_b,
                 "calibration_f32": cf["traffic_bytes_corrected"] / 51_772_000_000 if cf else None,
                 "calibration_bf16": cb["traffic_bytes_corrected"] / 26_908_000_000 if cb else None}
-dump("r4_pmc_config4.json", c4)
+dump(RND + "_pmc_config4.json", c4)
 if s.get("union"):
-    dump("r4_pmc_union.json", {
+    dump(RND + "_pmc_union.json", {
         "workload": "config 3: the REAL union of the five DBP-5L KGs, N=56 589, E=197 604 (train-mode graphs), nr=4805, d=300 "
                     "(tools/union_agg_probe.py); fp32 and bf16 tables (bf16 halves padded to 304)",
         "method": METHOD, "algorithmic_bytes_fwd": 612323100, "algorithmic_bytes_fwd_bf16": 341244900,
         "note": "341-612 MB working sets: Infinity-Cache resident, traffic below the algorithmic bytes", "kernels": s["union"]})
 if s.get("ja"):
-    dump("r4_pmc_ja.json", {"workload": "the REAL DBP-5L ja KG, train-mode graph N=11 805, E=17 979, d=300 (tools/ja_sweep.py ja-real)",
+    dump(RND + "_pmc_ja.json", {"workload": "the REAL DBP-5L ja KG, train-mode graph N=11 805, E=17 979, d=300 (tools/ja_sweep.py ja-real)",
                             "method": METHOD, "algorithmic_bytes_fwd": 71767092, "algorithmic_bytes_bwd": 129129912, "kernels": s["ja"]})
