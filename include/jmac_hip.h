@@ -508,6 +508,14 @@ int jmac_wcat_pack_f32(const float* const* w_att, const float* const* gcn, float
                        int32_t n_layers, int64_t d, const float* extra_src, float* extra_dst,
                        int64_t extra_floats, int64_t* const* counters, int32_t n_counters,
                        jmac_stream_t stream);
+/* The same with the step's DROPOUT SEEDS riding along (round 5): seed_state [2] = persistent device int64 words, advanced by one
+ * per launch; seed_out [2] receives the advanced values -- the seeds jmac_row_normalize_dropseed_{fwd,bwd}_f32 draw from in this
+ * step (completion_dropout, src/jmac_model.py:179,191).  No torch RNG op per step: a captured step that uses none is replayed
+ * without the generator-state fills torch puts in front of every replay of a graph that does.  Both NULL: as above. */
+int jmac_wcat_pack_seed_f32(const float* const* w_att, const float* const* gcn, float* const* wcat, int32_t n_layers,
+                            int64_t d, const float* extra_src, float* extra_dst, int64_t extra_floats,
+                            int64_t* const* counters, int32_t n_counters, int64_t* seed_state, int64_t* seed_out,
+                            jmac_stream_t stream);
 int jmac_wcat_unpack_f32(const float* const* dwcat, float* const* d_watt, float* const* d_gcn,
                          int32_t n_layers, int64_t d, const float* extra_src, float* extra_dst,
                          int64_t extra_floats, jmac_stream_t stream);

@@ -94,6 +94,7 @@ _SIGS = {
     "jmac_row_normalize_dropseed_bwd_f32": (C.c_int, [vp, i64, vp, vp, f32, vp, i64, i64, i64, f32, vp, i64, i32, vp]),
     "jmac_gemm_grouped_f32": (C.c_int, [C.POINTER(GemmTask), i32, vp]),
     "jmac_wcat_pack_f32": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, vp, vp, i64, C.POINTER(vp), i32, vp]),
+    "jmac_wcat_pack_seed_f32": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, vp, vp, i64, C.POINTER(vp), i32, vp, vp, vp]),
     "jmac_wcat_unpack_f32": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, vp, vp, i64, vp]),
     "jmac_rows_compact_f32": (C.c_int, [C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), i32, vp, i64, i64, vp]),
     "jmac_rows_expand_f32": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(i32), i32, vp, i64, i64, vp]),

@@ -620,12 +620,19 @@ struct WcatArgs {
     int64_t extra_n4;                      // float4s
     int64_t* counters[JMAC_WCAT_MAX];      // incremented by one (BatchNorm's num_batches_tracked of the layers), pack only
     int n_counters;
+    int64_t* seed_state;                   // pack only: [2] persistent dropout seed words, advanced by one per launch ...
+    int64_t* seed_out;                     // ... and copied here: the seeds THIS step's normalise + dropout kernels draw from
     int n, d;
 };
 template <bool ADJOINT>
 __global__ __launch_bounds__(256) void wcat_kernel(const WcatArgs a) {
     const int l = blockIdx.y, d = a.d, D4 = d / 4;
     if (!ADJOINT && blockIdx.x == 0 && l == 0 && threadIdx.x < (unsigned)a.n_counters) a.counters[threadIdx.x][0] += 1;
+    if (!ADJOINT && blockIdx.x == 0 && l == 0 && a.seed_state && threadIdx.x >= 64 && threadIdx.x < 66) {
+        const int64_t v = a.seed_state[threadIdx.x - 64] + 1;
+        a.seed_state[threadIdx.x - 64] = v;
+        a.seed_out[threadIdx.x - 64] = v;
+    }
     if (l == a.n) {                                            // the extra copy
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.extra_n4; i += (int64_t)gridDim.x * 256)
             st4(a.extra_dst + 4 * i, ld4(a.extra_src + 4 * i));
@@ -776,9 +783,18 @@ static int wcat_extra(WcatArgs& a, const float* src, float* dst, int64_t n) {
 int jmac_wcat_pack_f32(const float* const* w_att, const float* const* gcn, float* const* wcat, int32_t n_layers, int64_t d,
                        const float* extra_src, float* extra_dst, int64_t extra_floats, int64_t* const* counters,
                        int32_t n_counters, jmac_stream_t stream) {
+    return jmac_wcat_pack_seed_f32(w_att, gcn, wcat, n_layers, d, extra_src, extra_dst, extra_floats, counters, n_counters, nullptr,
+                                   nullptr, stream);
+}
+
+int jmac_wcat_pack_seed_f32(const float* const* w_att, const float* const* gcn, float* const* wcat, int32_t n_layers, int64_t d,
+                            const float* extra_src, float* extra_dst, int64_t extra_floats, int64_t* const* counters,
+                            int32_t n_counters, int64_t* seed_state, int64_t* seed_out, jmac_stream_t stream) {
     if (n_layers <= 0 || n_layers > JMAC_WCAT_MAX || d <= 0 || !w_att || !gcn || !wcat) return JMAC_EINVAL;
     if (d % 4) return JMAC_EDIM;
+    if ((seed_state == nullptr) != (seed_out == nullptr)) return JMAC_EINVAL;
     WcatArgs a{};
+    a.seed_state = seed_state; a.seed_out = seed_out;
     a.n = n_layers; a.d = (int)d;
     for (int i = 0; i < n_layers; ++i) {
         if (!w_att[i] || !gcn[i] || !wcat[i]) return JMAC_EINVAL;

@@ -493,16 +493,40 @@ def _extra_copy(copy):
     return ptr(src), ptr(dst), src.numel()
 
 
-def _wcat_pack(w_atts, gcns, d, copy=None, counters=()):
+def _wcat_pack(w_atts, gcns, d, copy=None, counters=(), seed=None):
     """[Wt | Wb | Wgcn] [d, 3d] of each layer (w_att = [Wt; Wb] stacked by rows, src/jmac_model.py:24,75-76): ONE launch for
     all layers of the call (torch.cat: one per layer).  ``copy`` = (src, dst): one more block copied by the same launch;
-    ``counters``: int64 device scalars it increments (the layers' num_batches_tracked)."""
+    ``counters``: int64 device scalars it increments (the layers' num_batches_tracked); ``seed`` = (state, out): the persistent
+    dropout seed words advanced by one and copied to ``out`` (the seeds of this step's draws)."""
     w_atts, gcns = [w.contiguous() for w in w_atts], [g.contiguous() for g in gcns]
     out = [_empty(w_atts[0].device, d, 3 * d) for _ in w_atts]
     counters = list(counters)
-    check(lib().jmac_wcat_pack_f32(_vp_array(w_atts), _vp_array(gcns), _vp_array(out), len(out), d, *_extra_copy(copy),
-                                   _vp_array(counters) if counters else None, len(counters), stream()), "jmac_wcat_pack_f32")
+    check(lib().jmac_wcat_pack_seed_f32(_vp_array(w_atts), _vp_array(gcns), _vp_array(out), len(out), d, *_extra_copy(copy),
+                                        _vp_array(counters) if counters else None, len(counters),
+                                        ptr(seed[0]) if seed is not None else None, ptr(seed[1]) if seed is not None else None,
+                                        stream()), "jmac_wcat_pack_seed_f32")
     return out
+
+
+def _drop_seed_state(cache, dev):
+    """The persistent dropout seed words of a model (device int64 [2]), or None.  Drawn from torch's generator whenever that
+    generator has been touched since this function last drew (re-seeded, or consumed by anything else) -- so ``torch.manual_seed``
+    reproduces a run exactly as before -- and otherwise left to the weight-pack launch, which advances it by one per step: a
+    step then contains NO torch RNG op, and a hipGraph of it is replayed without the two generator-state fills (and the launch
+    gap in front of them) torch adds to every replay of a graph that consumed random numbers.  Inside a stream capture the
+    generator is never touched: the state of the eager warm-up steps is used (None if there was none: the caller draws per step)."""
+    if cache is None:
+        return None
+    hit = cache.get("drop_seed")
+    if torch.cuda.is_current_stream_capturing():
+        return hit[0] if hit is not None and hit[0].device == dev else None
+    gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+    cur = (gen.initial_seed(), gen.get_offset())
+    if hit is not None and hit[1] == cur and hit[0].device == dev:
+        return hit[0]
+    state = torch.empty(2, dtype=torch.int64, device=dev).random_()
+    cache["drop_seed"] = (state, (gen.initial_seed(), gen.get_offset()))
+    return state
 
 
 def _wcat_unpack(dwcs, d, copy=None):
@@ -891,8 +915,13 @@ class _EncoderName(torch.autograd.Function):
         u11 = U11.contiguous()
         # ... and so are the layers' num_batches_tracked counters (nn.BatchNorm1d bumps them in train mode)
         t.bumped = [lay.bn.num_batches_tracked for lay in (la, lc, l2) if training and lay.bn.track_running_stats]
+        # ... and the step's dropout seeds: the model's persistent seed words advanced by one (no torch RNG op per step)
+        seeds = None
+        if training and p_drop > 0.0:
+            state = _drop_seed_state(getattr(cfg, "cache", None), dev)
+            seeds = (state, torch.empty(2, dtype=torch.int64, device=dev)) if state is not None else None
         t.wc = _wcat_pack([p[3] for p in (pa, pc, p2)], [p[5] for p in (pa, pc, p2)], d, copy=(u11[:d], t.w[:d]),
-                          counters=t.bumped)
+                          counters=t.bumped, seed=seeds)
         # ---- relation side: three dependency levels, one launch each; the layers' chains on the rows the edges name
         t.rc = _RelCompact(graph, Rc.shape[0])
         Ra_u, Rc_u = t.rc.gather([Ra, Rc])
@@ -908,9 +937,11 @@ class _EncoderName(torch.autograd.Function):
         t.cat0_lease = _cat0_take(getattr(cfg, "cache", None), info_n, N, d, dev,
                                    persistent=getattr(cfg, "info_persistent", False))     # right block = info, already in place
         t.cat0, t.cat1, t.catA = t.cat0_lease.buf, _empty(dev, N, 2 * d), _empty(dev, N, 3 * d)
-        # dropout draws: two device-resident seeds from torch's generator (one tiny launch, fresh on every replay of a captured
-        # step); the normalise kernels draw from them, forward and backward -- no [N, d] mask is written or read
-        seeds = (torch.empty(2, dtype=torch.int64, device=dev).random_() if training and p_drop > 0.0 else None)
+        # dropout draws: two device-resident seed words per step (the model's persistent seed state, advanced by the weight-pack
+        # launch above: fresh on every replay of a captured step); the normalise kernels draw from them, forward and backward -- no
+        # [N, d] mask is written or read
+        seeds = (seeds[1] if seeds is not None                     # (no persistent state, e.g. a first call inside a capture: drawn here)
+                 else (torch.empty(2, dtype=torch.int64, device=dev).random_() if training and p_drop > 0.0 else None))
         sd = (lambda i: seeds[i:i + 1]) if seeds is not None else (lambda i: None)
         t.inv0, t.drop0 = _norm_drop_fwd(E_n, p_drop, training, t.cat0[:, :d], seed=sd(0))                # :179
         align0 = t.catA[:, :d]
