@@ -174,6 +174,19 @@ int jmac_rel_attn_aggregate_fwd_bf16_padded(const uint16_t* P, int64_t ldp, cons
                                             float out_scale, float* out, int64_t ldo, float* seg_max, float* seg_den,
                                             void* ws, size_t ws_bytes, jmac_stream_t stream);
 
+/* Up to TWO independent calls of jmac_rel_attn_aggregate_fwd_f32 as ONE launch (round 5): the first two layers of
+ * JMAC.forward_name (conv1_alignment, conv1_completion: src/jmac_model.py:183,190) read different tables / weights / loop rows but
+ * the same graph and do not depend on each other; at DBP-5L size each launch is a chain of dependent round trips with most of the
+ * chip idle.  A job = the arguments of the single call.  Jobs whose form is the one-wave-per-item kernel (small graphs, fp32)
+ * share a grid (blocks [0, g0) job 0, the rest job 1); any other pair runs as two launches.  Results: those of the single calls,
+ * bit for bit. */
+typedef struct {
+    const float *P; int64_t ldp; const float *QZ; int64_t ldqz; const float *RR; int64_t ldrr; const float *a_att;
+    const int32_t *col, *etype; const jmac_view_t *by_dst; int64_t N, d; float slope; int32_t loop_rel; int64_t self_off;
+    float out_scale; float *out; int64_t ldo; float *seg_max, *seg_den; void *ws; size_t ws_bytes;
+} jmac_agg_fwd_job_t;
+int jmac_rel_attn_aggregate_fwd_jobs_f32(const jmac_agg_fwd_job_t* jobs, int32_t n_jobs, jmac_stream_t stream);
+
 /* Merge of per-source-chunk partial aggregations: the slab-pipelined exchange of the destination-sharded layer
  * (jmac_amd/dist.py; the reference has one process and no exchange: modules/helper/message_passing.py:24,28 are the
  * per-destination softmax / sum that make the partials mergeable).  Part c = the forward above on the edges whose SOURCE is

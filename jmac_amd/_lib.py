@@ -36,6 +36,13 @@ class LinkLayer(C.Structure):
     _fields_ = [("ent", vp), ("ld_ent", i64), ("rel", vp), ("ld_rel", i64), ("table", vp), ("ld_table", i64)]
 
 
+class AggFwdJob(C.Structure):
+    """jmac_agg_fwd_job_t"""
+    _fields_ = [("P", vp), ("ldp", i64), ("QZ", vp), ("ldqz", i64), ("RR", vp), ("ldrr", i64), ("a_att", vp), ("col", vp), ("etype", vp),
+                ("by_dst", C.POINTER(View)), ("N", i64), ("d", i64), ("slope", f32), ("loop_rel", i32), ("self_off", i64),
+                ("out_scale", f32), ("out", vp), ("ldo", i64), ("seg_max", vp), ("seg_den", vp), ("ws", vp), ("ws_bytes", sz)]
+
+
 class GemmTask(C.Structure):
     """jmac_gemm_task_t"""
     _fields_ = [("A", vp), ("A2", vp), ("lda", i64), ("a_split", i64), ("transA", i32), ("transB", i32),
@@ -64,6 +71,7 @@ _SIGS = {
                                                    i64, i64, f32, i32, i64, f32, vp, i64, vp, vp, vp, sz, vp]),
     "jmac_rel_attn_aggregate_fwd_bf16_padded": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, vp, vp, vp, C.POINTER(View),
                                                           i64, i64, f32, i32, i64, f32, vp, i64, vp, vp, vp, sz, vp]),
+    "jmac_rel_attn_aggregate_fwd_jobs_f32": (C.c_int, [C.POINTER(AggFwdJob), i32, vp]),
     "jmac_softmax_parts_merge_f32": (C.c_int, [vp, i64, vp, vp, vp, i32, i64, i64, vp, i64, vp, f32, vp, i64, vp, vp, vp]),
     "jmac_rel_attn_bwd_workspace_bytes": (sz, [i64, i64, i64, i64, i64, i64, i64, i32]),
     "jmac_rel_attn_aggregate_bwd_f32": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp,

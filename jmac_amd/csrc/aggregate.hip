@@ -114,8 +114,9 @@ __device__ __forceinline__ float4 sel4(bool c, float4 a) { return c ? a : f4zero
 #else
 #define JMAC_FWD_ATTR
 #endif
+// bid / nblk: the block's index and the block count of ITS job (one launch may carry two independent jobs: below)
 template <int NCH, int U, int D4T, typename TT>
-__global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdArgs a) {
+__device__ __forceinline__ void rel_attn_fwd_body(const FwdArgs& a, const int bid, const int nblk) {
     typedef typename RawOf<TT>::type raw_t;
     // cooperative segments: the partial softmax states of the block's four waves meet here
     __shared__ float4 coop_acc[kWavesPerBlock][NCH][64];
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
     const TT* const tRR = static_cast<const TT*>(a.RR);
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nwaves = gridDim.x * kWavesPerBlock;
+    const int nwaves = nblk * kWavesPerBlock;
     const int n_items = a.counts[0];
     const int n_empty = a.counts[3];
     const int n_coop = a.n_coop;                  // == counts[4]; from the host so that no address below waits for it
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
     // batch of item k+1 are already in flight, so a wave's critical path per item is one gather round trip
     // instead of header -> col/type -> gather (measured: 65k rows of degree 1 took 114 us serialised).
     // The first header is fetched at a clamped index so that it does not wait for the device-side counts.
-    const int it0 = blockIdx.x * kWavesPerBlock + wave;
+    const int it0 = bid * kWavesPerBlock + wave;
     // the loop relation's Rz row is the same for every destination: one read per wave
     // (kept RAW like the Z[i] chunks below: half the registers for bf16 tables, converted where they are used)
     raw_t rl[NCH];
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
     };
 
     // ---- 1. cooperative segments: one workgroup per segment -----------------------------------------------------------
-    for (int cb = blockIdx.x; cb < n_coop; cb += gridDim.x) {
+    for (int cb = bid; cb < n_coop; cb += nblk) {
         const jmac_item_t item = a.items[cb * kWavesPerBlock + wave];
         const int i = item.seg;
         int ccol, ctyp;
@@ -480,6 +481,26 @@ __global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdA
         ctyp = ntyp;
     }
     empties(it - n_reg);                    // persistent grids: the waves share the empty segments after their items
+}
+
+template <int NCH, int U, int D4T, typename TT>
+__global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_kernel(FwdArgs a) {
+    rel_attn_fwd_body<NCH, U, D4T, TT>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// TWO independent aggregation jobs in one launch (blocks [0, g0): job 0, the rest: job 1): conv1_alignment and conv1_completion of
+// JMAC.forward_name (src/jmac_model.py:183,190) read different tables, weights and loop rows but share the graph and do not depend
+// on each other -- at DBP-5L size each launch is a chain of dependent round trips with most of the chip idle, so two jobs side by
+// side cost little more than one.  Same body, same per-row arithmetic and order: results are those of two launches, bit for bit.
+// The body is instantiated once per job, each on ITS by-value argument struct: a struct picked at run time (a reference, or a
+// copy fetched from the kernarg segment at a run-time offset) loses the "kernel arguments point to global memory" inference --
+// 90 flat_loads instead of global_loads in the ISA, each counted on two wait counters.
+template <int NCH, int U, int D4T, typename TT>
+__global__ __launch_bounds__(kBlock) JMAC_FWD_ATTR void rel_attn_fwd_jobs_kernel(FwdArgs a0, FwdArgs a1, int g0) {
+    if ((int)blockIdx.x < g0)                                         // block-uniform
+        rel_attn_fwd_body<NCH, U, D4T, TT>(a0, (int)blockIdx.x, g0);
+    else
+        rel_attn_fwd_body<NCH, U, D4T, TT>(a1, (int)blockIdx.x - g0, (int)gridDim.x - g0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1727,15 +1748,29 @@ void launch_reduce_rows(const float* partial, int nparts, int W, float scale, fl
 }
 }  // namespace jmac
 
+// What launch_rel_attn_fwd decided for one call, for jmac_rel_attn_aggregate_fwd_jobs_f32: a call whose form is the plain
+// small-graph kernel (one wave per item) is NOT launched when a plan is asked for -- the caller pairs two of them in one launch
+struct FwdPlan {
+    FwdArgs a;
+    unsigned grid;
+    int nch;
+    bool plain_small, slope01, launched;
+    int64_t n_comb;                      // split (non-cooperative) destinations: the combine kernel follows the main launch
+};
+
 // dh: pitch of the halves of a [Q|Z] / [Rq|Rz] row in elements (Q at 0, Z at dh): d, or the padded pitch of the bf16 tables
 template <typename TT>
 static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t ldqz, const TT* RR, int64_t ldrr, int64_t dh,
                                const float* a_att,
                                const int32_t* col, const int32_t* etype, const jmac_view_t* v, int64_t N, int64_t d, float slope,
                                int32_t loop_rel, int64_t self_off, float out_scale, float* out, int64_t ldo, float* seg_max,
-                               float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream) {
+                               float* seg_den, void* ws, size_t ws_bytes, jmac_stream_t stream, FwdPlan* plan = nullptr) {
+    if (plan) *plan = FwdPlan{};
     if (N < 0 || !v || v->n_items_max < 0 || v->n_splits_max < 0) return JMAC_EINVAL;
-    if (N == 0) return JMAC_OK;
+    if (N == 0) {
+        if (plan) plan->launched = true;
+        return JMAC_OK;
+    }
     if (!P || !QZ || !RR || !a_att || !v->ptr || !v->items || !v->counts || !out || !seg_max || !seg_den) return JMAC_EINVAL;
     if (int rc = check_dims(d, ldp, ldqz, ldrr)) return rc;
     if (ldo % 4) return JMAC_EDIM;
@@ -1792,7 +1827,14 @@ static int launch_rel_attn_fwd(const TT* P, int64_t ldp, const TT* QZ, int64_t l
     // measured (rocprofv3 / HIP events, MI355X): config 4 (persistent grid) bf16 7.53 -> 6.48 ms (0.43 -> 0.50 of the HBM peak),
     // fp32 10.93 -> 10.45 / 9.67 ms; on the 56 589-entity union (one wave per item) the 64-lane kernel stays ahead
     // (fp32 116 against 120 us, bf16 87 against 105 us): the small-graph form keeps it
-    if (hw_env && slope01 && aligned && hw_shape && (fwd_u != 2 || hw_small_env)) {
+    const bool use_hw = hw_env && slope01 && aligned && hw_shape && (fwd_u != 2 || hw_small_env);
+    if (plan) {
+        plan->a = a; plan->grid = grid; plan->nch = nch; plan->slope01 = slope01; plan->n_comb = n_splits_max - n_coop;
+        plan->plain_small = !use_hw && fwd_u == 2 && sizeof(TT) == 4;
+        if (plan->plain_small) return JMAC_OK;          // the caller launches it (paired with another job where it can)
+        plan->launched = true;
+    }
+    if (use_hw) {
         static const int hw_depth_env = env_int("JMAC_FWD_HW_DEPTH", 0);
         // gathers in flight per wave (persistent form): two groups, EVERY path issuing the same loads (PIPE 12: exact vmcnt waits).
         // Config 4, MI355X: bf16 6.9 ms with the three-deep conditional form this replaced (one vmcnt(0) per trip in its ISA)
@@ -1847,6 +1889,45 @@ int jmac_rel_attn_aggregate_fwd_f32(const float* P, int64_t ldp, const float* QZ
                                     void* ws, size_t ws_bytes, jmac_stream_t stream) {
     return launch_rel_attn_fwd<float>(P, ldp, QZ, ldqz, RR, ldrr, d, a_att, col, etype, by_dst, N, d, slope, loop_rel, self_off,
                                       out_scale, out, ldo, seg_max, seg_den, ws, ws_bytes, stream);
+}
+
+int jmac_rel_attn_aggregate_fwd_jobs_f32(const jmac_agg_fwd_job_t* jobs, int32_t n_jobs, jmac_stream_t stream) {
+    if (!jobs || n_jobs < 1 || n_jobs > 2) return JMAC_EINVAL;
+    FwdPlan pl[2];
+    for (int k = 0; k < n_jobs; ++k) {
+        const jmac_agg_fwd_job_t& q = jobs[k];
+        if (int rc = launch_rel_attn_fwd<float>(q.P, q.ldp, q.QZ, q.ldqz, q.RR, q.ldrr, q.d, q.a_att, q.col, q.etype, q.by_dst, q.N, q.d,
+                                                q.slope, q.loop_rel, q.self_off, q.out_scale, q.out, q.ldo, q.seg_max, q.seg_den, q.ws,
+                                                q.ws_bytes, stream, &pl[k]))
+            return rc;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    auto single = [&](const FwdPlan& p) {
+        const FwdArgs& a = p.a;
+        const bool slope01 = p.slope01;
+        const int nch = p.nch;
+        JMAC_DISPATCH_D(a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_kernel<NCH, 2, D4T, float>), dim3(p.grid), dim3(kBlock), 0, st, a));
+    };
+    const bool pair = n_jobs == 2 && !pl[0].launched && !pl[1].launched && pl[0].plain_small && pl[1].plain_small &&
+                      pl[0].nch == pl[1].nch && pl[0].a.D4 == pl[1].a.D4 && pl[0].slope01 == pl[1].slope01;
+    if (pair) {
+        const bool slope01 = pl[0].slope01;
+        const int nch = pl[0].nch;
+        const unsigned grid = pl[0].grid + pl[1].grid;
+        JMAC_DISPATCH_D(pl[0].a.D4, nch, hipLaunchKernelGGL((rel_attn_fwd_jobs_kernel<NCH, 2, D4T, float>), dim3(grid), dim3(kBlock), 0,
+                                                            st, pl[0].a, pl[1].a, (int)pl[0].grid));
+    } else {
+        for (int k = 0; k < n_jobs; ++k)
+            if (!pl[k].launched) single(pl[k]);
+    }
+    for (int k = 0; k < n_jobs; ++k) {
+        if (pl[k].launched || pl[k].n_comb <= 0) continue;          // (a job launched by launch_rel_attn_fwd ran its combine there)
+        const FwdArgs& a = pl[k].a;
+        const int nch = pl[k].nch;
+        const unsigned g2 = split_grid(pl[k].n_comb);
+        JMAC_DISPATCH_NCH(nch, hipLaunchKernelGGL((rel_attn_fwd_combine_kernel<NCH, float>), dim3(g2), dim3(kBlock), 0, st, a));
+    }
+    return (int)hipGetLastError();
 }
 
 int jmac_rel_attn_aggregate_fwd_bf16(const uint16_t* P, int64_t ldp, const uint16_t* QZ, int64_t ldqz, const uint16_t* RR,

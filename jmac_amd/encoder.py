@@ -32,7 +32,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from ._lib import GemmTask, check, lib, ptr, require_device, stream
+from ._lib import AggFwdJob, GemmTask, check, lib, ptr, require_device, stream
 from .graph import RelGraph
 
 ACT_NONE, ACT_LEAKY, ACT_RELU, DACT_LEAKY, DACT_RELU = 0, 1, 2, 3, 4
@@ -148,6 +148,39 @@ def _agg_fwd(PQZ, RR, a, graph: RelGraph, slope, out_scale=0.5, compact=False):
     if ev0 is not None:
         ops.PROFILE.append(("rel_attn_fwd_bf16" if bf16 else "rel_attn_fwd", ev0, ops._ev()))
     return out, smax, sden
+
+
+PAIR_LAUNCHES = True      # tests / A-B: False runs the two independent first layers' aggregations as two launches each
+
+
+def _agg_fwd_pair(specs, graph: RelGraph, out_scale=0.5, compact=False):
+    """jmac_rel_attn_aggregate_fwd_jobs_f32: the forward aggregation of TWO independent layers on the same graph (fp32 tables
+    [P|Q|Z], relation tables, attention vectors, slopes = ``specs``) as one launch -> [(out, seg_max, seg_den)] * 2."""
+    L = lib()
+    s = graph.by_dst
+    etype = graph.etype_c if compact else graph.etype
+    sview = s.view_compact(graph.col, graph.etype_c) if compact else s.view()
+    jobs = (AggFwdJob * len(specs))()
+    res, keep = [], []
+    for k, (PQZ, RR, a, slope) in enumerate(specs):
+        N, d3 = PQZ.shape
+        d = d3 // 3
+        dev = PQZ.device
+        out, smax, sden = _empty(dev, N, d), _empty(dev, max(N, 1)), _empty(dev, max(N, 1))
+        wsb = int(L.jmac_rel_attn_fwd_workspace_bytes(s.n_parts_max, d))
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        j = jobs[k]
+        j.P, j.ldp, j.QZ, j.ldqz, j.RR, j.ldrr, j.a_att = ptr(PQZ), d3, PQZ.data_ptr() + d * 4, d3, ptr(RR), RR.stride(0), ptr(a)
+        j.col, j.etype, j.by_dst, j.N, j.d, j.slope = ptr(graph.col), ptr(etype), C.pointer(sview), N, d, float(slope)
+        j.loop_rel, j.self_off, j.out_scale = RR.shape[0] - 1, 0, float(out_scale)
+        j.out, j.ldo, j.seg_max, j.seg_den, j.ws, j.ws_bytes = ptr(out), d, ptr(smax), ptr(sden), ptr(ws), wsb
+        res.append((out, smax, sden))
+        keep.append(ws)
+    ev0 = ops._ev() if ops.PROFILE is not None else None
+    check(L.jmac_rel_attn_aggregate_fwd_jobs_f32(jobs, len(specs), stream()), "jmac_rel_attn_aggregate_fwd_jobs_f32")
+    if ev0 is not None:
+        ops.PROFILE.append(("rel_attn_fwd_pair", ev0, ops._ev()))
+    return res
 
 
 def _agg_bwd(PQZ, RR, a, graph: RelGraph, slope, out, smax, sden, G, out_scale=0.5, compact=False):
@@ -649,7 +682,11 @@ class _MlpChain:
                  gemm_task(self.L12u, dWp, dW1, ta=True, accumulate=True)]], (dW1, dW2, dloop), (dL11u, dL12u)
 
 
-def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch.float32, seg=None, compact=False, rows=None):
+_DEFER = object()
+
+
+def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch.float32, seg=None, compact=False, rows=None,
+               agg=None):
     """Node side of one RelationAwareLayer (src/jmac_model.py:44-52) given its relation tables: state for the backward.
     ``table_dtype`` bf16 (inference form, no backward: BASELINE config 3): the [P|Q|Z] table comes out of a bf16 GEMM and the
     relation table is rounded to bf16; the aggregation gathers half the bytes, its arithmetic and everything after it is fp32."""
@@ -679,10 +716,21 @@ def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch
     else:
         PQZ = torch.mm(X, wc)                                         # [P|Q|Z]: one library GEMM
     slope = float(lay.atv_mlp.negative_slope)
-    pre, smax, sden = _agg_fwd(PQZ, RR, a, graph, slope, compact=compact)
+    if agg is _DEFER:                                   # the caller aggregates (two layers in one launch) and finishes below
+        return SimpleNamespace(X=X, wc=wc, RR=RR, a=a, PQZ=PQZ, slope=slope)
+    pre, smax, sden = agg if agg is not None else _agg_fwd(PQZ, RR, a, graph, slope, compact=compact)
     mean, invstd, use_batch = _bn_fwd(pre, lay.bn, training, y, y2, seg)
     return SimpleNamespace(X=X, wc=wc, RR=RR, a=a, PQZ=PQZ, pre=pre, smax=smax, sden=sden, y=y, mean=mean, invstd=invstd,
                            use_batch=use_batch, slope=slope, bn_weight=lay.bn.weight, seg=seg, compact=compact, rows=rows)
+
+
+def _layer_finish(lay, part, agg, training, y, y2=None, seg=None, compact=False, rows=None):
+    """Second half of _layer_fwd for a layer whose tables were built with ``agg=_DEFER`` and aggregated by the caller."""
+    pre, smax, sden = agg
+    mean, invstd, use_batch = _bn_fwd(pre, lay.bn, training, y, y2, seg)
+    return SimpleNamespace(X=part.X, wc=part.wc, RR=part.RR, a=part.a, PQZ=part.PQZ, pre=pre, smax=smax, sden=sden, y=y, mean=mean,
+                           invstd=invstd, use_batch=use_batch, slope=part.slope, bn_weight=lay.bn.weight, seg=seg, compact=compact,
+                           rows=rows)
 
 
 def _layer_bwd(st, graph, gy, gy2, dX, dX_accumulate):
@@ -948,11 +996,20 @@ class _EncoderName(torch.autograd.Function):
         torch.mm(t.cat0, t.w, out=align0)                                                       # :180
         a_att = [p[4].reshape(-1) for p in (pa, pc, p2)]
         seg = getattr(cfg, "seg", None)
-        t.sa = _layer_fwd(la, align0, t.wc[0], t.cha.RR, a_att[0], graph, training, t.catA[:, d:2 * d], t.cat1[:, d:],
-                          table_dtype=cfg.table_dtype, seg=seg, compact=t.rc.on, rows=ro)                               # :183
         c1 = _empty(dev, N, d)
-        t.sc = _layer_fwd(lc, E_n, t.wc[1], t.chc.RR, a_att[1], graph, training, c1, table_dtype=cfg.table_dtype, seg=seg,
-                          compact=t.rc.on, rows=ro)                                  # :190
+        if PAIR_LAUNCHES and cfg.table_dtype == torch.float32:
+            # conv1_alignment (:183) and conv1_completion (:190) do not depend on each other and share the graph: their tables first,
+            # then BOTH aggregations as one launch (jmac_rel_attn_aggregate_fwd_jobs_f32), then each layer's BatchNorm + tanh
+            pa_ = _layer_fwd(la, align0, t.wc[0], t.cha.RR, a_att[0], graph, training, None, rows=ro, agg=_DEFER)
+            pc_ = _layer_fwd(lc, E_n, t.wc[1], t.chc.RR, a_att[1], graph, training, None, rows=ro, agg=_DEFER)
+            ra, rc_ = _agg_fwd_pair([(pa_.PQZ, pa_.RR, pa_.a, pa_.slope), (pc_.PQZ, pc_.RR, pc_.a, pc_.slope)], graph, compact=t.rc.on)
+            t.sa = _layer_finish(la, pa_, ra, training, t.catA[:, d:2 * d], t.cat1[:, d:], seg=seg, compact=t.rc.on, rows=ro)
+            t.sc = _layer_finish(lc, pc_, rc_, training, c1, seg=seg, compact=t.rc.on, rows=ro)
+        else:
+            t.sa = _layer_fwd(la, align0, t.wc[0], t.cha.RR, a_att[0], graph, training, t.catA[:, d:2 * d], t.cat1[:, d:],
+                              table_dtype=cfg.table_dtype, seg=seg, compact=t.rc.on, rows=ro)                           # :183
+            t.sc = _layer_fwd(lc, E_n, t.wc[1], t.chc.RR, a_att[1], graph, training, c1, table_dtype=cfg.table_dtype, seg=seg,
+                              compact=t.rc.on, rows=ro)                              # :190
         t.inv1, t.drop1 = _norm_drop_fwd(c1, p_drop, training, t.cat1[:, :d], seed=sd(1))                 # :191
         t.a_in = torch.mm(t.cat1, U21)                                                          # :192
         t.s2 = _layer_fwd(l2, t.a_in, t.wc[2], t.ch2.RR, a_att[2], graph, training, t.catA[:, 2 * d:],

@@ -589,3 +589,31 @@ def test_active_row_projections_equal_the_full_products(use, monkeypatch):
         assert got is not None and bool(torch.isfinite(got).all()), k
         atol = 1e-4 * scale if k.endswith("loop_rel") else 1e-6 * scale
         assert_close(got, ref, 1e-4, atol, "grad " + k)
+
+
+def test_paired_first_layer_launches_equal_two_launches_bitwise():
+    """Round 5: conv1_alignment and conv1_completion of forward_name (src/jmac_model.py:183,190) are independent and share the
+    graph; their forward aggregations run as ONE launch (jmac_rel_attn_aggregate_fwd_jobs_f32).  Same body, same per-row order:
+    outputs and gradients are those of the two-launch form, bit for bit."""
+    from jmac_amd import encoder
+    n, nr, d, di = 5000, 37, 300, 20
+    rng = np.random.default_rng(9)
+    ei, et = random_graph(rng, n, nr, 12000, hub=300)
+    ei, et = torch.from_numpy(ei).to(DEV), torch.from_numpy(et).to(DEV)
+    m = _model(d, n, nr, di, False, 17)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    G = {k: torch.randn(s, device=DEV, generator=gen) for k, s in
+         (("align", (n, d)), ("c1", (n, d)), ("c0", (n, d)), ("r1", (nr, d)), ("r0", (nr, d)))}
+    m.train()
+    res = {}
+    for flag in (True, False):
+        encoder.PAIR_LAUNCHES = flag
+        try:
+            res[flag] = _run(m, True, ei, et, n, nr, ("align", "comp", "rel"), G)
+        finally:
+            encoder.PAIR_LAUNCHES = True
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    for k, ref in res[False][1].items():
+        got = res[True][1][k]
+        assert (ref is None and got is None) or torch.equal(got, ref), k

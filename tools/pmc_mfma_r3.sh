@@ -23,7 +23,7 @@ for tag in ("sim", "gg"):
         if "sim_gemm" in k or "grouped_gemm" in k:
             busy = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / max(len(c["SQ_VALU_MFMA_BUSY_CYCLES"]), 1)
             act = sum(c["GRBM_GUI_ACTIVE"]) / max(len(c["GRBM_GUI_ACTIVE"]), 1)
-            res[k.split("(")[0][-40:]] = {"launches": len(c["GRBM_GUI_ACTIVE"]), "SQ_VALU_MFMA_BUSY_CYCLES_mean": busy,
+            res["sim_gemm_kernel" if "sim_gemm" in k else "grouped_gemm_kernel"] = {"launches": len(c["GRBM_GUI_ACTIVE"]), "SQ_VALU_MFMA_BUSY_CYCLES_mean": busy,
                                           "GRBM_GUI_ACTIVE_mean": act, "MfmaUtil_percent_mean": busy / (act * 1024) * 100 * 8}
 print(json.dumps(res, indent=1))
 PY
