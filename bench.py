@@ -1436,7 +1436,7 @@ def main():
     fwd_ms = raw["fwd_ms"]
     roof = {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<3, 2, 75, float>", "achieved": fbytes / (fwd_ms * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fbytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": (pmc_traffic("ja", "rel_attn_fwd_kernel", ("r4", "r3") if a.data == "real" else ("r2",))
+            "traffic": (pmc_traffic("ja", "rel_attn_fwd_kernel", ("r5", "r4", "r3") if a.data == "real" else ("r2",))
                         if (w.d == 300 and a.workload == "dbp5l-ja") else None),
             "traffic_source": roof_src,
             "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": fwd_ms, "launches": raw["fwd_launches"],
@@ -1450,7 +1450,7 @@ def main():
                 "avg_launch_ms": prof["rel_attn_bwd"][0], "back_to_back_ms": raw["bwd_ms"],
                 "implementation_bytes": synth.bwd_implementation_bytes(w.N, w.E, w.d)}
     if a.data == "real" and a.dim == 300:             # the three launches' HBM-side bytes from the committed PMC passes
-        parts = [pmc_traffic("ja", k, ("r4", "r3")) for k in ("rel_attn_bwd_dst_kernel", "rel_attn_bwd_gather_kernel", "bwd_finalize_kernel")]
+        parts = [pmc_traffic("ja", k, ("r5", "r4", "r3")) for k in ("rel_attn_bwd_dst_kernel", "rel_attn_bwd_gather_kernel", "bwd_finalize_kernel")]
         roof_bwd["traffic"] = float(sum(parts)) if all(p is not None for p in parts) else None
         roof_bwd["traffic_source"] = roof_src
 
