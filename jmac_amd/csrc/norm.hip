@@ -743,6 +743,139 @@ __global__ __launch_bounds__(kBlock) void row_normalize_drop_bwd_kernel(const fl
     }
 }
 
+// ---- the same two kernels with R rows per wave in flight (rows of up to 128 float4: d <= 512) ---------------------------------
+// The forms above give every row a wave that reads it, reduces, reads it AGAIN and writes: two dependent round trips per row and
+// (backward) two Philox evaluations per element; at DBP-5L size (11 805 rows x 300) they move 28-56 MB at 2.2 TB/s.  Here a wave
+// keeps R rows in registers (two float4 per lane and row), issues all their loads before the first reduction (interleaved DPP
+// chains: wave_sum_n) and writes from registers.  Per-lane summation order as above: the same bits.
+template <bool SEED, int R>
+__global__ __launch_bounds__(kBlock) void row_normalize_drop_fwd_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t N, int D4,
+                                                                             float eps, DropSrc ds, float* __restrict__ y, int64_t ldy,
+                                                                             float* __restrict__ inv) {
+    const int lane = lane_id();
+    const int64_t w0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+    uint2 key = make_uint2(0u, 0u);
+    if (SEED) {
+        const uint64_t sd = (uint64_t)ds.seed[0];
+        key = make_uint2((uint32_t)sd, (uint32_t)(sd >> 32));
+    }
+    const bool drop = SEED || ds.mask != nullptr;
+    const int cc[2] = {lane, lane + 64};
+    const bool ok[2] = {cc[0] < D4, cc[1] < D4};
+    for (int64_t r0 = w0 * R; r0 < N; r0 += nw * R) {
+        float4 v[R][2];
+        float ss[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const float* xr = x + (r0 + u < N ? r0 + u : N - 1) * ldx;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) v[u][k] = ld4(xr + (ok[k] ? cc[k] : 0) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            ss[u] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!ok[k]) v[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 q = v[u][k];
+                ss[u] = fmaf(q.x, q.x, fmaf(q.y, q.y, fmaf(q.z, q.z, fmaf(q.w, q.w, ss[u]))));
+            }
+        }
+        wave_sum_n<R>(ss);
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int64_t r = r0 + u;
+            if (r >= N) break;                                     // wave-uniform
+            const float iv = 1.f / fmaxf(sqrtf(ss[u]), eps);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!ok[k]) continue;
+                float4 q = v[u][k];
+                q.x *= iv; q.y *= iv; q.z *= iv; q.w *= iv;
+                if (drop) {
+                    const float4 m = drop_factors<SEED>(ds, key, r, cc[k], D4);
+                    q.x *= m.x; q.y *= m.y; q.z *= m.z; q.w *= m.w;
+                }
+                st4(y + r * ldy + cc[k] * 4, q);
+            }
+            if (lane == 0) inv[r] = iv;
+        }
+    }
+}
+
+template <bool SEED, int R>
+__global__ __launch_bounds__(kBlock) void row_normalize_drop_bwd_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                             const float* __restrict__ inv, DropSrc ds,
+                                                                             const float* __restrict__ g, int64_t ldg, int64_t N, int D4,
+                                                                             float eps, float* __restrict__ gx, int64_t ldgx,
+                                                                             int accumulate) {
+    const int lane = lane_id();
+    const int64_t w0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (kBlock / 64);
+    uint2 key = make_uint2(0u, 0u);
+    if (SEED) {
+        const uint64_t sd = (uint64_t)ds.seed[0];
+        key = make_uint2((uint32_t)sd, (uint32_t)(sd >> 32));
+    }
+    const bool drop = SEED || ds.mask != nullptr;
+    const int cc[2] = {lane, lane + 64};
+    const bool ok[2] = {cc[0] < D4, cc[1] < D4};
+    for (int64_t r0 = w0 * R; r0 < N; r0 += nw * R) {
+        float4 v[R][2], q[R][2], p[R][2];
+        float iv[R], dot[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int64_t r = r0 + u < N ? r0 + u : N - 1;
+            iv[u] = inv[r];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = ok[k] ? cc[k] : 0;
+                v[u][k] = ld4(x + r * ldx + c * 4);
+                q[u][k] = ld4(g + r * ldg + c * 4);
+                if (accumulate) p[u][k] = ld4(gx + r * ldgx + c * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int64_t r = r0 + u < N ? r0 + u : N - 1;
+            dot[u] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!ok[k]) {
+                    q[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else if (drop) {
+                    const float4 m = drop_factors<SEED>(ds, key, r, cc[k], D4);
+                    q[u][k].x *= m.x; q[u][k].y *= m.y; q[u][k].z *= m.z; q[u][k].w *= m.w;
+                }
+                const float4 a = v[u][k], b = q[u][k];
+                dot[u] = fmaf(b.x, a.x * iv[u], fmaf(b.y, a.y * iv[u], fmaf(b.z, a.z * iv[u], fmaf(b.w, a.w * iv[u], dot[u]))));
+            }
+        }
+        wave_sum_n<R>(dot);
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int64_t r = r0 + u;
+            if (r >= N) break;                                     // wave-uniform
+            const float d_ = iv[u] * eps >= 1.f ? 0.f : dot[u];   // ||x|| <= eps: y = x / eps, no radial term
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!ok[k]) continue;
+                const float4 a = v[u][k], b = q[u][k];
+                float4 o;
+                o.x = iv[u] * (b.x - a.x * iv[u] * d_); o.y = iv[u] * (b.y - a.y * iv[u] * d_);
+                o.z = iv[u] * (b.z - a.z * iv[u] * d_); o.w = iv[u] * (b.w - a.w * iv[u] * d_);
+                if (accumulate) {
+                    o.x += p[u][k].x; o.y += p[u][k].y; o.z += p[u][k].z; o.w += p[u][k].w;
+                }
+                st4(gx + r * ldgx + cc[k] * 4, o);
+            }
+        }
+    }
+}
+
+constexpr int kDropRows = 4;             // rows per wave of the *_rows forms
+constexpr int64_t kDropRowsMinN = 2048;  // below this the one-row-per-wave forms have more waves to hide latency with
+
 }  // namespace
 
 extern "C" {
@@ -855,6 +988,17 @@ static int drop_fwd(const float* x, int64_t ldx, int64_t N, int64_t d, float eps
     if (N == 0) return JMAC_OK;
     if (!x || !y || !inv) return JMAC_EINVAL;
     if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)ds.mask) & 15) != 0) return JMAC_EDIM;
+    if (d <= 512 && N >= kDropRowsMinN) {                          // R rows per wave in flight
+        int64_t rb = ((N + kDropRows - 1) / kDropRows + kBlock / 64 - 1) / (kBlock / 64);
+        if (rb > 8192) rb = 8192;
+        if (seeded)
+            hipLaunchKernelGGL((row_normalize_drop_fwd_rows_kernel<true, kDropRows>), dim3((unsigned)rb), dim3(kBlock), 0,
+                               (hipStream_t)stream, x, ldx, N, (int)(d / 4), eps, ds, y, ldy, inv);
+        else
+            hipLaunchKernelGGL((row_normalize_drop_fwd_rows_kernel<false, kDropRows>), dim3((unsigned)rb), dim3(kBlock), 0,
+                               (hipStream_t)stream, x, ldx, N, (int)(d / 4), eps, ds, y, ldy, inv);
+        return (int)hipGetLastError();
+    }
     int64_t blocks = (N + kBlock / 64 - 1) / (kBlock / 64);
     if (blocks > 8192) blocks = 8192;
     if (seeded)
@@ -873,6 +1017,17 @@ static int drop_bwd(const float* x, int64_t ldx, const float* inv, const DropSrc
     if (N == 0) return JMAC_OK;
     if (!x || !inv || !g || !gx) return JMAC_EINVAL;
     if ((((uintptr_t)x | (uintptr_t)g | (uintptr_t)gx | (uintptr_t)ds.mask) & 15) != 0) return JMAC_EDIM;
+    if (d <= 512 && N >= kDropRowsMinN) {
+        int64_t rb = ((N + kDropRows - 1) / kDropRows + kBlock / 64 - 1) / (kBlock / 64);
+        if (rb > 8192) rb = 8192;
+        if (seeded)
+            hipLaunchKernelGGL((row_normalize_drop_bwd_rows_kernel<true, kDropRows>), dim3((unsigned)rb), dim3(kBlock), 0,
+                               (hipStream_t)stream, x, ldx, inv, ds, g, ldg, N, (int)(d / 4), eps, gx, ldgx, accumulate ? 1 : 0);
+        else
+            hipLaunchKernelGGL((row_normalize_drop_bwd_rows_kernel<false, kDropRows>), dim3((unsigned)rb), dim3(kBlock), 0,
+                               (hipStream_t)stream, x, ldx, inv, ds, g, ldg, N, (int)(d / 4), eps, gx, ldgx, accumulate ? 1 : 0);
+        return (int)hipGetLastError();
+    }
     int64_t blocks = (N + kBlock / 64 - 1) / (kBlock / 64);
     if (blocks > 8192) blocks = 8192;
     if (seeded)

@@ -331,11 +331,13 @@ def test_grouped_gemm_many_tasks_and_odd_shapes():
         assert_close(out, ref, 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize("N,d", [(333, 40), (4099, 300), (2049, 512)], ids=["row-per-wave", "four-rows-per-wave-d300", "four-rows-per-wave-d512"])
 @pytest.mark.parametrize("with_mask", [False, True])
-def test_normalize_dropout_kernels(with_mask):
+def test_normalize_dropout_kernels(with_mask, N, d):
+    """(N >= 2048: the forms that keep four rows per wave in registers -- ragged last wave, d = 300 = 75 float4 on 64 + 11 lanes,
+    d = 512 = the widest row they take.)"""
     from jmac_amd._lib import check, lib, ptr, stream
     gen = torch.Generator(device=DEV).manual_seed(1)
-    N, d = 333, 40
     x = torch.randn(N, d, device=DEV, generator=gen)
     x[5] = 0.0                                                    # clamped norm
     mask = (torch.rand(N, d, device=DEV, generator=gen) > 0.4).float() if with_mask else None
@@ -374,7 +376,7 @@ def test_normalize_dropout_seeded_draws(p_drop):
     the kernel, the seed tensor's CONTENT is what changes)."""
     from jmac_amd._lib import check, lib, ptr, stream
     gen = torch.Generator(device=DEV).manual_seed(11)
-    N, d = 2000, 300
+    N, d = 2050, 300                                              # (>= 2048 rows: the four-rows-per-wave forms, ragged last wave)
     x = torch.randn(N, d, device=DEV, generator=gen) + 3.0        # no exact zeros among the normalised values
     seed = torch.tensor([0x1234_5678_9ABC_DEF0 >> 1, 77], dtype=torch.int64, device=DEV)
     L = lib()
