@@ -46,8 +46,8 @@ def enable_gemm_tuning(rank):
         import torch.cuda.tunable as tun
         tun.enable(True)
         tun.tuning_enable(True)
-        tun.set_max_tuning_duration(30)
-        tun.set_max_tuning_iterations(10)
+        tun.set_max_tuning_duration(int(os.environ.get("JMAC_TUNE_MS", "30")))          # per candidate kernel, ms (env: A/B knob)
+        tun.set_max_tuning_iterations(int(os.environ.get("JMAC_TUNE_ITERS", "10")))
         fn = os.environ.get("JMAC_TUNABLEOP_FILE", "/tmp/jmac_tunableop_rank%d.csv" % rank)
         tun.set_filename(fn)
         if hasattr(tun, "write_file_on_exit"):

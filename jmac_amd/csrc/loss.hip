@@ -503,22 +503,22 @@ __global__ __launch_bounds__(kMarginBlock) void margin_loss_fwd_kernel(const flo
     __shared__ float red[kMarginBlock];
     const float gamma = gamma_p[0];
     float acc = 0.f;
-    const int64_t total = (int64_t)B * K;
+    const int total = B * K;                  // (launcher: B K < 2^31) 32-bit index arithmetic: a 64-bit modulo is ~40 instructions
     // eight independent (positive, negative) pairs in flight per trip: a rolled loop pays the load latency once per element
     // (25 dependent round trips per thread at the reference's batch: 11 us for 26 000 scores)
-    int64_t i = threadIdx.x;
+    int i = threadIdx.x;
     for (; i + 7 * kMarginBlock < total; i += 8 * kMarginBlock) {
         float p[8], n[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int64_t j = i + (int64_t)u * kMarginBlock;
-            p[u] = score[(int)(j % B)];
+            const int j = i + u * kMarginBlock;
+            p[u] = score[(unsigned)j % (unsigned)B];
             n[u] = score[B + j];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += fmaxf(p[u] - n[u], -gamma);      // fixed order per thread: reproducible
     }
-    for (; i < total; i += kMarginBlock) acc += fmaxf(score[(int)(i % B)] - score[B + i], -gamma);
+    for (; i < total; i += kMarginBlock) acc += fmaxf(score[(unsigned)i % (unsigned)B] - score[B + i], -gamma);
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = kMarginBlock / 2; s > 0; s >>= 1) {
@@ -737,7 +737,7 @@ int jmac_pair_cosine_bwd_f32(const float* e1, int64_t ld1, const float* e2, int6
 
 int jmac_margin_loss_fwd_acc_f32(const float* score, int64_t B, int64_t K, const float* gamma, const float* add_to, float* loss,
                                  jmac_stream_t stream) {
-    if (B <= 0 || K <= 0 || B >= INT32_MAX || K >= INT32_MAX) return JMAC_EINVAL;
+    if (B <= 0 || K <= 0 || B >= INT32_MAX || K >= INT32_MAX || B * K + B >= INT32_MAX) return JMAC_EINVAL;
     if (!score || !gamma || !loss) return JMAC_EINVAL;
     hipLaunchKernelGGL(margin_loss_fwd_kernel, dim3(1), dim3(kMarginBlock), 0, (hipStream_t)stream, score, (int)B, (int)K, gamma, add_to,
                        loss);
