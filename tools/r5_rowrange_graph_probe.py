@@ -52,6 +52,20 @@ def ranged_classes():                                  # input gradient by row c
         torch.mm(dPQZ[l][s1:, d:2 * d], wc[l][:, d:2 * d].t(), out=dX[l][s1:])          # neither: Z
         torch.mm(X[l].t(), dPQZ[l], out=dwc[l])
 
+def ranged_w():                                        # ... and the weight gradient's K range per column block
+    for l in range(L):
+        torch.mm(X[l], wc[l][:, d:2 * d], out=PQZ[l][:, d:2 * d])
+        torch.mm(X[l][s0:s1], wc[l][:, :d], out=PQZ[l][s0:s1, :d])
+        torch.mm(X[l][:nD], wc[l][:, 2 * d:], out=PQZ[l][:nD, 2 * d:])
+    for l in range(L):
+        torch.mm(dPQZ[l][:, d:2 * d], wc[l][:, d:2 * d].t(), out=dX[l])
+        dX[l][s0:s1].addmm_(dPQZ[l][s0:s1, :d], wc[l][:, :d].t())
+        dX[l][:nD].addmm_(dPQZ[l][:nD, 2 * d:], wc[l][:, 2 * d:].t())
+        torch.mm(X[l].t(), dPQZ[l][:, d:2 * d], out=dwc[l][:, d:2 * d])
+        torch.mm(X[l][s0:s1].t(), dPQZ[l][s0:s1, :d], out=dwc[l][:, :d])
+        torch.mm(X[l][:nD].t(), dPQZ[l][:nD, 2 * d:], out=dwc[l][:, 2 * d:])
+
+
 def graph_time(fn, reps=30):
     for _ in range(12):
         fn()
@@ -72,5 +86,6 @@ def graph_time(fn, reps=30):
     bench.enable_gemm_tuning(0)
     return e0.elapsed_time(e1) / reps * 1e3
 
-for name, fn in (("full products", full), ("row ranges (accumulating input gradient)", ranged), ("row ranges (input gradient by class)", ranged_classes)):
+for name, fn in (("full products", full), ("row ranges (accumulating input gradient)", ranged), ("row ranges (input gradient by class)", ranged_classes),
+                 ("row ranges, weight gradient by K range too", ranged_w)):
     print("%-44s %7.1f us per step's 9 projection products" % (name, graph_time(fn)))
