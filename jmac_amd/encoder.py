@@ -427,12 +427,18 @@ COMPACT_RELATIONS = True      # tests / A-B: False runs every relation-side prod
 ACTIVE_ROWS = True            # tests / A-B: False keeps the entity order and the full products
 ACTIVE_ROWS_MAX_FRACTION = 0.85   # taken only where (destinations + sources) / 2N is below this: the copies must pay for themselves
 ACTIVE_ROWS_MIN_N = 4096
+# Stacked KGs (forward_stacked: per-KG row blocks): the class order is per block, i.e. 2 range products per KG for P and Q instead
+# of 2 in all -- measured SLOWER than the full products (real el + ja pair step 1.368 -> 1.43 ms, five-KG training step 7.16 ->
+# 7.53 ms: launch-bound 2 000-6 000-row GEMMs and copies of the stacked tables).  Built, tested (tests run it), off.
+ACTIVE_ROWS_STACKED = False
 
 
 class _RowOrder:
-    """Class order of one graph's entities + the graph re-indexed in it."""
+    """Class order of one graph's entities + the graph re-indexed in it.  ``seg`` (RowBlocks of a stacked launch set): the order
+    is by class INSIDE every block, so the blocks keep their row ranges (per-KG BatchNorm statistics, the losses' row windows)
+    and destinations / sources are one row range per block (``dst_ranges`` / ``src_ranges``)."""
 
-    def __init__(self, graph: RelGraph):
+    def __init__(self, graph: RelGraph, seg=None):
         dev, N, E = graph.device, graph.N, graph.E
         deg = graph.degrees()
         is_dst = deg > 0
@@ -440,14 +446,23 @@ class _RowOrder:
         col = graph.col[:E].long()
         is_src[col] = True
         cls = torch.where(is_dst & ~is_src, 0, torch.where(is_dst & is_src, 1, torch.where(is_src, 2, 3)))
-        self.old_of_new = torch.sort(cls, stable=True)[1].contiguous()          # int64 [N]: row of the caller's table per node row
+        offsets = list(seg.offsets) if (seg is not None and seg.nb > 1) else [0, N]
+        nb = len(offsets) - 1
+        key = cls
+        if nb > 1:
+            bounds = torch.tensor(offsets[1:-1], dtype=torch.int64, device=dev)
+            key = torch.bucketize(torch.arange(N, device=dev), bounds, right=True) * 4 + cls
+        self.old_of_new = torch.sort(key, stable=True)[1].contiguous()          # int64 [N]: row of the caller's table per node row
         self.new_of_old = torch.empty_like(self.old_of_new)
         self.new_of_old[self.old_of_new] = torch.arange(N, device=dev)
         self.pos32 = self.new_of_old.to(torch.int32).contiguous()               # jmac_rows_expand_f32's position list
-        n = torch.bincount(cls, minlength=4).tolist()                           # one host read per graph (build time)
-        self.nD, self.s0, self.s1 = n[0] + n[1], n[0], n[0] + n[1] + n[2]
+        cnt = torch.bincount(key, minlength=4 * nb).view(nb, 4).tolist()        # one host read per graph (build time)
+        self.dst_ranges = [(offsets[k], offsets[k] + c[0] + c[1]) for k, c in enumerate(cnt)]
+        self.src_ranges = [(offsets[k] + c[0], offsets[k] + c[0] + c[1] + c[2]) for k, c in enumerate(cnt)]
+        self.nD, self.s0, self.s1 = self.dst_ranges[0][1], self.src_ranges[0][0], self.src_ranges[0][1]    # (one block: tests)
         self.N = N
-        self.fraction = (self.nD + (self.s1 - self.s0)) / (2.0 * max(N, 1))
+        active = sum(b - a for a, b in self.dst_ranges) + sum(b - a for a, b in self.src_ranges)
+        self.fraction = active / (2.0 * max(N, 1))
         dst = torch.repeat_interleave(torch.arange(N, device=dev), deg.long())
         ei = torch.stack((self.new_of_old[dst], self.new_of_old[col])).contiguous()
         et = graph.etype[:E].long().contiguous()
@@ -470,14 +485,19 @@ class _RowOrder:
 
 
 def _row_order(cfg, graph: RelGraph, N: int):
-    """The class order for this call, or None: one KG (no row blocks), enough rows, fp32 tables, and few enough active rows."""
-    if not ACTIVE_ROWS or getattr(cfg, "seg", None) is not None or N < ACTIVE_ROWS_MIN_N or graph.E == 0 or graph.num_src != graph.N:
+    """The class order for this call, or None: enough rows, fp32 tables, and few enough active rows."""
+    if not ACTIVE_ROWS or N < ACTIVE_ROWS_MIN_N or graph.E == 0 or graph.num_src != graph.N or cfg.table_dtype != torch.float32:
         return None
-    if cfg.table_dtype != torch.float32 or torch.cuda.is_current_stream_capturing() and getattr(graph, "_row_order", None) is None:
+    seg = getattr(cfg, "seg", None)
+    if seg is not None and (seg.offsets[-1] != N or (seg.nb > 1 and not ACTIVE_ROWS_STACKED)):
         return None
-    ro = getattr(graph, "_row_order", None)
+    key = tuple(seg.offsets) if (seg is not None and seg.nb > 1) else None
+    cache = graph.__dict__.setdefault("_row_orders", {})
+    ro = cache.get(key)
     if ro is None:
-        ro = graph._row_order = _RowOrder(graph)
+        if torch.cuda.is_current_stream_capturing():     # built in an eager (warm-up) call only: it reads counts back to the host
+            return None
+        ro = cache[key] = _RowOrder(graph, seg if key is not None else None)
     return ro if ro.fraction <= ACTIVE_ROWS_MAX_FRACTION else None
 
 
@@ -709,10 +729,12 @@ def _layer_fwd(lay, X, wc, RR, a, graph, training, y, y2=None, table_dtype=torch
         d = wc.shape[0]
         PQZ = _empty(X.device, X.shape[0], 3 * d)
         torch.mm(X, wc[:, 2 * d:], out=PQZ[:, 2 * d:])
-        if rows.nD > 0:
-            torch.mm(X[:rows.nD], wc[:, :d], out=PQZ[:rows.nD, :d])
-        if rows.s1 > rows.s0:
-            torch.mm(X[rows.s0:rows.s1], wc[:, d:2 * d], out=PQZ[rows.s0:rows.s1, d:2 * d])
+        for r0, r1 in rows.dst_ranges:                                # (one range per KG of a stacked launch set)
+            if r1 > r0:
+                torch.mm(X[r0:r1], wc[:, :d], out=PQZ[r0:r1, :d])
+        for r0, r1 in rows.src_ranges:
+            if r1 > r0:
+                torch.mm(X[r0:r1], wc[:, d:2 * d], out=PQZ[r0:r1, d:2 * d])
     else:
         PQZ = torch.mm(X, wc)                                         # [P|Q|Z]: one library GEMM
     slope = float(lay.atv_mlp.negative_slope)
@@ -747,10 +769,12 @@ def _layer_bwd(st, graph, gy, gy2, dX, dX_accumulate):
             dX.addmm_(dPQZ[:, 2 * d:], st.wc[:, 2 * d:].t())
         else:
             torch.mm(dPQZ[:, 2 * d:], st.wc[:, 2 * d:].t(), out=dX)
-        if rows.nD > 0:
-            dX[:rows.nD].addmm_(dPQZ[:rows.nD, :d], st.wc[:, :d].t())
-        if rows.s1 > rows.s0:
-            dX[rows.s0:rows.s1].addmm_(dPQZ[rows.s0:rows.s1, d:2 * d], st.wc[:, d:2 * d].t())
+        for r0, r1 in rows.dst_ranges:
+            if r1 > r0:
+                dX[r0:r1].addmm_(dPQZ[r0:r1, :d], st.wc[:, :d].t())
+        for r0, r1 in rows.src_ranges:
+            if r1 > r0:
+                dX[r0:r1].addmm_(dPQZ[r0:r1, d:2 * d], st.wc[:, d:2 * d].t())
     elif dX is not None:
         if dX_accumulate:
             dX.addmm_(dPQZ, st.wc.t())
@@ -1028,10 +1052,12 @@ class _EncoderName(torch.autograd.Function):
                 # whatever the buffer held -- zero them for the tests' arithmetic)
                 PQZ_c = st.PQZ
                 if ro is not None:
-                    PQZ_c = st.PQZ.clone()
-                    PQZ_c[ro.nD:, :d] = 0
-                    PQZ_c[:ro.s0, d:2 * d] = 0
-                    PQZ_c[ro.s1:, d:2 * d] = 0
+                    PQZ_c = torch.zeros_like(st.PQZ)
+                    PQZ_c[:, 2 * d:] = st.PQZ[:, 2 * d:]
+                    for r0, r1 in ro.dst_ranges:
+                        PQZ_c[r0:r1, :d] = st.PQZ[r0:r1, :d]
+                    for r0, r1 in ro.src_ranges:
+                        PQZ_c[r0:r1, d:2 * d] = st.PQZ[r0:r1, d:2 * d]
                     PQZ_c = PQZ_c[ro.new_of_old]
                 CAPTURE[name + ".tables"] = (PQZ_c, t.rc.full_rows(st.RR))
                 CAPTURE[name + ".rel_act"] = ch.T                        # the relation transform's activation (its sign = the kink side)

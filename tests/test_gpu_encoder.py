@@ -574,7 +574,7 @@ def test_active_row_projections_equal_the_full_products(use, monkeypatch):
         if flag:
             from jmac_amd.graph import graph_cache
             g = graph_cache.get(ei, et, n, nr + 1, m.conv1_completion.chunk)
-            ro = g._row_order
+            ro = g._row_orders[None]
             assert 0 < ro.s0 < ro.nD < ro.s1 < n and ro.fraction < 0.6          # all four classes; the path was taken
     (out_a, g_a, bn_a), (out_f, g_f, bn_f) = res[True], res[False]
     for a, b, what in zip(out_a, out_f, ("align_out", "c1", "rel_c1")):

@@ -322,3 +322,35 @@ def test_pair_step_captures_and_replays():
     with torch.no_grad():
         l1 = float(w.loss())
     assert np.isfinite(l1) and l1 < l0, (l0, l1)
+
+
+def test_stacked_active_rows_equal_full_products():
+    """The class order per KG block (encoder.ACTIVE_ROWS_STACKED: built, measured slower than the full products on stacked KGs,
+    off by default) on the real el + ja pair step: loss and every gradient equal the default form to rounding, the per-KG
+    BatchNorm buffers included."""
+    from jmac_amd import encoder
+    w = _pair_workload(300)
+    w.model.completion_dropout.p = 0.0
+    dev = w.links.device
+    res = {}
+    for flag in (True, False):
+        encoder.ACTIVE_ROWS_STACKED = flag
+        try:
+            w.model.load_state_dict({k: v.to(dev) for k, v in w.state_cpu.items()}, strict=True)
+            w.opt.zero_grad(set_to_none=True)
+            loss = w.loss()
+            loss.backward()
+            torch.cuda.synchronize()
+            res[flag] = (float(loss), {k: p.grad.clone() for k, p in w.model.named_parameters() if p.grad is not None},
+                         {k: v.clone() for k, v in w.model.state_dict().items() if "running" in k})
+        finally:
+            encoder.ACTIVE_ROWS_STACKED = False
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+    assert set(res[True][1]) == set(res[False][1])
+    gscale = max(float(g.abs().max()) for g in res[False][1].values())
+    for k, ref in res[False][1].items():
+        # loop_rel's gradient is mathematically zero under train-mode BN (rounding noise of either form): on the others' scale
+        atol = 1e-5 * gscale if k.endswith("loop_rel") else 1e-9
+        assert float((res[True][1][k] - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1e-30) + atol, k
+    for k, ref in res[False][2].items():
+        assert torch.allclose(res[True][2][k], ref, rtol=1e-5, atol=1e-7), k
