@@ -174,6 +174,10 @@ def lib() -> C.CDLL:
             raise JmacError(
                 "jmac_amd: %s is missing. Build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
                 "(or `make -C jmac_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+        # load order: torch bundles a HIP runtime with the same SONAME (libamdhip64.so.7) as /opt/rocm's, so whichever is
+        # mapped first serves both.  This host side hands torch's device pointers and streams to the library: they must
+        # belong to ONE runtime, torch's (loading this library first gave "no ROCm-capable device" on the first launch).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
@@ -195,6 +199,7 @@ def testing_lib() -> C.CDLL:
         if not os.path.exists(path):
             raise JmacError("jmac_amd: %s is missing (the atomic backward lives in the testing build only: "
                             "`make -C jmac_amd/csrc`)" % path)
+        import torch  # noqa: F401  (same load order as lib())
         l = C.CDLL(path)
         for name in ("jmac_rel_attn_aggregate_bwd_f32", "jmac_rel_attn_bwd_workspace_bytes", "jmac_strerror"):
             fn = getattr(l, name)
