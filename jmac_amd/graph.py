@@ -8,7 +8,6 @@ is cached per tensor identity, so the drop-in layer can keep the reference's cal
 from __future__ import annotations
 
 import ctypes as C
-import os
 from collections import OrderedDict
 from typing import Optional, Tuple
 
@@ -20,11 +19,11 @@ from ._lib import View, check, check_index_range, lib, ptr, require_device, stre
 DEFAULT_CHUNK = None          # None -> auto_chunk()
 # schedules of up to this many items carry the first two entries of each item inline (the forward kernel gives every
 # item its own wave there -- aggregate.hip fwd_grid -- and is bound by dependent round trips, not by bandwidth)
-INLINE_EDGES_MAX_ITEMS = int(os.environ.get("JMAC_SMALL_ITEMS", "65536"))   # env: tuning knob (debug)
+INLINE_EDGES_MAX_ITEMS = 65536          # (tools/_knobs.py sets these module attributes from the environment for the probes)
 # the by-source / by-relation views (backward passes B / C) switch to their small-graph form (short items, inline entries) on
 # their own threshold: measured on the 56 589-entity union the forward gains from the small form (136 -> 117 us fp32, 122 -> 86 us
 # bf16) while the backward loses (306 -> 346 us)
-SMALL_BWD_MAX_ITEMS = int(os.environ.get("JMAC_SMALL_BWD_ITEMS", "16384"))
+SMALL_BWD_MAX_ITEMS = 16384
 # order of a destination's edges inside its CSR row: by relation type, then input order (False: input order)
 SORT_ROWS_BY_TYPE = True
 
@@ -50,10 +49,10 @@ SMALL_BWD_CHUNK = 32
 # cooperative splits (forward kernel, small graphs): rows longer than COOP_MIN and up to COOP_MAX entries are processed by
 # the four waves of one workgroup and merged in LDS.  Measured on the DBP-5L ja shape: the kernel's duration was set by
 # its longest row (28 entries = 14 dependent gather rounds in one wave); capping the rows at 8 entries took 19.4 -> 15.8 us.
-COOP_MIN, COOP_MAX = int(os.environ.get("JMAC_COOP_MIN", "8")), 256     # env: tuning knob (debug)
+COOP_MIN, COOP_MAX = 8, 256
 # ... and on graphs past COOP_SIZE_SPLIT items, which have the waves to hide a longer row behind, only rows longer than this
 # (56 589-entity union, bf16 tables: 87.3 / 79.1 / 76.5 us at 8 / 12 / 16, fp32 tables 116 +- 1 us at any of them)
-COOP_MIN_LARGE, COOP_SIZE_SPLIT = int(os.environ.get("JMAC_COOP_MIN_LARGE", "16")), 16384
+COOP_MIN_LARGE, COOP_SIZE_SPLIT = 16, 16384
 
 
 def coop_min_for(n_seg: int, n_entries: int, chunk: int) -> int:

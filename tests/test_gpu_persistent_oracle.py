@@ -170,7 +170,7 @@ def test_forward_forms_vs_oracle(d, form, env, tmp_path):
     """Every selectable forward form against the ORACLE (not against each other)."""
     out = str(tmp_path / ("%s_%d.npz" % (form, d)))
     e = dict(os.environ)
-    for k in ("JMAC_FWD_HW", "JMAC_FWD_HOT", "JMAC_FWD_NT", "JMAC_FWD_HW_DEPTH", "JMAC_FWD_U", "JMAC_GRID", "JMAC_SMALL_ITEMS"):
+    for k in ("JMAC_FWD_HW", "JMAC_FWD_HOT", "JMAC_FWD_NT", "JMAC_FWD_HW_DEPTH", "JMAC_FWD_U", "JMAC_GRID"):
         e.pop(k, None)
     e.update(env)
     subprocess.run([sys.executable, os.path.join(HERE, "persistent_worker.py"), str(d), out], env=e, check=True, timeout=900)

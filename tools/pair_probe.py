@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import bench
+import _knobs
+_knobs.apply()       # JMAC_SMALL_ITEMS & co. -> jmac_amd.graph attributes
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batched", type=int, default=1)

@@ -7,6 +7,8 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from jmac_amd import ops, synth
 from jmac_amd.graph import RelGraph
+import _knobs
+_knobs.apply()       # JMAC_SMALL_ITEMS & co. -> jmac_amd.graph attributes
 
 dev = torch.device("cuda")
 if os.environ.get("UNION_SYNTH"):
