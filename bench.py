@@ -25,6 +25,8 @@ import os
 import sys
 import time
 
+T_START = time.perf_counter()       # process start, for the run's own wall-clock record (bench_wall_s)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -1429,6 +1431,13 @@ def main():
         return
 
     from jmac_amd import synth
+    wall, t_wall = {"headline_step_and_parity": round(time.perf_counter() - T_START, 2)}, [time.perf_counter()]
+
+    def lap(name):                       # wall-clock seconds of each section of this run (the default run's budget: minutes)
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        wall[name] = round(now - t_wall[0], 2)
+        t_wall[0] = now
     prof = kernel_profile(w, max(5, min(a.steps, 20)))
     fbytes = synth.fwd_algorithmic_bytes(w.N, w.E, w.d)
     bbytes = synth.bwd_algorithmic_bytes(w.N, w.E, w.d)
@@ -1470,16 +1479,19 @@ def main():
     cpu_on = not a.no_cpu_baseline
     ncpu_small = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(ncpu_small)
+    lap("roofline_timing")
     line["layer"] = layer_bench(w, device, cpu_on)
     line["scoring"] = scoring_bench(w, cpu=cpu_on)
     try:
         line["sim"] = sim_bench(device, cpu=cpu_on)
     except Exception as ex:                          # pragma: no cover
         line["sim"] = {"error": str(ex)}
+    lap("layer_scoring_sim")
     try:
         line["union"] = union_bench(a, device, cpu=cpu_on)
     except Exception as ex:                          # pragma: no cover
         line["union"] = {"error": str(ex)}
+    lap("union")
     if a.data == "real":
         try:
             line["pair"] = pair_bench(a, device, rank, ms, cpu=cpu_on)
@@ -1487,6 +1499,7 @@ def main():
             raise
         except Exception as ex:                      # pragma: no cover
             line["pair"] = {"error": str(ex)}
+        lap("pair")
 
     if cpu_on:
         # PyTorch-CPU scales poorly past one socket's worth of cores on these small ops (256 threads ran 30x
@@ -1510,14 +1523,13 @@ def main():
                                           "PyTorch CPU, %d threads), %.2f s/step" % (nsteps, ncpu, cdt),
                                 "cpu_model": _cpu_model()}
         # BASELINE.md section 2 asks for torch.set_num_threads(os.cpu_count()): that figure beside the best-case one (bounded:
-        # one warm-up + at most two timed steps or 25 s)
+        # at most two timed steps or 25 s)
         nall = os.cpu_count() or 1
         if nall not in (16, 32):
             try:
                 torch.set_num_threads(nall)
-                cstep()
-                t0, k = time.perf_counter(), 0
-                while k < 2 and (k == 0 or time.perf_counter() - t0 < 25):
+                t0, k = time.perf_counter(), 0            # no separate warm-up: the oracle's buffers are warm from the timed
+                while k < 2 and (k == 0 or time.perf_counter() - t0 < 25):   # passes above, and one such step takes over a minute
                     cstep()
                     k += 1
                 adt = (time.perf_counter() - t0) / k
@@ -1529,6 +1541,7 @@ def main():
                 line["cpu_baseline"]["all_cores"] = {"error": str(ex)}
             torch.set_num_threads(ncpu)
         line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        lap("cpu_baseline")
     if not a.no_synth:
         sp = None
         if not a.no_parity_check:                 # the persistent-grid kernels meet the oracle before they are timed
@@ -1540,6 +1553,7 @@ def main():
             line["synth"]["parity"] = sp
         except Exception as ex:                      # pragma: no cover
             line["synth"] = {"error": str(ex), "parity": sp}
+        lap("synth")
         # the destination-sharded config-4 step at ONE rank (no collective runs): the base of the N > 1 lines' value
         try:
             from bench_dist import run_sharded
@@ -1550,6 +1564,9 @@ def main():
                                                   "scaling_model", "scaling_model_strong_10x", "scaling_model_strong_10x_10M_entities") if k in sl}
         except Exception as ex:                      # pragma: no cover
             line["sharded"] = {"error": str(ex)}
+        lap("sharded")
+    wall["total"] = round(time.perf_counter() - T_START, 2)
+    line["bench_wall_s"] = wall
     emit(line)
 
 
