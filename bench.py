@@ -105,6 +105,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-synth", action="store_true")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the library GEMM heuristics as they are")
+    ap.add_argument("--torch-adam", action="store_true", help="step torch.optim.Adam(fused, capturable) instead of jmac_amd.optim.Adam")
     ap.add_argument("--bwd-mode", type=int, default=1)
     ap.add_argument("--synth-scale", type=float, default=1.0, help="scale of the config-4 side measurement")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -179,6 +180,16 @@ def launch_ranks(a):
     return rc
 
 
+def make_adam(params, a):
+    """train.py:406-407: torch.optim.Adam(model.parameters(), lr).  Default: the same update as ONE launch sized for the chip
+    (jmac_amd.optim.Adam = jmac_adam_step_f32; torch's fused multi-tensor kernel puts 125 workgroups on 256 CUs for this model);
+    --torch-adam: torch's own fused, capturable Adam."""
+    if getattr(a, "torch_adam", False):
+        return torch.optim.Adam(params, lr=1e-3, fused=True, capturable=True)
+    from jmac_amd import optim
+    return optim.Adam(params, lr=1e-3)
+
+
 def make_args(dim, batch, negatives, device):
     import types
     return types.SimpleNamespace(dim=dim, dropout=0.4, leaky_relu_w=0.05, comp_op="sub", num_gcn_layer=2,
@@ -233,7 +244,7 @@ class JaWorkload:
         self.pair_cols = (self.pairs[:, 0].contiguous(), self.pairs[:, 1].contiguous())
         self.state_cpu = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
         self.name_emb = torch.from_numpy(name_emb)
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True, capturable=True)
+        self.opt = make_adam(self.model.parameters(), a)
         self.model.train()
 
     # the product's fused loss gathers; the CPU baseline swaps in the reference's torch formulation
@@ -402,7 +413,7 @@ class PairWorkload:
                      "rel_bases2": [nr, 2 * nr]}
         self.state_cpu = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
         self.name_emb = torch.from_numpy(name_emb)
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=True, capturable=True)
+        self.opt = make_adam(self.model.parameters(), a)
         self.model.train()
 
     def blocks(self):
@@ -1061,7 +1072,7 @@ def union_train_step(a, device, m, kgs):
     t = torch.from_numpy(np.concatenate([trip[:, 2], rng.integers(0, ja.num_entity, B * K)])).to(device)
     pairs = torch.from_numpy(rng.integers(0, ja.num_entity, (2000, 2))).to(device)
     p0, p1 = pairs[:, 0].contiguous(), pairs[:, 1].contiguous()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True, capturable=True)
+    opt = make_adam(m.parameters(), a)
     k_ja = sorted(kgs).index("ja")
 
     def make(batched):
@@ -1474,6 +1485,8 @@ def main():
                                       a.batch, a.negatives),
                        "exec": exec_mode, "bwd_mode": "deterministic" if a.bwd_mode else "atomic",
                        "library_gemm": "torch.mm (hipBLASLt/rocBLAS), TunableOp %s" % ("on" if tuned else "off"),
+                       "optimizer": ("torch.optim.Adam(fused=True, capturable=True)" if a.torch_adam else
+                                     "jmac_amd.optim.Adam (torch.optim.Adam's update, one launch: jmac_adam_step_f32)"),
                        "edges_counted_per_step": layer_calls * w.E},
             "roofline": roof, "roofline_bwd": roof_bwd, "parity": parity}
     cpu_on = not a.no_cpu_baseline

@@ -533,6 +533,30 @@ int jmac_wcat_unpack_f32(const float* const* dwcat, float* const* d_watt, float*
                          int32_t n_layers, int64_t d, const float* extra_src, float* extra_dst,
                          int64_t extra_floats, jmac_stream_t stream);
 
+/* Adam over every parameter tensor of the model in ONE launch (round 5).  train.py:406-407 build torch.optim.Adam(model.parameters(),
+ * lr) and :358-359 step it once per batch; torch's fused multi-tensor form gives each 65 536-element chunk to one workgroup -- 125
+ * workgroups for the 6.3 M parameters of the DBP-5L model, under half of the 256 CUs.  Same arithmetic as torch.optim.Adam (defaults:
+ * betas 0.9 / 0.999, eps 1e-8, weight_decay 0; decoupled != 0 = AdamW's decay; amsgrad is not offered), bias corrections in double:
+ *   g' = (maximize ? -g : g) (+ wd p);  m = m + (g' - m)(1 - b1);  v = b2 v + (1 - b2) g'^2
+ *   p = p - lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps),      t = step[0] + 1
+ * tasks: HOST array (copied into the kernel arguments: capture-safe; more than JMAC_ADAM_MAX_TASKS: several launches); p / g / m / v
+ * contiguous fp32 of n elements (`vec4` is set by the library).  step [1] device float = completed steps, advanced by one by the
+ * call.  aux [3] device double, 8-byte aligned = { beta1^step, beta2^step, 0 }: the running powers the bias corrections are made
+ * from (advanced by the call; the caller initialises them for the count it starts from -- {1, 1, 0} for a fresh optimizer -- and
+ * again if it changes the betas) and a word that is zero at rest (the last workgroup to finish advances step and powers: every
+ * workgroup has read them by then). */
+#define JMAC_ADAM_MAX_TASKS 64
+typedef struct {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+    int32_t vec4;
+} jmac_adam_task_t;
+int jmac_adam_step_f32(const jmac_adam_task_t* tasks, int32_t n_tasks, float* step, double* aux, double lr, double beta1,
+                       double beta2, double eps, double weight_decay, int32_t decoupled, int32_t maximize, jmac_stream_t stream);
+
 /* Used-relation compaction.  A DBP-5L KG names 153-833 of its 961 relation rows in its edges (ja: 158), and the layer's
  * relation transform + projection (src/jmac_model.py:39-42 and the hoisted R''[Wb|Wg]) matter for named rows only: the encoder
  * runs those products on the COMPACT table of used rows (+ the loop row), with edge types renumbered accordingly.

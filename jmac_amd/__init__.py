@@ -9,6 +9,7 @@ this package is the Python host side that mirrors the reference's operator inter
     jmac_amd.scoring                       l1_scores / filtered_rank / get_neg / alignment_quality
     jmac_amd.scatter                       torch_scatter-compatible scatter_add / scatter / scatter_softmax
     jmac_amd.dist                          destination-sharded multi-GPU layer (RCCL over xGMI)
+    jmac_amd.optim                         Adam / AdamW: torch.optim.Adam's update (train.py:406-407) as one launch
 """
 from ._lib import JmacError, lib  # noqa: F401
 

@@ -43,6 +43,11 @@ class AggFwdJob(C.Structure):
                 ("out_scale", f32), ("out", vp), ("ldo", i64), ("seg_max", vp), ("seg_den", vp), ("ws", vp), ("ws_bytes", sz)]
 
 
+class AdamTask(C.Structure):
+    """jmac_adam_task_t"""
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64), ("vec4", i32)]
+
+
 class GemmTask(C.Structure):
     """jmac_gemm_task_t"""
     _fields_ = [("A", vp), ("A2", vp), ("lda", i64), ("a_split", i64), ("transA", i32), ("transB", i32),
@@ -103,6 +108,8 @@ _SIGS = {
     "jmac_gemm_grouped_f32": (C.c_int, [C.POINTER(GemmTask), i32, vp]),
     "jmac_wcat_pack_f32": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, vp, vp, i64, C.POINTER(vp), i32, vp]),
     "jmac_wcat_pack_seed_f32": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, vp, vp, i64, C.POINTER(vp), i32, vp, vp, vp]),
+    "jmac_adam_step_f32": (C.c_int, [C.POINTER(AdamTask), i32, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i32, i32,
+                                     vp]),
     "jmac_wcat_unpack_f32": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, vp, vp, i64, vp]),
     "jmac_rows_compact_f32": (C.c_int, [C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), i32, vp, i64, i64, vp]),
     "jmac_rows_expand_f32": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(i32), i32, vp, i64, i64, vp]),

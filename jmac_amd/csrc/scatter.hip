@@ -119,6 +119,6 @@ const char* jmac_strerror(int rc) {
 // 100: rounds 1-2;  110: round 3 changed jmac_sim_topk_workspace_bytes to (L, N, k);  120: round 4 additions (segmented BatchNorm,
 // padded bf16 aggregation, exact margin / sorted cosine adjoints; jmac_gemm_nt_x3_f32 moved to the testing library);
 // 121: jmac_softmax_parts_merge_f32 added
-int jmac_version(void) { return 123; }
+int jmac_version(void) { return 124; }
 
 }  // extern "C"

@@ -18,10 +18,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(w, steps):
+def _run(w, steps, torch_adam=False):
+    import bench
     dev = next(w.model.parameters()).device
     w.model.load_state_dict({k: v.to(dev) for k, v in w.state_cpu.items()}, strict=True)
-    w.opt = torch.optim.Adam(w.model.parameters(), lr=1e-3, fused=True, capturable=True)
+    w.opt = bench.make_adam(w.model.parameters(), argparse.Namespace(torch_adam=torch_adam))
     torch.manual_seed(123)
     losses = []
     for _ in range(steps):
@@ -33,8 +34,9 @@ def _run(w, steps):
     return losses, grads, state, moments
 
 
+@pytest.mark.parametrize("torch_adam", [False, True])
 @pytest.mark.parametrize("kind", ["ja", "pair"])
-def test_two_full_steps_are_bitwise_identical(kind):
+def test_two_full_steps_are_bitwise_identical(kind, torch_adam):
     """bench.py's own workloads on the REAL data at d = 300 (dropout 0.4 on): ``ja`` = the single-KG step of the headline
     (forward_base + completion / cosine losses + backward + Adam), ``pair`` = JMAC.completion_loss on the el + ja pair through the
     stacked launch set."""
@@ -43,7 +45,7 @@ def test_two_full_steps_are_bitwise_identical(kind):
     a = argparse.Namespace(dim=300, batch=1000, negatives=25, bwd_mode=1)
     w = bench.JaWorkload(a, torch.device("cuda"), data="real") if kind == "ja" else bench.PairWorkload(a, torch.device("cuda"))
     assert w.model.completion_dropout.p == 0.4 and w.model.training
-    a1, a2 = _run(w, 2), _run(w, 2)
+    a1, a2 = _run(w, 2, torch_adam), _run(w, 2, torch_adam)
     for x, y in zip(a1[0], a2[0]):
         assert torch.equal(x, y), (float(x), float(y))
     for name in a1[1]:

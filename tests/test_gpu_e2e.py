@@ -13,8 +13,12 @@ pytestmark = pytest.mark.gpu
 from e2e_replay import check_outcome, feeddict, fixture
 
 
-def test_hip_path_replays_reference_training_run():
-    from jmac_amd import harness, scoring
+@pytest.mark.parametrize("optimizer", ["torch.optim.Adam", "jmac_amd.optim.Adam"])
+def test_hip_path_replays_reference_training_run(optimizer):
+    """Both optimizers replay the run: the reference's own (torch.optim.Adam, train.py:406-407) and this library's one-launch form of
+    the same update -- it has to land on the same losses, checkpoint ranks and metrics."""
+    from jmac_amd import harness, optim, scoring
+    Adam = torch.optim.Adam if optimizer == "torch.optim.Adam" else optim.Adam
     from jmac_amd.model import JMAC
     g, m = fixture()
     dev = torch.device("cuda")
@@ -25,8 +29,8 @@ def test_hip_path_replays_reference_training_run():
     model.ent_info_att = model.ent_info_att.to(dev)
     for lay in (model.conv1_alignment, model.conv2_alignment, model.conv1_completion):
         lay.loop_rel.requires_grad_(False)                    # as in the fixture (see gen_e2e: zero-gradient parameter + Adam)
-    opt_a = torch.optim.Adam(model.parameters(), lr=m["lr"])  # train.py:406-407
-    opt_c = torch.optim.Adam(model.parameters(), lr=m["lr"])
+    opt_a = Adam(model.parameters(), lr=m["lr"])  # train.py:406-407
+    opt_c = Adam(model.parameters(), lr=m["lr"])
     e1i, e1t, e2i, e2t = (torch.from_numpy(g[k]).to(dev) for k in ("e1_index", "e1_type", "e2_index", "e2_type"))
     feed = feeddict(g, m)
     val = g["val1"]

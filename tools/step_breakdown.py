@@ -1,7 +1,7 @@
 import csv, collections, sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-adam=[i for i,r in enumerate(rows) if 'multi_tensor_apply' in r['Kernel_Name'] and 'FusedOptimizer' in r['Kernel_Name']]
+adam=[i for i,r in enumerate(rows) if ('multi_tensor_apply' in r['Kernel_Name'] and 'FusedOptimizer' in r['Kernel_Name']) or 'adam_step_kernel' in r['Kernel_Name']]   # the step's last kernel: either optimizer
 a,b=adam[-21],adam[-1]
 win=rows[a+1:b+1]
 tot=collections.Counter(); cnt=collections.Counter()

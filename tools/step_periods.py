@@ -5,7 +5,7 @@ import csv, sys
 import numpy as np
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-adam = [i for i, r in enumerate(rows) if 'multi_tensor_apply' in r['Kernel_Name'] and 'FusedOptimizer' in r['Kernel_Name']]
+adam = [i for i, r in enumerate(rows) if ('multi_tensor_apply' in r['Kernel_Name'] and 'FusedOptimizer' in r['Kernel_Name']) or 'adam_step_kernel' in r['Kernel_Name']]   # the step's last kernel: either optimizer
 ends = np.array([int(rows[i]['End_Timestamp']) for i in adam], dtype=np.float64)
 per = np.diff(ends) / 1e3
 gaps = np.array([(int(rows[i + 1]['Start_Timestamp']) - int(rows[i]['End_Timestamp'])) / 1e3 for i in adam[:-1] if i + 1 < len(rows)])

@@ -3,7 +3,7 @@ usage: python tools/step_timeline.py <p_kernel_trace.csv>"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-adam = [i for i, r in enumerate(rows) if 'multi_tensor_apply' in r['Kernel_Name'] and 'FusedOptimizer' in r['Kernel_Name']]
+adam = [i for i, r in enumerate(rows) if ('multi_tensor_apply' in r['Kernel_Name'] and 'FusedOptimizer' in r['Kernel_Name']) or 'adam_step_kernel' in r['Kernel_Name']]   # the step's last kernel: either optimizer
 a, b = adam[-2], adam[-1]
 t0 = int(rows[a]['End_Timestamp'])
 busy = 0
