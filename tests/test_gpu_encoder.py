@@ -517,7 +517,7 @@ def test_relation_side_on_used_rows_equals_all_rows(no_name):
                 if not torch.is_tensor(loss):
                     continue
                 loss.backward()
-                res[(use, flag)] = (float(loss), [x.detach().clone() for x in (a, comp[1], rel[1])],
+                res[(use, flag)] = (float(loss.detach()), [x.detach().clone() for x in (a, comp[1], rel[1])],
                                     {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()})
             finally:
                 encoder.COMPACT_RELATIONS = True
