@@ -18,3 +18,13 @@ for n,t in tot.items():
 print(dict(groups))
 for n,t in tot.most_common(int(sys.argv[2]) if len(sys.argv)>2 else 30):
     print("%8.1f us  x%5.1f  %s"%(t/20/1e3,cnt[n]/20,n[:110]))
+if len(sys.argv) > 3 and sys.argv[3] == "grid":       # launch geometry per kernel: workgroups, workgroup size, VGPRs, LDS
+    seen = {}
+    for r in win:
+        n = r['Kernel_Name']
+        g = (int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z'])) // max(1, int(r['Workgroup_Size_X']) * int(r['Workgroup_Size_Y']) * int(r['Workgroup_Size_Z']))
+        seen.setdefault((n, g, int(r['Workgroup_Size_X']), int(r['VGPR_Count']), int(r['LDS_Block_Size'])), []).append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    print("-- launch geometry: us (mean)  workgroups  wg-size  vgpr  lds  kernel")
+    for (n, g, wg, vg, lds), d in sorted(seen.items(), key=lambda kv: -sum(kv[1])):
+        if not n.startswith("Cijk"):
+            print("%8.1f  x%4.1f  %7d  %5d  %4d  %6d  %s" % (sum(d) / len(d) / 1e3, len(d) / 20, g, wg, vg, lds, n[:90]))
