@@ -192,3 +192,33 @@ def test_changed_betas_restart_the_powers():
         o.param_groups[0]["lr"] = 5e-4
         _run(o, ps, 23, 6, first=6)
     _close(pj, p64, p32, p0, "param")
+
+
+def test_param_groups_empty_tensors_and_strided_gradients():
+    """Two groups with their own hyper-parameters (each has its own device step count), a zero-element parameter, and gradients that
+    arrive as expanded / transposed views (autograd hands those out: sum().backward(), .t())."""
+    from jmac_amd import optim
+    shapes = [(300, 40), (40,), (0, 7), (64, 64), (5,)]
+
+    def build(dtype, device, cls):
+        ps = _params(10, shapes, dtype=dtype, device=device)
+        return ps, cls([{"params": ps[:3], "lr": 2e-3, "weight_decay": 0.01}, {"params": ps[3:], "betas": (0.7, 0.95)}], lr=1e-3)
+
+    (p64, o64), (p32, o32), (pj, oj) = (build(torch.float64, "cpu", torch.optim.Adam), build(torch.float32, "cuda", torch.optim.Adam),
+                                        build(torch.float32, "cuda", optim.Adam))
+    p0 = [p.detach().clone() for p in p64]
+    for k in range(8):
+        for ps in (p64, p32, pj):
+            gs = _grads(29, shapes, k)
+            for i, (p, g) in enumerate(zip(ps, gs)):
+                g = g.to(device=p.device, dtype=p.dtype)
+                if i == 1:
+                    g = g[:1].expand(40)                       # stride 0
+                if i == 3:
+                    g = g.t()                                  # transposed view
+                p.grad = g
+        for o in (o64, o32, oj):
+            o.step()
+    _close([p for i, p in enumerate(pj) if i != 2], [p for i, p in enumerate(p64) if i != 2], [p for i, p in enumerate(p32) if i != 2],
+           [p for i, p in enumerate(p0) if i != 2], "param")
+    assert len({id(oj.state[p]["step"]) for p in pj}) == 2
