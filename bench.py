@@ -38,6 +38,7 @@ import torch
 REAL_DATA = os.path.join(ROOT, "tests", "golden", "dbp5l_ja_el_data.npz")   # the real el / ja triples as integer arrays
 REAL_ALL = os.path.join(ROOT, "tests", "golden", "dbp5l_all_data.npz")      # all five real KGs + the ten seed-pair files
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+PMC_ROUNDS = ("r6", "r5", "r4", "r3")    # committed rocprofv3 --pmc summaries, newest first (profiles/<round>_pmc_<key>.json)
 
 
 def enable_gemm_tuning(rank):
@@ -78,15 +79,19 @@ def freeze_gemm_tuning():
 
 
 def emit(line):
-    """Rank 0's ONE JSON line, as the last thing on stdout: RCCL writes a version banner through C stdio, which sits
-    in libc's buffer until it is flushed -- flush it first, then print."""
+    """Rank 0's ONE JSON line, as the last thing on stdout, at most bench_line.LIMIT (4 096) bytes: the keys the driver checks
+    (bench_line.compact); the whole record -- every side measurement, the scaling models, the wall-clock sections -- goes to
+    bench_full.json beside this file (bench_line.write_full; round 5's single 23 KB line was cut by the driver's stdout tail).
+    RCCL writes a version banner through C stdio, which sits in libc's buffer until it is flushed -- flush it first, then print."""
+    import bench_line
     try:
         import ctypes
         ctypes.CDLL(None).fflush(None)
     except Exception:                                    # pragma: no cover
         pass
     sys.stdout.flush()
-    print(json.dumps(line), flush=True)
+    path = bench_line.write_full(line)
+    print(json.dumps(bench_line.compact(line, path or "not written")), flush=True)
 
 
 def parse():
@@ -103,6 +108,11 @@ def parse():
     ap.add_argument("--negatives", type=int, default=25)
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the CPU port with torch.set_num_threads(os.cpu_count()) (BASELINE.md section 2's setting; on a "
+                         "256-thread host one such step takes over a minute -- profiles/r5_bench.json holds the figure)")
+    ap.add_argument("--no-torch-adam-leg", action="store_true",
+                    help="skip the second timing of the headline step with torch.optim.Adam (ms_per_step_torch_adam)")
     ap.add_argument("--no-synth", action="store_true")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the library GEMM heuristics as they are")
     ap.add_argument("--torch-adam", action="store_true", help="step torch.optim.Adam(fused, capturable) instead of jmac_amd.optim.Adam")
@@ -1047,20 +1057,21 @@ def pair_bench(a, device, rank, ms_single, cpu=True):
     return res
 
 
-def union_train_step(a, device, m, kgs):
-    """Train-mode config 3: the five real KGs encoded as ONE launch set with per-KG BatchNorm statistics (JMAC.forward_stacked),
+def union_train_setup(a, device, m, kgs):
+    """(make(batched) -> step closure, E, N) of train-mode config 3: the five real KGs encoded as ONE launch set with per-KG BatchNorm statistics (JMAC.forward_stacked),
     a completion margin loss on a batch of the target's triples (both layers) + a cosine term on the el-ja seed links of the
     alignment output, backward through all three layers of all five KGs, Adam; fp32 tables (training form), one hipGraph.
-    Beside it: the same step as five forward_base calls."""
+    make(False): the same step as five forward_base calls."""
     from jmac_amd import losses
     from jmac_amd.data import edges_from_triples
     m.set_table_dtype(torch.float32)
     m.train()
-    blocks, E = [], 0
+    blocks, E, N = [], 0, 0
     for lang in sorted(kgs):
         kg = kgs[lang]
         ei, et = edges_from_triples(kg.train_data, False)
         E += ei.shape[1]
+        N += kg.num_entity
         blocks.append((torch.from_numpy(ei).to(device), torch.from_numpy(et).to(device), [kg.entity_id_base, kg.upper_entity_base],
                        [kg.relation_id_base, kg.upper_relation_base]))
     ja = kgs["ja"]
@@ -1094,6 +1105,27 @@ def union_train_step(a, device, m, kgs):
             opt.step()
             return loss
         return step
+    return make, E, N
+
+
+def union_real_model(a, device):
+    """(JMAC over the union id space of the five real KGs, kgs) as union_bench builds them (tools/pair_probe.py --union)."""
+    from jmac_amd import data as jdata
+    from jmac_amd.model import JMAC
+    rng = np.random.default_rng(11)
+    kgs, _, _, _ = jdata.kgs_from_arrays(jdata.load_dbp5l_arrays(REAL_ALL), "ja")
+    _, _, n, nr, _, _ = jdata.union_edges(kgs)
+    torch.manual_seed(11)
+    m = JMAC(make_args(a.dim, a.batch, a.negatives, device), rng.standard_normal((n, 300)).astype(np.float32), nr, n).to(device)
+    m.ent_info_att = m.ent_info_att.to(device)
+    return m, kgs
+
+
+def union_train_step(a, device, m, kgs):
+    """Train-mode config 3 timed: the batched step (one launch set, one hipGraph) and the five-call form beside it, plus the
+    aggregation backward's roofline at THIS size (197 604 edges per layer call: not latency-bound as the 18 k-edge ja graph is)."""
+    from jmac_amd import ops, synth
+    make, E, N = union_train_setup(a, device, m, kgs)
     out = {"workload": "forward_stacked over the five real KGs (per-KG BatchNorm statistics), fp32 tables, losses on the ja block, "
                        "backward through 3 layers x 5 KGs, Adam", "E": E}
     for key, batched in (("ms_per_step", True), ("separate_calls_ms_per_step", False)):
@@ -1117,6 +1149,36 @@ def union_train_step(a, device, m, kgs):
     out["edges_per_s"] = 3 * E / (out["ms_per_step"] * 1e-3)
     out["speedup_over_separate_calls"] = out["separate_calls_ms_per_step"] / out["ms_per_step"]
     m.batched_pairs = True
+    # the aggregation kernels inside this step: HIP events around each op of an eager pass (live) and the kernels' durations inside
+    # the replayed step (committed rocprofv3 kernel trace, tools/pair_probe.py --union); bytes by SURVEY 8d's formulas on the union
+    step = make(True)
+    ops.PROFILE = []
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    rec, ops.PROFILE = ops.PROFILE, None
+    ev = {}
+    for name, e0, e1 in rec:
+        ev.setdefault(name, []).append(e0.elapsed_time(e1))
+    calls = 3                                                    # layer calls per step (the first two are one paired launch)
+    fb, bb = synth.fwd_algorithmic_bytes(N, E, a.dim), synth.bwd_algorithmic_bytes(N, E, a.dim)
+    kern, ksrc = step_kernels("union_train") if a.dim == 300 else (None, None)
+    f_us, b_us = in_step_us(kern, "rel_attn_fwd"), in_step_us(kern, "rel_attn_bwd", "bwd_finalize_kernel")
+    for key, nbytes, us, evname in (("roofline_fwd", fb, f_us, "rel_attn_fwd"), ("roofline_bwd", bb, b_us, "rel_attn_bwd")):
+        evs = [t for n_, ts in ev.items() if n_.startswith(evname) for t in ts]        # "rel_attn_fwd_pair": the paired first-layer launch
+        ev_ms = float(np.sum(evs)) / 5 / calls if evs else None
+        ms_in = us / calls * 1e-3 if us else None
+        ms = max(x for x in (ev_ms, ms_in) if x is not None) if (ev_ms or ms_in) else None
+        if ms is None:
+            continue
+        out[key] = {"bound": "hbm", "algorithmic_bytes_per_layer_call": nbytes, "avg_ms_per_layer_call": ms, "in_step_event_ms": ev_ms,
+                    "in_step_rocprof_ms": ms_in, "source": ksrc, "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if a.dim == 300:
+        parts = [pmc_traffic("union_train", k, ("r6",)) for k in ("rel_attn_bwd_dst_kernel", "rel_attn_bwd_gather_kernel", "bwd_finalize_kernel")]
+        if "roofline_bwd" in out and all(p is not None for p in parts):
+            out["roofline_bwd"]["traffic_per_step"] = float(sum(parts))
+            out["roofline_bwd"]["traffic_over_algorithmic"] = float(sum(parts)) / (calls * bb)
     return out
 
 
@@ -1282,7 +1344,7 @@ def complete_sharded_line(line, a):
                                               "one rank's graph; not collected by this run)")
 
 
-def pmc_traffic(key, kernel_prefix, rounds=("r5", "r4", "r3", "r2"), section="kernels"):
+def pmc_traffic(key, kernel_prefix, rounds=("r6", "r5", "r4", "r3", "r2"), section="kernels"):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r2_pmc_<key>.json), or None.
     PMC collection needs rocprofv3 around the process, so bench.py reports the committed measurement."""
     for rnd in rounds:
@@ -1296,7 +1358,7 @@ def pmc_traffic(key, kernel_prefix, rounds=("r5", "r4", "r3", "r2"), section="ke
     return None
 
 
-def pmc_source(key, rounds=("r5", "r4", "r3", "r2")):
+def pmc_source(key, rounds=("r6", "r5", "r4", "r3", "r2")):
     """The newest committed PMC file for ``key`` (what pmc_traffic reads), for the line's *_source fields."""
     for rnd in rounds:
         fn = os.path.join("profiles", "%s_pmc_%s.json" % (rnd, key))
@@ -1305,9 +1367,43 @@ def pmc_source(key, rounds=("r5", "r4", "r3", "r2")):
     return None
 
 
+def step_kernels(workload, rounds=("r6",)):
+    """Per-kernel durations INSIDE the hipGraph-replayed step (rocprofv3 --kernel-trace of tools/pair_probe.py, summarised by
+    tools/step_breakdown.py --json into profiles/<round>_step_kernels.json): ({kernel name: (us per step, calls per step)}, file)
+    or (None, None).  A kernel in the step runs behind other kernels' cache state, which back-to-back launches of one kernel
+    do not see; the line's roofline.frac is the smaller of the two readings."""
+    for rnd in rounds:
+        fn = os.path.join("profiles", "%s_step_kernels.json" % rnd)
+        try:
+            d = json.load(open(os.path.join(ROOT, fn)))["workloads"][workload]
+            return {k["name"]: (k["us_per_step"], k["calls_per_step"]) for k in d["kernels"]}, fn
+        except (OSError, KeyError, ValueError, TypeError):
+            pass
+    return None, None
+
+
+def in_step_us(kern, *needles):
+    """Sum of us per step over the kernels whose name contains one of ``needles`` (None when nothing matches)."""
+    if not kern:
+        return None
+    hit = [us for n, (us, _) in kern.items() if any(x in n for x in needles)]
+    return float(sum(hit)) if hit else None
+
+
+def crosstime_ratio():
+    """(median oracle / reference cost ratio of the CPU port, file) from the committed cross-timing in the build container
+    (tests/golden/crosstime_reference.py -> profiles/r6_crosstime.json), or (None, None).  BASELINE.md section 2: the port stands
+    in for the reference's CPU path on the condition of equal cost +-10 %."""
+    fn = os.path.join("profiles", "r6_crosstime.json")
+    try:
+        return float(json.load(open(os.path.join(ROOT, fn)))["median_ratio"]), fn
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, None
+
+
 def pmc_mfma_util():
     """(rocprofv3's MfmaUtil for sim_gemm_kernel from the newest committed PMC pass, that file's name), or (None, None)."""
-    for rnd in ("r5", "r3"):
+    for rnd in ("r6", "r5", "r3"):
         fn = os.path.join("profiles", "%s_pmc_mfma.json" % rnd)
         try:
             d = json.load(open(os.path.join(ROOT, fn)))
@@ -1454,23 +1550,39 @@ def main():
     bbytes = synth.bwd_algorithmic_bytes(w.N, w.E, w.d)
     raw = raw_kernel_timing(w.N, w.E, w.nr, w.d, w.ei, w.et, device, iters=50, bwd_mode=a.bwd_mode)
     fwd_ms = raw["fwd_ms"]
-    roof = {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<3, 2, 75, float>", "achieved": fbytes / (fwd_ms * 1e-3) / 1e9,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fbytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": (pmc_traffic("ja", "rel_attn_fwd_kernel", ("r5", "r4", "r3") if a.data == "real" else ("r2",))
+    # two readings of the forward kernel's duration: HIP events around back-to-back launches (live, this run) and the kernel's
+    # duration inside the replayed step (committed rocprofv3 kernel trace of the same step: the first layer's two independent calls
+    # are ONE launch there, rel_attn_fwd_jobs_kernel, so the per-launch figure is the step's total over its layer_calls).  frac is
+    # the smaller of the two.
+    kern, kern_src = step_kernels("ja") if (a.data == "real" and w.d == 300 and a.workload == "dbp5l-ja") else (None, None)
+    f_us, b_us = in_step_us(kern, "rel_attn_fwd"), in_step_us(kern, "rel_attn_bwd", "bwd_finalize_kernel")
+    frac_b2b = fbytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    frac_in = (layer_calls * fbytes / (f_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if f_us else None
+    frac = min(frac_b2b, frac_in) if frac_in is not None else frac_b2b
+    roof = {"bound": "hbm", "kernel": "rel_attn_fwd_kernel<3, 2, 75, float>", "achieved": frac * HBM_PEAK_GBS,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac, "frac_in_step": frac_in, "frac_back_to_back": frac_b2b,
+            "traffic": (pmc_traffic("ja", "rel_attn_fwd_kernel", PMC_ROUNDS if a.data == "real" else ("r2",))
                         if (w.d == 300 and a.workload == "dbp5l-ja") else None),
             "traffic_source": roof_src,
             "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": fwd_ms, "launches": raw["fwd_launches"],
-            "timing": "HIP events around %d back-to-back C-ABI launches on the launch stream" % raw["fwd_launches"],
+            "in_step_launch_ms": (f_us / layer_calls * 1e-3) if f_us else None,
+            "source": ("frac = min(in-step: %s, rocprofv3 kernel trace of the replayed step; back-to-back: HIP events around %d "
+                       "C-ABI launches in this run)" % (kern_src, raw["fwd_launches"])) if frac_in is not None else
+                      ("HIP events around %d back-to-back C-ABI launches on the launch stream (no committed in-step trace for this "
+                       "workload)" % raw["fwd_launches"]),
             "in_step_op_ms": prof["rel_attn_fwd"][0],
             "note": "ja-scale working set (72 MB) is Infinity-Cache resident; HBM-scale figure is in 'synth'"}
+    bwd_ms_in = (b_us / layer_calls * 1e-3) if b_us else None           # rocprof: dst + gather(s) + finalize, per layer call
+    bwd_ms = max(prof["rel_attn_bwd"][0], bwd_ms_in) if bwd_ms_in else prof["rel_attn_bwd"][0]
     roof_bwd = {"bound": "hbm", "kernels": "rel_attn_bwd_dst + 2x rel_attn_bwd_gather (+reductions)",
                 "bytes": "SURVEY 8d backward formula E(2ds+8) + E*2d*4 + N(3d*4+16)", "algorithmic_bytes": bbytes,
-                "achieved": bbytes / (prof["rel_attn_bwd"][0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": bbytes / (prof["rel_attn_bwd"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "avg_launch_ms": prof["rel_attn_bwd"][0], "back_to_back_ms": raw["bwd_ms"],
+                "achieved": bbytes / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": bbytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "avg_launch_ms": bwd_ms, "in_step_event_ms": prof["rel_attn_bwd"][0], "in_step_rocprof_ms": bwd_ms_in,
+                "back_to_back_ms": raw["bwd_ms"],
                 "implementation_bytes": synth.bwd_implementation_bytes(w.N, w.E, w.d)}
     if a.data == "real" and a.dim == 300:             # the three launches' HBM-side bytes from the committed PMC passes
-        parts = [pmc_traffic("ja", k, ("r5", "r4", "r3")) for k in ("rel_attn_bwd_dst_kernel", "rel_attn_bwd_gather_kernel", "bwd_finalize_kernel")]
+        parts = [pmc_traffic("ja", k, PMC_ROUNDS) for k in ("rel_attn_bwd_dst_kernel", "rel_attn_bwd_gather_kernel", "bwd_finalize_kernel")]
         roof_bwd["traffic"] = float(sum(parts)) if all(p is not None for p in parts) else None
         roof_bwd["traffic_source"] = roof_src
 
@@ -1487,12 +1599,29 @@ def main():
                        "library_gemm": "torch.mm (hipBLASLt/rocBLAS), TunableOp %s" % ("on" if tuned else "off"),
                        "optimizer": ("torch.optim.Adam(fused=True, capturable=True)" if a.torch_adam else
                                      "jmac_amd.optim.Adam (torch.optim.Adam's update, one launch: jmac_adam_step_f32)"),
-                       "edges_counted_per_step": layer_calls * w.E},
+                       "edges_counted_per_step": layer_calls * w.E,
+                       "batch_reuse": "one fixed batch replayed; index upload outside the timed region"},
             "roofline": roof, "roofline_bwd": roof_bwd, "parity": parity}
+    lap("roofline_timing")
+    if not a.no_torch_adam_leg and not a.torch_adam:
+        # rounds 1-4 stepped torch.optim.Adam(fused, capturable): the same step with it, so the round-to-round series stays comparable
+        try:
+            ta = argparse.Namespace(**vars(a))
+            ta.torch_adam = True
+            w2 = JaWorkload(ta, device, seed=1234 + rank, data=a.data)
+            for _ in range(2):
+                w2.step()
+            torch.cuda.synchronize()
+            fn2 = w2.step if a.no_graph else try_capture(w2).replay
+            line["ms_per_step_torch_adam"] = time_steps(fn2, a.steps, a.warmup, False) / a.steps * 1e3
+            del w2, fn2
+        except Exception as ex:                      # pragma: no cover
+            line["ms_per_step_torch_adam"] = None
+            sys.stderr.write("torch-adam leg failed (%s)\n" % (ex,))
+        lap("torch_adam_leg")
     cpu_on = not a.no_cpu_baseline
     ncpu_small = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(ncpu_small)
-    lap("roofline_timing")
     line["layer"] = layer_bench(w, device, cpu_on)
     line["scoring"] = scoring_bench(w, cpu=cpu_on)
     try:
@@ -1537,8 +1666,12 @@ def main():
                                 "cpu_model": _cpu_model()}
         # BASELINE.md section 2 asks for torch.set_num_threads(os.cpu_count()): that figure beside the best-case one (bounded:
         # at most two timed steps or 25 s)
+        ratio, rsrc = crosstime_ratio()
+        if ratio is not None:                    # committed: measured in the build container, where the reference can be imported
+            line["cpu_baseline"]["port_vs_reference_cost_ratio"] = ratio
+            line["cpu_baseline"]["port_vs_reference_source"] = rsrc
         nall = os.cpu_count() or 1
-        if nall not in (16, 32):
+        if a.cpu_all_cores and nall not in (16, 32):
             try:
                 torch.set_num_threads(nall)
                 t0, k = time.perf_counter(), 0            # no separate warm-up: the oracle's buffers are warm from the timed

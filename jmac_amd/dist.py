@@ -535,12 +535,18 @@ class _ChunkedAllGather(torch.autograd.Function):
     def backward(ctx, g):
         sg, group = ctx.sg, ctx.group
         world = _world(group)
-        done = getattr(g, "_jmac_reduced", None)             # _ChunkedAggregate.backward already reduce-scattered it, slab by slab
-        if done is not None:
-            global HANDOFF_COUNT
-            HANDOFF_COUNT += 1
+        # _ChunkedAggregate.backward may already have reduce-scattered this very gradient, slab by slab.  The hand-off is valid only
+        # while ``g`` is still that tensor, untouched: a second differentiable consumer of the table makes autograd accumulate
+        # its gradient onto ``g`` IN PLACE (the attribute survives, the version counter moves) -- then the full reduce below is the
+        # right thing, because ``g`` is the complete sum.
+        hand = getattr(g, "_jmac_reduced", None)
+        if hand is not None:
             g._jmac_reduced = None
-            return done, None, None
+            done, version, ptr = hand
+            if g._version == version and g.data_ptr() == ptr:
+                global HANDOFF_COUNT
+                HANDOFF_COUNT += 1
+                return done, None, None
         own = g[world * sg.n_max:]                           # gradient of the own-rows copy (the self loop's dZ)
         if _skip(group):
             return g[:sg.n_max] + own, None, None
@@ -600,7 +606,8 @@ class _ChunkedAggregate(torch.autograd.Function):
         global OVERLAP_COUNT
         P, table, RR, a, pre, seg_max, seg_den = ctx.saved_tensors
         sg, kernels = ctx.sg, ctx.kernels
-        if not (OVERLAP_BACKWARD and ctx.group is not None and hasattr(kernels, "backward_phased")):
+        # the phased form exists to hide d table's reduce-scatters: without a gradient for the table there is nothing to exchange
+        if not (OVERLAP_BACKWARD and ctx.group is not None and ctx.needs_input_grad[1] and hasattr(kernels, "backward_phased")):
             dP, dT, dRR, da = kernels.backward(P, table, RR, a, sg, ctx.slope, pre, seg_max, seg_den, G.contiguous())
             return dP, dT, dRR, da, None, None, None
         # Overlapped form (adjoint of the slab-pipelined exchange): pass B -- the by-source sums that produce d table -- runs slab by
@@ -639,7 +646,8 @@ class _ChunkedAggregate(torch.autograd.Function):
             _cdone("reduce_scatter_dqz_chunk", e0, gc)
         out += own
         dT = bp.dQZ
-        dT._jmac_reduced = out                               # _ChunkedAllGather.backward hands it on instead of reducing again
+        # _ChunkedAllGather.backward hands ``out`` on instead of reducing again -- if dT reaches it as it is now (version, storage)
+        dT._jmac_reduced = (out, dT._version, dT.data_ptr())
         OVERLAP_COUNT += 1
         return bp.dP, dT, bp.dRR, bp.da, None, None, None
 

@@ -4,6 +4,7 @@ single-process oracle.  The rank-local aggregation is a torch stand-in INJECTED 
 default is the HIP op; there is no CPU fallback in jmac_amd)."""
 import os
 import socket
+import types
 
 import numpy as np
 import pytest
@@ -319,3 +320,71 @@ def test_bf16_wire_format_rounds_only_the_gathered_table(monkeypatch):
         assert torch.allclose(o["gr"], Rg.grad, atol=2e-4, rtol=1e-3), float((o["gr"] - Rg.grad).abs().max())
         for k, g in o["grads"].items():
             assert torch.allclose(g, p[k].grad, atol=5e-4, rtol=1e-3), (k, float((g - p[k].grad).abs().max()))
+
+
+def _two_consumer_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torch.nn.functional as F
+        import jmac_amd.dist as jd
+        from jmac_amd.dist import ShardedGraph, chunked_aggregate, chunked_all_gather, partition_rows
+        ei, et, X, R, G, n, nr, d = _case()
+        sg = ShardedGraph(ei, et, partition_rows(np.bincount(ei[0], minlength=n), world), rank, chunks=3)
+        gen = torch.Generator().manual_seed(5)
+        P = torch.randn(sg.n_local, d, generator=gen)
+        RR = torch.randn(nr + 1, 2 * d, generator=gen)
+        a = torch.randn(d, generator=gen)
+        W = torch.randn(sg.table_rows, 2 * d, generator=torch.Generator().manual_seed(50 + rank))
+        res = {}
+        for order in ("aggregate_first", "second_first"):
+            for overlap in (True, False):
+                jd.OVERLAP_BACKWARD, jd.HANDOFF_COUNT, jd.OVERLAP_COUNT = overlap, 0, 0
+                x = torch.randn(sg.n_local, 2 * d, generator=torch.Generator().manual_seed(9 + rank)).requires_grad_(True)
+                table = chunked_all_gather(F.pad(x, (0, 0, 0, sg.n_max - sg.n_local)), sg, None)
+                if order == "aggregate_first":
+                    pre = chunked_aggregate(P, table, RR, a, sg, 0.05, kernels=_StandinChunked)
+                    second = (table * W).sum()
+                else:                                       # the node order of the graph decides whose gradient reaches the
+                    second = (table * W).sum()              # table's input buffer first (and which one is accumulated in place)
+                    pre = chunked_aggregate(P, table, RR, a, sg, 0.05, kernels=_StandinChunked)
+                ((pre * G[sg.lo:sg.hi]).sum() + second).backward()
+                res[(order, overlap)] = (x.grad.clone(), jd.OVERLAP_COUNT, jd.HANDOFF_COUNT)
+        jd.OVERLAP_BACKWARD = True
+        # the hand-off itself, without relying on which buffer the autograd engine accumulates into: an untouched d table takes
+        # the shortcut, one that was added to in place afterwards is reduced in full
+        ctx = types.SimpleNamespace(sg=sg, group=None)
+        g = torch.randn(sg.table_rows, 2 * d, generator=torch.Generator().manual_seed(70 + rank))
+        full = jd._ChunkedAllGather.backward(ctx, g.clone())[0]
+        marker = torch.full((sg.n_max, 2 * d), 7.0)
+        g1 = g.clone()
+        g1._jmac_reduced = (marker, g1._version, g1.data_ptr())
+        took = jd._ChunkedAllGather.backward(ctx, g1)[0]
+        g2 = g.clone()
+        g2._jmac_reduced = (marker, g2._version, g2.data_ptr())
+        g2.add_(1.0)                                        # what AccumulateGrad-style in-place summation does
+        full2 = jd._ChunkedAllGather.backward(ctx, g2)[0]
+        res["handoff"] = (took is marker, torch.equal(full2, jd._ChunkedAllGather.backward(ctx, g + 1.0)[0]), bool((full2 != 7.0).any()),
+                          getattr(g2, "_jmac_reduced", None) is None, torch.isfinite(full).all().item())
+        ret[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_table_with_a_second_consumer_keeps_both_gradients():
+    """the overlapped backward hands the already reduce-scattered gradient to _ChunkedAllGather.backward through
+    an attribute on d table.  With a second differentiable consumer of the public chunked_all_gather table, autograd sums the two
+    gradients -- in place onto d table when it arrives first -- and the stale hand-off would drop the second consumer's share.
+    The hand-off is taken only for an untouched d table (version + storage); otherwise the complete sum is reduced in full."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_two_consumer_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        for order in ("aggregate_first", "second_first"):
+            g_over, n_over, n_hand = ret[r][(order, True)]
+            g_plain, n_over0, _ = ret[r][(order, False)]
+            assert n_over == 1 and n_over0 == 0 and n_hand <= 1
+            assert torch.isfinite(g_over).all()
+            assert torch.allclose(g_over, g_plain, atol=1e-5, rtol=1e-5), (r, order, float((g_over - g_plain).abs().max()))
+        assert ret[r]["handoff"] == (True, True, True, True, True), ret[r]["handoff"]
