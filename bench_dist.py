@@ -207,6 +207,157 @@ def run_sharded(a, rank, world, device):
     return line
 
 
+def _ms(fn, n=3, warm=1):
+    """Median HIP-event milliseconds of fn() on the current stream."""
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+def rehearse_world(a, device, world=8, chunks=4, check=True):
+    """ONE process, no collective: rank 0's share of weak-scaled config 4 at ``world`` ranks -- n_loc local destinations, e_loc
+    edges whose sources are uniform over the whole world * n_loc-row [Q|Z] table (19.2 GB fp32 at world 8, d = 300), the table
+    filled locally with what the all-gather would have delivered.  Timed, with HIP events on the launch stream:
+      (a) the one-piece forward (jmac_rel_attn_aggregate_fwd_f32, fused self loop) and the one-call deterministic backward;
+      (b) the slab-pipelined forward: ``chunks`` partial passes over the chunk-major table + jmac_softmax_parts_merge_f32;
+      (c) the phased backward: begin() = passes A, C and their merges, then pass B slab by slab (what the reduce-scatters hide behind).
+    What scaling_model carried over from the world-1 run (a 1M-row, 2.4 GB table) is measured here at the table the rank would
+    really gather from.  check: the size-independent properties of tests/test_gpu_fullsize.py on THIS graph (softmax
+    normalisation through every merge, backward conservation laws), pipelined == one-piece, phased == one-call -- the kernels
+    index a table of more than 2^32 bytes."""
+    from jmac_amd import ops, synth
+    from jmac_amd.dist import ShardedGraph, _HipChunked
+    d, nr, slope = a.dim, 1000, 0.05
+    n_loc, e_loc = int(1_000_000 * a.synth_scale), int(20_000_000 * a.synth_scale)
+    ei, et = _local_graph(0, world, n_loc, e_loc, nr)
+    bounds = np.arange(world + 1, dtype=np.int64) * n_loc
+    sg = ShardedGraph(ei, et, bounds, 0, already_local=True, chunks=1)
+    gen = torch.Generator(device=device).manual_seed(77)
+    rows = world * n_loc
+    QZ = torch.empty(rows, 2 * d, device=device)
+    for r0 in range(0, rows, 1 << 20):                                   # filled slab by slab: no second 19 GB temporary
+        QZ[r0:r0 + (1 << 20)].normal_(0.0, 0.3, generator=gen)
+    P = torch.randn(n_loc, d, device=device, generator=gen) * 0.3
+    RR = torch.randn(nr + 1, 2 * d, device=device, generator=gen) * 0.3
+    av = torch.randn(d, device=device, generator=gen) * 0.1
+    G = torch.randn(n_loc, d, device=device, generator=gen)
+    g = sg.rel_graph(device, nr + 1)
+    g.ensure_backward_views()
+    deg = (g.rowptr[1:] - g.rowptr[:-1]).double()
+    res = {"world": world, "local_rows": n_loc, "local_edges": e_loc, "table_rows": rows, "table_GB": rows * 2 * d * 4 / 1e9,
+           "what": "rank 0's share of weak-scaled config 4 at world %d in one process: sources uniform over the %d-row [Q|Z] table, "
+                   "table filled locally, no collective" % (world, rows)}
+    checks = {}
+    if check:
+        # softmax normalisation: Z = 1, Rz = 0, no self term -> out = sqrt(deg) exactly, through every split-segment merge
+        Zsave = QZ[:, d:].clone() if rows * d * 4 < 40e9 else None
+        QZ[:, d:] = 1.0
+        R1 = RR.clone()
+        R1[:, d:] = 0.0
+        nb, _, _ = ops.rel_attn_split_fwd_raw(P, QZ, R1, av, g, slope, 1.0, -1, 0)
+        want = deg.float().sqrt().view(-1, 1)
+        checks["softmax_normalisation_max_err"] = float((nb - want).abs().max())
+        checks["softmax_normalisation_ok"] = bool(checks["softmax_normalisation_max_err"] <= 2e-4 * max(1.0, float(want.max())))
+        del nb, R1
+        QZ[:, d:] = Zsave
+        del Zsave
+    out, smax, sden = ops.rel_attn_split_fwd_raw(P, QZ, RR, av, g, slope, 0.5, nr, sg.self_off)
+    res["one_piece_fwd_ms"] = _ms(lambda: ops.rel_attn_split_fwd_raw(P, QZ, RR, av, g, slope, 0.5, nr, sg.self_off), n=5)
+    bw = lambda: ops.rel_attn_split_bwd_raw(P, QZ, RR, av, g, slope, 0.5, nr, sg.self_off, out, smax, sden, G)
+    res["one_call_bwd_ms"] = _ms(bw, n=3)
+    fb, bb = synth.fwd_algorithmic_bytes(n_loc, e_loc, d), synth.bwd_algorithmic_bytes(n_loc, e_loc, d)
+    res["fwd_frac_hbm"] = fb / (res["one_piece_fwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    res["bwd_frac_hbm"] = bb / (res["one_call_bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    dP1, dQZ1, dRR1, da1 = bw()
+    if check:
+        # conservation (pure edge op: no self term): sum_j dZ[j] = sum_i sqrt(deg_i) g_i, sum dRz = -sum dZ, sum dQ = sum dP = -sum dRq
+        o2, m2, l2 = ops.rel_attn_split_fwd_raw(P, QZ, RR, av, g, slope, 1.0, -1, 0)
+        dP, dQZ, dRR, _ = ops.rel_attn_split_bwd_raw(P, QZ, RR, av, g, slope, 1.0, -1, 0, o2, m2, l2, G)
+        sdP, sdQ, sdZ = dP.double().sum(0), dQZ[:, :d].double().sum(0), dQZ[:, d:].double().sum(0)
+        sdRq, sdRz = dRR[:, :d].double().sum(0), dRR[:, d:].double().sum(0)
+        want_dz = (deg.sqrt().view(-1, 1) * G.double()).sum(0)
+
+        def rel(x, y):
+            return float((x - y).abs().max() / max(float(y.abs().max()), float(x.abs().max()), 1e-30))
+        checks["conservation_rel_err"] = {"dZ_vs_sqrtdeg_g": rel(sdZ, want_dz), "dRz_vs_minus_dZ": rel(sdRz, -sdZ),
+                                          "dQ_vs_dP": rel(sdQ, sdP), "dRq_vs_minus_dP": rel(sdRq, -sdP)}
+        checks["conservation_ok"] = bool(max(checks["conservation_rel_err"].values()) <= 2e-4 + 1e-6 * e_loc ** 0.5)
+        del o2, m2, l2, dP, dQZ, dRR
+    # ---- (b) the slab-pipelined forward on the chunk-major table (the same values, re-laid: chunk c of every rank in one slice)
+    sgc = ShardedGraph(ei, et, bounds, 0, already_local=True, chunks=chunks)
+    del ei, et
+    cb, C = sgc.chunk_bounds, sgc.chunks
+    table = torch.empty(sgc.table_rows, 2 * d, device=device)
+    for c in range(C):
+        rc = int(cb[c + 1] - cb[c])
+        for ow in range(world):
+            table[world * int(cb[c]) + ow * rc: world * int(cb[c]) + (ow + 1) * rc] = QZ[ow * sgc.n_max + int(cb[c]): ow * sgc.n_max + int(cb[c + 1])]
+    table[world * sgc.n_max:] = QZ[:sgc.n_max]                          # rank 0's own rows once more (fused self loop of the merge)
+    dQZ1_own = dQZ1[:sgc.n_max].clone() if check else None
+    dQZ1_sum = dQZ1.double().sum(0) if check else None
+    del QZ, dQZ1
+    for c in range(C):
+        sgc.chunk_graph(c, device, nr + 1)
+    part_ms = [_ms(lambda c=c: _HipChunked.partial(P, table, RR, av, sgc, c, slope), n=3) for c in range(C)]
+    parts = [_HipChunked.partial(P, table, RR, av, sgc, c, slope) for c in range(C)]
+    zself = table[sgc.self_off:sgc.self_off + n_loc, d:]
+    rz = RR[-1, d:].contiguous()
+    merge = lambda: _HipChunked.merge(parts, n_loc, d, device, zself, rz, 0.5)
+    res["pipelined"] = {"chunks": C, "partial_ms": part_ms, "merge_ms": _ms(merge, n=3),
+                        "table_rows": sgc.table_rows, "table_GB": sgc.table_rows * 2 * d * 4 / 1e9}
+    res["pipelined"]["fwd_ms"] = float(sum(part_ms)) + res["pipelined"]["merge_ms"]
+    res["pipelined"]["extra_over_one_piece_ms"] = res["pipelined"]["fwd_ms"] - res["one_piece_fwd_ms"]
+    pre, pmax, pden = merge()
+    if check:
+        checks["pipelined_vs_one_piece_max_abs"] = float((pre - out).abs().max())
+        checks["pipelined_vs_one_piece_scale"] = float(out.abs().max())
+        checks["pipelined_ok"] = bool(checks["pipelined_vs_one_piece_max_abs"] <= 2e-5 * max(1.0, checks["pipelined_vs_one_piece_scale"]))
+    del parts
+    # ---- (c) the phased backward on the same table: begin() then pass B per slab (last slab = the own-rows copy)
+    slabs = [world * int(b) for b in cb] + [int(table.shape[0])]
+    gfull = sgc.rel_graph(device, nr + 1)
+    gfull.ensure_backward_views()
+
+    def phased():
+        bp = _HipChunked.backward_phased(P, table, RR, av, sgc, slope, pre, pmax, pden, G, slabs)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(C + 3)]
+        evs[0].record()
+        bp.begin()
+        evs[1].record()
+        for c in range(C + 1):
+            bp.slab(c)
+            evs[c + 2].record()
+        torch.cuda.synchronize()
+        return bp, [evs[i].elapsed_time(evs[i + 1]) for i in range(C + 2)]
+    phased()
+    runs = [phased() for _ in range(3)]
+    tms = np.median(np.array([t for _, t in runs]), axis=0)
+    bp = runs[-1][0]
+    res["phased_bwd"] = {"begin_ms": float(tms[0]), "slab_ms": [float(x) for x in tms[1:C + 1]], "own_rows_slab_ms": float(tms[C + 1]),
+                         "total_ms": float(tms.sum()), "pass_b_share": float(tms[1:].sum() / tms.sum()),
+                         "extra_over_one_call_ms": float(tms.sum()) - res["one_call_bwd_ms"]}
+    if check:
+        checks["phased_dP_equals_one_call"] = bool(torch.equal(bp.dP, dP1))
+        checks["phased_dRR_max_abs_diff"] = float((bp.dRR - dRR1).abs().max())
+        tot = bp.dQZ[:world * sgc.n_max].double().sum(0) + bp.dQZ[world * sgc.n_max:].double().sum(0)
+        checks["phased_dQZ_column_sums_rel_err"] = float((tot - dQZ1_sum).abs().max() / dQZ1_sum.abs().max())
+        checks["phased_ok"] = bool(checks["phased_dP_equals_one_call"] and checks["phased_dQZ_column_sums_rel_err"] <= 1e-6)
+        checks["ok"] = bool(all(v for k, v in checks.items() if k.endswith("_ok")))
+        res["checks"] = checks
+    res["max_memory_GB"] = torch.cuda.max_memory_allocated() / 1e9
+    del table, bp, runs, pre, out, P, G, dP1, dRR1
+    torch.cuda.empty_cache()
+    return res
+
+
 XGMI_LINK_GBS, XGMI_EFF = 153.0, 0.8     # one xGMI link per peer pair (MI355X: 7 links x ~153 GB/s per GPU), sustained fraction assumed
 PASS_B_SHARE = 0.4                       # assumed share of the aggregation backward that is pass B (by source: what a reduce-scatter of
                                          # d[Q|Z] slabs can hide behind); ja-size kernel times: A 28 us, B || C 27 us, merges 11 us
@@ -299,3 +450,28 @@ def scaling_model(step_ms, agg_fwd_ms, agg_bwd_ms, n_layers, n_glob, e_glob, d, 
                                   "the kernels; 'forward' = the slab-pipelined all-gather (built: --pipeline-chunks), 'forward+backward' = "
                                   "slab-wise reduce-scatters behind pass B with pass B = %.1f of the aggregation backward" % PASS_B_SHARE)
     return out
+
+
+def main():
+    """python bench_dist.py --rehearse-world 8 [--pipeline-chunks 4] [--synth-scale 1.0] [--dim 300]: the one-GPU rehearsal of a
+    rank's world-W share alone (one JSON line; bench.py's default run carries the same object as sharded.rehearsal_world8)."""
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rehearse-world", type=int, default=8)
+    ap.add_argument("--pipeline-chunks", type=int, default=4)
+    ap.add_argument("--synth-scale", type=float, default=1.0)
+    ap.add_argument("--dim", type=int, default=300)
+    ap.add_argument("--no-check", action="store_true")
+    a = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_dist.py needs an MI355X (no CPU fallback for the product path)")
+    res = rehearse_world(a, torch.device("cuda", 0), a.rehearse_world, a.pipeline_chunks, check=not a.no_check)
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    main()

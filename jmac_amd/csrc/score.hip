@@ -390,6 +390,23 @@ constexpr int SG_PLANE = SG_T * 4 + 8;      // floats per (sub-slab q, k-half h)
 constexpr int SG_IMG = 4 * SG_PLANE;        // one operand slab: planes (q, h) = (0,0) (0,1) (1,0) (1,1)
 constexpr int SG_SUPER = 8;                 // super-tile of 8x8 tiles per XCD visit (L2: 2 x 1.2 MB at d=300)
 constexpr int SG_FL_CAP = 256;              // FILTER epilogue: passing elements a wave collects before it claims their slots
+// Ablation builds (tools/r6_simgemm_ablation.sh; the product is built with 0): where does the matrix pipe's idle time go?
+//   bit 0  the C tile is not stored (a store behind a never-true data-dependent test keeps the accumulators live)
+//   bit 1  no global loads after a block's first slab (the staging registers are re-used: LDS traffic and barriers stay)
+//   bit 2  no LDS stores, fragment reads or barriers inside the K loop: the MFMA chain alone (implies nothing about results)
+#ifndef JMAC_SG_ABLATE
+#define JMAC_SG_ABLATE 0
+#endif
+#ifndef JMAC_SG_PRIO
+#define JMAC_SG_PRIO 0        // experiment: wave priority rises with the tile's progress (s_setprio): resident blocks drift out of phase
+#endif
+#ifndef JMAC_SG_NT
+#define JMAC_SG_NT 0          // experiment: non-temporal C stores (the 576 MB result does not displace the operand panels in L2)
+#endif
+#ifndef JMAC_SG_OCC
+#define JMAC_SG_OCC 3         // resident blocks per CU the register budget is set for
+#endif
+constexpr bool SG_NO_STORE = (JMAC_SG_ABLATE & 1) != 0, SG_NO_LOAD = (JMAC_SG_ABLATE & 2) != 0, SG_MFMA_ONLY = (JMAC_SG_ABLATE & 4) != 0;
 
 // FILTER = true: the scores are not stored.  An element that reaches its row's threshold tau (a lower bound of the row's k-th
 // largest score, taken from a column sample: jmac_sim_topk_f32) is appended to the row's candidate list instead -- the running
@@ -405,7 +422,7 @@ struct SimFilter {
 };
 
 template <bool FILTER>
-__global__ __launch_bounds__(kBlock, 3) void sim_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
+__global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
                                                           int64_t ldb, int M, int N, int d, float* __restrict__ C, int64_t ldc,
                                                           int tiles_m, int tiles_n, int super_order, int n_ids, SimFilter flt) {
     // LDS image of one operand slab (16 k): plane (q, h) holds, for every tile row, the 4 floats k = 8q + 4h .. +3.
@@ -507,37 +524,47 @@ __global__ __launch_bounds__(kBlock, 3) void sim_gemm_kernel(const float* __rest
         // slab kt+1; the q=1 MFMAs cover the first fragment reads of slab kt+1 and the global loads of slab kt+2.
         sstore(As[0], ra, 0);
         sstore(Bs[0], rb, 0);
-        if (nk > 1) {
+        if (nk > 1 && !SG_NO_LOAD) {
             gload(A, lda, m0, M, SG_K, ra);
             gload(Bm, ldb, n0, N, SG_K, rb);
         }
         __syncthreads();
         frags(0, 0, af0, bf0);
+        if (SG_MFMA_ONLY) frags(0, 1, af1, bf1);
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            frags(cur, 1, af1, bf1);
+#if JMAC_SG_PRIO
+            if (kt == nk / 4) __builtin_amdgcn_s_setprio(1);
+            else if (kt == nk / 2) __builtin_amdgcn_s_setprio(2);
+            else if (kt == (3 * nk) / 4) __builtin_amdgcn_s_setprio(3);
+#endif
+            if (!SG_MFMA_ONLY) frags(cur, 1, af1, bf1);
             __builtin_amdgcn_sched_barrier(0);
             mfma16(af0, bf0);
             __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < nk) {
+            if (kt + 1 < nk && !SG_MFMA_ONLY) {
                 sstore(As[cur ^ 1], ra, (kt + 1) * SG_K);
                 sstore(Bs[cur ^ 1], rb, (kt + 1) * SG_K);
-                if (kt + 2 < nk) {
+                if (kt + 2 < nk && !SG_NO_LOAD) {
                     gload(A, lda, m0, M, (kt + 2) * SG_K, ra);
                     gload(Bm, ldb, n0, N, (kt + 2) * SG_K, rb);
                 }
             }
-            __syncthreads();
-            if (kt + 1 < nk) frags(cur ^ 1, 0, af0, bf0);
+            if (!SG_MFMA_ONLY) __syncthreads();
+            if (kt + 1 < nk && !SG_MFMA_ONLY) frags(cur ^ 1, 0, af0, bf0);
             __builtin_amdgcn_sched_barrier(0);
             mfma16(af1, bf1);
             __builtin_amdgcn_sched_barrier(0);
         }
+#if JMAC_SG_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        if (SG_MFMA_ONLY) __syncthreads();               // (the next tile's first sstore must not race this tile's first fragment reads)
         // the next tile's first slab is requested BEFORE this tile's 64 KB of results are stored: the stores and the
         // loads overlap, and no wave reads LDS any more (the last fragment reads precede the last barrier)
         int ntm = 0, ntn = 0;
         const int nid = next_tile(id + gridDim.x, ntm, ntn);
-        if (nid < n_ids) {
+        if (nid < n_ids && !SG_NO_LOAD) {
             gload(A, lda, ntm * SG_T, M, 0, ra);
             gload(Bm, ldb, ntn * SG_T, N, 0, rb);
         }
@@ -598,9 +625,19 @@ __global__ __launch_bounds__(kBlock, 3) void sim_gemm_kernel(const float* __rest
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float* cbase = C + (int64_t)(m0 + wm * 64 + i * 32 + 4 * h) * ldc + (n0 + wn * 64 + j * 32 + r);
-                if (full) {
+                if (SG_NO_STORE) {                         // ablation: nothing leaves the CU, the accumulators stay live
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) cbase[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg];
+                    for (int reg = 0; reg < 16; ++reg)
+                        if (acc[i][j][reg] == 123456.789f) cbase[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg];
+                } else if (full) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+#if JMAC_SG_NT
+                        __builtin_nontemporal_store(acc[i][j][reg], cbase + (int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc);
+#else
+                        cbase[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg];
+#endif
+                    }
                 } else {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {

@@ -5,7 +5,9 @@ container ("the same restatement must be cross-timed again
 Same step as bench.py's JaWorkload: JMAC.forward_base (num_gcn_layer=2 -> 3 RelationAwareLayer calls) on the DBP-5L
 ``ja``-shaped synthetic graph + the completion-style loss on a 26 000-triple batch + the alignment-style loss +
 backward, dropout off, CPU, N threads.  Prints seconds per step for the reference (src/jmac_model.py, torch_scatter
-stand-in of oracle/_shim) and for oracle/jmac_oracle.py, and their ratio.  Not a test; the numbers are quoted in DESIGN.md.
+stand-in of oracle/_shim) and for oracle/jmac_oracle.py, and their ratio.  Not a test: tools/r6_crosstime.sh runs it five times
+and commits the lines (profiles/r6_crosstime.txt) and the median ratio (profiles/r6_crosstime.json, read by bench.py as
+cpu_baseline.port_vs_reference_cost_ratio; quoted in DESIGN.md section 2).
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/crosstime_reference.py [dim] [threads]
 """
