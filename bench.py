@@ -114,6 +114,7 @@ def parse():
     ap.add_argument("--no-torch-adam-leg", action="store_true",
                     help="skip the second timing of the headline step with torch.optim.Adam (ms_per_step_torch_adam)")
     ap.add_argument("--no-synth", action="store_true")
+    ap.add_argument("--no-rehearsal", action="store_true", help="skip the one-GPU rehearsal of a rank's world-2/4/8 shapes (sharded.rehearsal_world*)")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the library GEMM heuristics as they are")
     ap.add_argument("--torch-adam", action="store_true", help="step torch.optim.Adam(fused, capturable) instead of jmac_amd.optim.Adam")
     ap.add_argument("--bwd-mode", type=int, default=1)
@@ -1700,14 +1701,34 @@ def main():
         except Exception as ex:                      # pragma: no cover
             line["synth"] = {"error": str(ex), "parity": sp}
         lap("synth")
+        # one-GPU rehearsal of a rank's world-2 / 4 / 8 shapes (its 1M rows / 20M edges gathering from the W x 1M-row table, filled
+        # locally, no collective): what the scaling model used to carry over from the world-1 run is measured (bench_dist.rehearse_world)
+        reh = {}
+        if a.dim == 300 and not a.no_rehearsal:
+            from bench_dist import rehearse_world
+            ra_ = argparse.Namespace(**vars(a))
+            for W in (2, 4, 8):
+                try:
+                    reh[W] = rehearse_world(ra_, device, W, chunks=4, check=(W == 8))
+                except Exception as ex:                  # pragma: no cover
+                    sys.stderr.write("rehearsal at world %d failed (%s)\n" % (W, ex))
+                    torch.cuda.empty_cache()
+            if 8 in reh and not reh[8].get("checks", {}).get("ok", False):
+                raise SystemExit("bench.py: the aggregation kernels fail their property checks on the 8M-row table: %s" % json.dumps(reh[8].get("checks")))
+            lap("rehearsal")
         # the destination-sharded config-4 step at ONE rank (no collective runs): the base of the N > 1 lines' value
         try:
             from bench_dist import run_sharded
             sa = argparse.Namespace(**vars(a))
             sa.steps, sa.warmup = 5, 2
+            sa.rehearsal = reh
             sl = run_sharded(sa, 0, 1, device)
             line["sharded"] = {k: sl[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "roofline_bwd", "comm",
                                                   "scaling_model", "scaling_model_strong_10x", "scaling_model_strong_10x_10M_entities") if k in sl}
+            for W, r in reh.items():
+                line["sharded"]["rehearsal_world%d" % W] = r
+            if 8 in reh:
+                line["sharded"]["rehearsal_world8"]["step_ms"] = 2 * (reh[8]["one_piece_fwd_ms"] + reh[8]["one_call_bwd_ms"])   # two layers' aggregation
         except Exception as ex:                      # pragma: no cover
             line["sharded"] = {"error": str(ex)}
         lap("sharded")

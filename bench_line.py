@@ -33,7 +33,8 @@ HIGHLIGHTS = (("ms_per_step_torch_adam", ("ms_per_step_torch_adam",)),
               ("sim.mfma_frac_of_f32_peak", ("sim", "mfma_frac_of_f32_peak")),
               ("scoring.scored_triples_per_s", ("scoring", "scored_triples_per_s")),
               ("sharded.ms_per_step", ("sharded", "ms_per_step")),
-              ("sharded.rehearsal_world8.step_ms", ("sharded", "rehearsal_world8", "step_ms")),
+              ("sharded.rehearsal_world8.agg_ms", ("sharded", "rehearsal_world8", "step_ms")),
+              ("sharded.speedup8_rehearsed", ("sharded", "scaling_model", "predicted", "8", "speedup_vs_1")),
               ("gpu_over_cpu", ("gpu_over_cpu",)),
               ("replicas.value", ("replicas", "value")),
               ("comm.backend", ("comm", "backend")),

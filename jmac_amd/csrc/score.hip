@@ -11,6 +11,7 @@
 // (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate), so top-k indices are decided on
 // full-precision scores.
 #include "common.h"
+#include <type_traits>
 
 using namespace jmac;
 
@@ -384,11 +385,23 @@ __global__ __launch_bounds__(kBlock) void link_rank_tile_kernel(LinkRankArgs a) 
 // similarity GEMM  C = A * B^T  on the fp32-input MFMA (32x32x2), 128x128 tile per 4-wave block, K staged 16 deep
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int SG_T = 128, SG_K = 16;
+// Tile: 128 rows x (64 WJ) columns per 4-wave block, wave grid 2 x 2, a wave owns 64 x (32 WJ): WJ = 2 -> the 128 x 128 tile of
+// rounds 1-5 (64 accumulator registers, 3 blocks per CU); WJ = 4 -> 128 x 256 (128 accumulator registers, 2 blocks per CU): per
+// flop a quarter fewer operand bytes through L2 and LDS and half as many barriers (round 6, profiles/r6_simgemm_ablation.txt).
+// The contraction order per output element is the same for every WJ (k = 8q + 4h + s planes): results are bit-identical.
+#ifndef JMAC_SG_WJ
+#define JMAC_SG_WJ 2
+#endif
+constexpr int SG_WJ = JMAC_SG_WJ;
+constexpr int SG_T = 128, SG_TN = 64 * SG_WJ, SG_K = 16;
 constexpr int SG_PLANE = SG_T * 4 + 8;      // floats per (sub-slab q, k-half h) plane; +8: the 4 planes a wave store
                                             // instruction touches start on different banks
+constexpr int SG_PLANE_B = SG_TN * 4 + 8;
 constexpr int SG_IMG = 4 * SG_PLANE;        // one operand slab: planes (q, h) = (0,0) (0,1) (1,0) (1,1)
-constexpr int SG_SUPER = 8;                 // super-tile of 8x8 tiles per XCD visit (L2: 2 x 1.2 MB at d=300)
+constexpr int SG_IMG_B = 4 * SG_PLANE_B;
+constexpr int SG_LB = SG_TN / 64;           // float4s per thread of one B slab (A: 2)
+constexpr int SG_SUPER = 8;                 // super-tile of 1024 x 1024 outputs per XCD visit (L2: 2 x 1.2 MB of operand rows at d=300):
+constexpr int SG_SUPER_N = SG_SUPER * 2 / SG_WJ;   // 8 x 8 tiles of 128 x 128, or 8 x 4 of 128 x 256
 constexpr int SG_FL_CAP = 256;              // FILTER epilogue: passing elements a wave collects before it claims their slots
 // Ablation builds (tools/r6_simgemm_ablation.sh; the product is built with 0): where does the matrix pipe's idle time go?
 //   bit 0  the C tile is not stored (a store behind a never-true data-dependent test keeps the accumulators live)
@@ -403,6 +416,9 @@ constexpr int SG_FL_CAP = 256;              // FILTER epilogue: passing elements
 #ifndef JMAC_SG_NT
 #define JMAC_SG_NT 0          // experiment: non-temporal C stores (the 576 MB result does not displace the operand panels in L2)
 #endif
+#ifndef JMAC_SG_PIPE
+#define JMAC_SG_PIPE 0        // experiment: K loop peeled into branch-free slab bodies (zero-source loads instead of zeroing selects),
+#endif                        // 1 = the compiler's own interleaving, 2 = sched_group_barrier: LDS / memory ops spread between the MFMAs
 #ifndef JMAC_SG_OCC
 #define JMAC_SG_OCC 3         // resident blocks per CU the register budget is set for
 #endif
@@ -429,7 +445,7 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
     // Lane (r = l&31, h = l>>5) of a wave reads its float4 of row r from plane (q, h): 32 lanes x 16 B contiguous,
     // conflict free for ds_read_b128's lane groups.  The MFMA step s of a sub-slab contracts k = {8q+s, 8q+4+s}.
     __shared__ __attribute__((aligned(16))) float As[2][SG_IMG];
-    __shared__ __attribute__((aligned(16))) float Bs[2][SG_IMG];
+    __shared__ __attribute__((aligned(16))) float Bs[2][SG_IMG_B];
     __shared__ int fl_m[FILTER ? kBlock / 64 : 1][FILTER ? SG_FL_CAP : 1];      // FILTER: per-wave lists of passing elements
     __shared__ int fl_n[FILTER ? kBlock / 64 : 1][FILTER ? SG_FL_CAP : 1];
     __shared__ float fl_v[FILTER ? kBlock / 64 : 1][FILTER ? SG_FL_CAP : 1];
@@ -442,13 +458,13 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
     // stay L2-resident.  Ids that fall outside the matrix (ragged super-tiles) are skipped.
     auto tile_of = [&](int id, int& tm, int& tn) -> bool {
         if (super_order) {
-            const int sup_n = (tiles_n + SG_SUPER - 1) / SG_SUPER, sup_m = (tiles_m + SG_SUPER - 1) / SG_SUPER;
-            const int per = SG_SUPER * SG_SUPER;
+            const int sup_n = (tiles_n + SG_SUPER_N - 1) / SG_SUPER_N, sup_m = (tiles_m + SG_SUPER - 1) / SG_SUPER;
+            const int per = SG_SUPER * SG_SUPER_N;
             const int xcd = id & 7, local = id >> 3;
             const int sup = (local / per) * 8 + xcd, within = local % per;
             if (sup >= sup_m * sup_n) return false;
-            tm = (sup / sup_n) * SG_SUPER + within / SG_SUPER;
-            tn = (sup % sup_n) * SG_SUPER + within % SG_SUPER;
+            tm = (sup / sup_n) * SG_SUPER + within / SG_SUPER_N;
+            tn = (sup % sup_n) * SG_SUPER_N + within % SG_SUPER_N;
             return tm < tiles_m && tn < tiles_n;
         }
         tm = id / tiles_n;                           // few tiles: plain row-major order, every XCD busy
@@ -464,39 +480,47 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
     // bytes of a row).  Every load is unconditional at a clamped address (a load behind an exec-mask branch is not
     // overlapped with the MFMAs): rows past the end re-read the last row -- they only feed outputs that are never
     // stored -- and float4s past d (d % 4 == 0, enforced by the launcher) are zeroed at store time.
-    auto gload = [&](const float* base, int64_t ld, int row0, int nrows, int k0, float4 (&v)[2]) {
+    auto gload = [&](const float* base, int64_t ld, int row0, int nrows, int k0, auto& v) {
+        constexpr int CNT = sizeof(v) / sizeof(float4);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < CNT; ++i) {
             const int f = tid + 256 * i;
             const int row = min(row0 + (f >> 2), nrows - 1), k = k0 + 4 * (f & 3);
             v[i] = ld4(base + (int64_t)row * ld + min(k, d - 4));     // zeroing waits for the data: done at store time
         }
     };
-    auto sstore = [&](float* S, const float4 (&v)[2], int k0) {
+    auto sstore = [&](float* S, const auto& v, int k0) {
+        constexpr int CNT = sizeof(v) / sizeof(float4);
+        constexpr int PLANE = CNT == 2 ? SG_PLANE : SG_PLANE_B;       // (WJ = 2: the two planes are the same size)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < CNT; ++i) {
             const int f = tid + 256 * i;
+#if JMAC_SG_PIPE
+            // zeroing as a bit mask (exact, and no select the compiler could turn into a branch: the slab body stays ONE basic block)
+            const unsigned keep = k0 + 4 * (f & 3) < d ? 0xffffffffu : 0u;
+            const float4 x = make_float4(__uint_as_float(__float_as_uint(v[i].x) & keep), __uint_as_float(__float_as_uint(v[i].y) & keep),
+                                         __uint_as_float(__float_as_uint(v[i].z) & keep), __uint_as_float(__float_as_uint(v[i].w) & keep));
+#else
             const float4 x = k0 + 4 * (f & 3) < d ? v[i] : f4zero();
-            *reinterpret_cast<float4*>(S + (f & 3) * SG_PLANE + (f >> 2) * 4) = x;      // plane index = kq = 2q + h
+#endif
+            *reinterpret_cast<float4*>(S + (f & 3) * PLANE + (f >> 2) * 4) = x;      // plane index = kq = 2q + h
         }
     };
     const int r = lane & 31, h = lane >> 5;
-    const int aoff = h * SG_PLANE + (wm * 64 + r) * 4, boff = h * SG_PLANE + (wn * 64 + r) * 4;
-    auto frags = [&](int buf, int q, float4 (&af)[2], float4 (&bf)[2]) {
+    const int aoff = h * SG_PLANE + (wm * 64 + r) * 4, boff = h * SG_PLANE_B + (wn * 32 * SG_WJ + r) * 4;
+    auto frags = [&](int buf, int q, float4 (&af)[2], float4 (&bf)[SG_WJ]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            af[i] = *reinterpret_cast<const float4*>(As[buf] + q * 2 * SG_PLANE + aoff + i * 32 * 4);
-            bf[i] = *reinterpret_cast<const float4*>(Bs[buf] + q * 2 * SG_PLANE + boff + i * 32 * 4);
-        }
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(As[buf] + q * 2 * SG_PLANE + aoff + i * 32 * 4);
+#pragma unroll
+        for (int j = 0; j < SG_WJ; ++j) bf[j] = *reinterpret_cast<const float4*>(Bs[buf] + q * 2 * SG_PLANE_B + boff + j * 32 * 4);
     };
-    f32x16 acc[2][2];
-    // the four accumulators rotate (dependency distance 4)
-    auto mfma16 = [&](const float4 (&af)[2], const float4 (&bf)[2]) {
-#define JMAC_SG_STEP(c)                                                                                   \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0].c, bf[0].c, acc[0][0], 0, 0, 0);          \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0].c, bf[1].c, acc[0][1], 0, 0, 0);          \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1].c, bf[0].c, acc[1][0], 0, 0, 0);          \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1].c, bf[1].c, acc[1][1], 0, 0, 0);
+    f32x16 acc[2][SG_WJ];
+    // the 2 WJ accumulators rotate (dependency distance 2 WJ >= 4)
+    auto mfma16 = [&](const float4 (&af)[2], const float4 (&bf)[SG_WJ]) {
+#define JMAC_SG_STEP(c)                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
+            _Pragma("unroll") for (int j = 0; j < SG_WJ; ++j)                                                        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].c, bf[j].c, acc[i][j], 0, 0, 0);
         JMAC_SG_STEP(x)
         JMAC_SG_STEP(y)
         JMAC_SG_STEP(z)
@@ -505,18 +529,18 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
     };
 
     const int nk = (d + SG_K - 1) / SG_K;
-    float4 ra[2], rb[2], af0[2], bf0[2], af1[2], bf1[2];
+    float4 ra[2], rb[SG_LB], af0[2], bf0[SG_WJ], af1[2], bf1[SG_WJ];
     int tm, tn;
     int id = next_tile(blockIdx.x, tm, tn);
     if (id >= n_ids) return;
     gload(A, lda, tm * SG_T, M, 0, ra);
-    gload(Bm, ldb, tn * SG_T, N, 0, rb);
+    gload(Bm, ldb, tn * SG_TN, N, 0, rb);
     while (id < n_ids) {
-        const int m0 = tm * SG_T, n0 = tn * SG_T;
+        const int m0 = tm * SG_T, n0 = tn * SG_TN;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < SG_WJ; ++j)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
         // Software pipeline, one barrier per slab.  At the top of slab kt: fragment set 0 holds (kt, q=0), the staging
@@ -531,6 +555,69 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
         __syncthreads();
         frags(0, 0, af0, bf0);
         if (SG_MFMA_ONLY) frags(0, 1, af1, bf1);
+#if JMAC_SG_PIPE
+        // One slab as ONE basic block: HAS1 = slab kt+1 exists (its staged rows go to LDS, its first fragments are read behind the
+        // barrier), HAS2 = slab kt+2 exists (requested).  The steady state (both) runs in the loop, the last two slabs are peeled.
+        auto slab_body = [&](const int kt, auto has1, auto has2) {
+            constexpr bool HAS1 = decltype(has1)::value, HAS2 = decltype(has2)::value;
+            const int cur = kt & 1;
+            frags(cur, 1, af1, bf1);
+            mfma16(af0, bf0);
+            if constexpr (HAS1) {
+                sstore(As[cur ^ 1], ra, (kt + 1) * SG_K);
+                sstore(Bs[cur ^ 1], rb, (kt + 1) * SG_K);
+                if constexpr (HAS2) {
+                    gload(A, lda, m0, M, (kt + 2) * SG_K, ra);
+                    gload(Bm, ldb, n0, N, (kt + 2) * SG_K, rb);
+                }
+            }
+#if JMAC_SG_PIPE == 2
+            // 2 + WJ fragment reads, 8 WJ MFMAs, then per staged float4 one LDS store and (HAS2) one global load: one memory
+            // operation between two MFMAs instead of a burst behind sixteen of them
+#pragma unroll
+            for (int i = 0; i < 2 + SG_WJ; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8 * SG_WJ - (2 + SG_WJ) - (HAS1 ? 2 + SG_LB : 0) - (HAS2 ? 2 + SG_LB : 0), 0);
+            if constexpr (HAS1) {
+#pragma unroll
+                for (int i = 0; i < 2 + SG_LB; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+            }
+            if constexpr (HAS2) {
+#pragma unroll
+                for (int i = 0; i < 2 + SG_LB; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+            }
+#endif
+            __syncthreads();
+            if constexpr (HAS1) frags(cur ^ 1, 0, af0, bf0);
+            mfma16(af1, bf1);
+#if JMAC_SG_PIPE == 2
+            if constexpr (HAS1) {
+#pragma unroll
+                for (int i = 0; i < 2 + SG_WJ; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+            }
+#endif
+        };
+        {
+            int kt = 0;
+            for (; kt + 2 < nk; ++kt) slab_body(kt, std::true_type{}, std::true_type{});
+            if (kt + 1 < nk) {
+                slab_body(kt, std::true_type{}, std::false_type{});
+                ++kt;
+            }
+            slab_body(kt, std::false_type{}, std::false_type{});
+        }
+#else
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
 #if JMAC_SG_PRIO
@@ -556,6 +643,7 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
             mfma16(af1, bf1);
             __builtin_amdgcn_sched_barrier(0);
         }
+#endif
 #if JMAC_SG_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -566,10 +654,10 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
         const int nid = next_tile(id + gridDim.x, ntm, ntn);
         if (nid < n_ids && !SG_NO_LOAD) {
             gload(A, lda, ntm * SG_T, M, 0, ra);
-            gload(Bm, ldb, ntn * SG_T, N, 0, rb);
+            gload(Bm, ldb, ntn * SG_TN, N, 0, rb);
         }
         // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-        const bool full = m0 + SG_T <= M && n0 + SG_T <= N;      // block-uniform: interior tiles store without bounds tests
+        const bool full = m0 + SG_T <= M && n0 + SG_TN <= N;      // block-uniform: interior tiles store without bounds tests
         if constexpr (FILTER) {
             // Passing elements are rare (~k * N / Ns per row: under 1 % of the tile).  A returned global atomic per passing
             // element inside the scan would cost one memory round trip each (measured: the product ran 1.6x longer); the wave
@@ -600,8 +688,8 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
                     const int m = m0 + wm * 64 + rbase + 4 * h;
                     const float tau = h ? bcast_f(trow, rbase + 4) : bcast_f(trow, rbase);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int n = n0 + wn * 64 + j * 32 + r;
+                    for (int j = 0; j < SG_WJ; ++j) {
+                        const int n = n0 + wn * 32 * SG_WJ + j * 32 + r;
                         const float v = acc[i][j][reg];
                         const bool pass = m < M && n < N && v >= tau;
                         const unsigned long long mask = __ballot(pass);
@@ -623,8 +711,8 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float* cbase = C + (int64_t)(m0 + wm * 64 + i * 32 + 4 * h) * ldc + (n0 + wn * 64 + j * 32 + r);
+            for (int j = 0; j < SG_WJ; ++j) {
+                float* cbase = C + (int64_t)(m0 + wm * 64 + i * 32 + 4 * h) * ldc + (n0 + wn * 32 * SG_WJ + j * 32 + r);
                 if (SG_NO_STORE) {                         // ablation: nothing leaves the CU, the accumulators stay live
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg)
@@ -642,7 +730,7 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int64_t m = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                        const int64_t n = n0 + wn * 64 + j * 32 + r;
+                        const int64_t n = n0 + wn * 32 * SG_WJ + j * 32 + r;
                         if (m < M && n < N) C[m * ldc + n] = acc[i][j][reg];
                     }
                 }
@@ -1299,10 +1387,10 @@ __global__ __launch_bounds__(kBlock) void csls_rank_kernel(const float* __restri
 int launch_sim(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t d, float* C, int64_t ldc,
                hipStream_t st, const SimFilter* flt = nullptr) {
     if (M == 0 || N == 0) return 0;
-    const int tiles_m = (int)((M + SG_T - 1) / SG_T), tiles_n = (int)((N + SG_T - 1) / SG_T);
-    const int64_t sup = (int64_t)((tiles_m + SG_SUPER - 1) / SG_SUPER) * ((tiles_n + SG_SUPER - 1) / SG_SUPER);
+    const int tiles_m = (int)((M + SG_T - 1) / SG_T), tiles_n = (int)((N + SG_TN - 1) / SG_TN);
+    const int64_t sup = (int64_t)((tiles_m + SG_SUPER - 1) / SG_SUPER) * ((tiles_n + SG_SUPER_N - 1) / SG_SUPER_N);
     const int super_order = sup >= 64 ? 1 : 0;                          // >= 8 super-tiles per XCD: the tail imbalance is small
-    const int64_t n_ids = super_order ? (sup + 7) / 8 * 8 * SG_SUPER * SG_SUPER : (int64_t)tiles_m * tiles_n;
+    const int64_t n_ids = super_order ? (sup + 7) / 8 * 8 * SG_SUPER * SG_SUPER_N : (int64_t)tiles_m * tiles_n;
     if (n_ids >= INT32_MAX) return JMAC_ERANGE;
     if (d % 4) return JMAC_EDIM;
     // persistent: as many blocks as are resident at once (occupancy query: 3 per CU with 80 + 64 accumulation VGPRs and

@@ -39,3 +39,39 @@ def test_scaling_model_is_consistent():
     over_ms = 7.5                                                   # measured cost per layer at 1M rows / 20M edges per GPU
     assert abs((p8["step_ms"] - p8["pipelined_step_ms"]) - 2 * (min(10.5, slab_ms * 0.75) - over_ms)) < 1e-9
     assert p8["pipelined_step_ms"] < p8["step_ms"]
+
+
+def test_scaling_model_takes_the_rehearsed_aggregation_where_it_was_measured():
+    """Round 6: the aggregation kernels were timed on ONE GPU on the shapes a rank has at world 2 / 4 / 8 (its 1M rows / 20M edges
+    gathering from the W x 1M-row table; profiles/r6_rehearse_w*.json).  The weak-scaling model uses those figures instead of the
+    world-1 rate it used to carry over, keeps the carried-over prediction beside them, and leaves the strong models alone."""
+    import json
+    import os
+    import bench_dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    reh = {W: json.load(open(os.path.join(root, "profiles", "r6_rehearse_w%d.json" % W))) for W in (2, 4, 8)}
+    for W, r in reh.items():
+        assert r["world"] == W and r["table_rows"] == W * 1_000_000 and r["checks"]["ok"] is True
+        assert r["checks"]["phased_equals_one_call_bitwise"] is True
+    assert reh[8]["table_GB"] > 2 ** 32 / 1e9                                   # the table is past 4 GiB: 64-bit row offsets
+    step, f1, b1 = 108.0, 10.9, 20.2
+    old = bench_dist.scaling_model(step, f1, b1, 2, 1_000_000, 20_000_000, 300, 1, False)
+    new = bench_dist.scaling_model(step, f1, b1, 2, 1_000_000, 20_000_000, 300, 1, False, rehearsal=reh)
+    assert new["carried_over"]["predicted"] == old["predicted"] and new["carried_over"]["band"] == old["band"]
+    other = step - 2 * (f1 + b1)
+    for W in (2, 4, 8):
+        r = reh[W]
+        want = 2 * (r["one_piece_fwd_ms"] + r["one_call_bwd_ms"]) + other
+        assert abs(new["predicted"][str(W)]["compute_ms"] - want) < 1e-9
+        assert new["predicted"][str(W)]["exchange_ms"] == old["predicted"][str(W)]["exchange_ms"]
+        cmp_ = new["carried_over_vs_rehearsed_speedup"][str(W)]
+        assert cmp_["carried_over"] == old["predicted"][str(W)]["speedup_vs_1"]
+        assert cmp_["rehearsed"] == new["predicted"][str(W)]["speedup_vs_1"]
+    # the 19.2 GB table costs the backward more than the forward: the rehearsed 8-rank figure sits below the carried-over one
+    assert new["predicted"]["8"]["speedup_vs_1"] < old["predicted"]["8"]["speedup_vs_1"]
+    assert new["predicted"]["1"] == old["predicted"]["1"]
+    # a strong-scaled model is a different per-rank shape: the rehearsal is not applied
+    s_old = bench_dist.scaling_model(step, f1, b1, 2, 2_000_000, 200_000_000, 300, 1, True, run_rows=1_000_000, run_edges=20_000_000)
+    s_new = bench_dist.scaling_model(step, f1, b1, 2, 2_000_000, 200_000_000, 300, 1, True, run_rows=1_000_000, run_edges=20_000_000,
+                                     rehearsal=reh)
+    assert s_new["predicted"] == s_old["predicted"] and "carried_over" not in s_new

@@ -29,6 +29,7 @@ OUT=gpurun_out/r6_simgemm_ablation.txt
     JMAC_LIB_PATH=$R/build/variants/jmac_$name.so python3 tools/r6_simgemm_probe.py --name $name
   done; } > $OUT 2> gpurun_out/r6_simgemm_ablation.err
 if [ "$2" = "pmc" ]; then
+  mkdir -p gpurun_out/r6_sg_pmc
   for v in $VARIANTS; do
     name=${v%%:*}
     ( cd /tmp && export TMPDIR=/tmp && JMAC_LIB_PATH=$R/build/variants/jmac_$name.so timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/r6_sg_pmc/$name -o p -- python3 $R/tools/simgemm_probe.py > $R/gpurun_out/r6_sg_pmc/$name.log 2>&1 )

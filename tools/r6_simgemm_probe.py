@@ -46,7 +46,7 @@ for nm, M, N in SHAPES:
     c = torch.empty(M, N, device="cuda")
     t = ms(lambda: scoring.sim_matrix(a, b, out=c))
     out[nm] = {"ms": round(t, 4), "tflops": round(2.0 * M * N * d / (t * 1e-3) / 1e12, 2)}
-    if x.name in ("base", "prio", "nt", "prio_nt", "occ2") or x.name.startswith("ok_"):     # result-preserving builds: check it
+    if not any(t in x.name for t in ("nostore", "noload", "mfma_only")):     # result-preserving builds: check it
         ref = torch.mm(a[:256].double(), b[:512].double().t())
         out[nm]["max_abs_err_vs_f64"] = float((c[:256, :512].double() - ref).abs().max())
 print(json.dumps(out), flush=True)
