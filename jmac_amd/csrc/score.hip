@@ -385,23 +385,25 @@ __global__ __launch_bounds__(kBlock) void link_rank_tile_kernel(LinkRankArgs a) 
 // similarity GEMM  C = A * B^T  on the fp32-input MFMA (32x32x2), 128x128 tile per 4-wave block, K staged 16 deep
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-// Tile: 128 rows x (64 WJ) columns per 4-wave block, wave grid 2 x 2, a wave owns 64 x (32 WJ): WJ = 2 -> the 128 x 128 tile of
-// rounds 1-5 (64 accumulator registers, 3 blocks per CU); WJ = 4 -> 128 x 256 (128 accumulator registers, 2 blocks per CU): per
-// flop a quarter fewer operand bytes through L2 and LDS and half as many barriers (round 6, profiles/r6_simgemm_ablation.txt).
-// The contraction order per output element is the same for every WJ (k = 8q + 4h + s planes): results are bit-identical.
-#ifndef JMAC_SG_WJ
-#define JMAC_SG_WJ 2
-#endif
-constexpr int SG_WJ = JMAC_SG_WJ;
-constexpr int SG_T = 128, SG_TN = 64 * SG_WJ, SG_K = 16;
+// Tile: 128 rows x (64 WJ) columns per 4-wave block, wave grid 2 x 2, a wave owns 64 x (32 WJ).  WJ = 2: the 128 x 128 tile of
+// rounds 1-5 (64 accumulator registers, 3 blocks per CU); WJ = 4: 128 x 256 (128 accumulator registers, 2 blocks per CU): per flop
+// a quarter fewer operand bytes through L2 and LDS and half as many barriers (round 6: +4..6 % where the tile count divides the
+// resident blocks as well, profiles/r6_simgemm_ablation.txt).  launch_sim picks per shape.  The contraction order per output
+// element is the same for both (planes k = 8q + 4h + s), so the results are bit-identical whichever runs.
+constexpr int SG_T = 128, SG_K = 16;
 constexpr int SG_PLANE = SG_T * 4 + 8;      // floats per (sub-slab q, k-half h) plane; +8: the 4 planes a wave store
                                             // instruction touches start on different banks
-constexpr int SG_PLANE_B = SG_TN * 4 + 8;
 constexpr int SG_IMG = 4 * SG_PLANE;        // one operand slab: planes (q, h) = (0,0) (0,1) (1,0) (1,1)
-constexpr int SG_IMG_B = 4 * SG_PLANE_B;
-constexpr int SG_LB = SG_TN / 64;           // float4s per thread of one B slab (A: 2)
-constexpr int SG_SUPER = 8;                 // super-tile of 1024 x 1024 outputs per XCD visit (L2: 2 x 1.2 MB of operand rows at d=300):
-constexpr int SG_SUPER_N = SG_SUPER * 2 / SG_WJ;   // 8 x 8 tiles of 128 x 128, or 8 x 4 of 128 x 256
+template <int WJ>
+struct SgTile {
+    static constexpr int TN = 64 * WJ;              // tile columns
+    static constexpr int PLANE_B = TN * 4 + 8;      // B operand's plane
+    static constexpr int IMG_B = 4 * PLANE_B;
+    static constexpr int LB = TN / 64;              // float4s per thread of one B slab (A: 2)
+    static constexpr int SUPER_N = 8 * 2 / WJ;      // super-tile of 1024 x 1024 outputs: 8 x 8 tiles of 128 x 128, or 8 x 4 of 128 x 256
+    static constexpr int OCC = WJ == 2 ? 3 : 2;     // resident blocks per CU the register budget is set for
+};
+constexpr int SG_SUPER = 8;                 // super-tile of 1024 x 1024 outputs per XCD visit (L2: 2 x 1.2 MB of operand rows at d=300)
 constexpr int SG_FL_CAP = 256;              // FILTER epilogue: passing elements a wave collects before it claims their slots
 // Ablation builds (tools/r6_simgemm_ablation.sh; the product is built with 0): where does the matrix pipe's idle time go?
 //   bit 0  the C tile is not stored (a store behind a never-true data-dependent test keeps the accumulators live)
@@ -409,18 +411,6 @@ constexpr int SG_FL_CAP = 256;              // FILTER epilogue: passing elements
 //   bit 2  no LDS stores, fragment reads or barriers inside the K loop: the MFMA chain alone (implies nothing about results)
 #ifndef JMAC_SG_ABLATE
 #define JMAC_SG_ABLATE 0
-#endif
-#ifndef JMAC_SG_PRIO
-#define JMAC_SG_PRIO 0        // experiment: wave priority rises with the tile's progress (s_setprio): resident blocks drift out of phase
-#endif
-#ifndef JMAC_SG_NT
-#define JMAC_SG_NT 0          // experiment: non-temporal C stores (the 576 MB result does not displace the operand panels in L2)
-#endif
-#ifndef JMAC_SG_PIPE
-#define JMAC_SG_PIPE 0        // experiment: K loop peeled into branch-free slab bodies (zero-source loads instead of zeroing selects),
-#endif                        // 1 = the compiler's own interleaving, 2 = sched_group_barrier: LDS / memory ops spread between the MFMAs
-#ifndef JMAC_SG_OCC
-#define JMAC_SG_OCC 3         // resident blocks per CU the register budget is set for
 #endif
 constexpr bool SG_NO_STORE = (JMAC_SG_ABLATE & 1) != 0, SG_NO_LOAD = (JMAC_SG_ABLATE & 2) != 0, SG_MFMA_ONLY = (JMAC_SG_ABLATE & 4) != 0;
 
@@ -437,15 +427,16 @@ struct SimFilter {
     int n_off;               // the product covers columns [n_off, n_off + N) of the full matrix: candidate index = n_off + n
 };
 
-template <bool FILTER>
-__global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
+template <bool FILTER, int WJ>
+__global__ __launch_bounds__(kBlock, SgTile<WJ>::OCC) void sim_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
                                                           int64_t ldb, int M, int N, int d, float* __restrict__ C, int64_t ldc,
                                                           int tiles_m, int tiles_n, int super_order, int n_ids, SimFilter flt) {
     // LDS image of one operand slab (16 k): plane (q, h) holds, for every tile row, the 4 floats k = 8q + 4h .. +3.
     // Lane (r = l&31, h = l>>5) of a wave reads its float4 of row r from plane (q, h): 32 lanes x 16 B contiguous,
     // conflict free for ds_read_b128's lane groups.  The MFMA step s of a sub-slab contracts k = {8q+s, 8q+4+s}.
     __shared__ __attribute__((aligned(16))) float As[2][SG_IMG];
-    __shared__ __attribute__((aligned(16))) float Bs[2][SG_IMG_B];
+    constexpr int SG_WJ = WJ, SG_TN = SgTile<WJ>::TN, SG_PLANE_B = SgTile<WJ>::PLANE_B, SG_LB = SgTile<WJ>::LB, SG_SUPER_N = SgTile<WJ>::SUPER_N;
+    __shared__ __attribute__((aligned(16))) float Bs[2][SgTile<WJ>::IMG_B];
     __shared__ int fl_m[FILTER ? kBlock / 64 : 1][FILTER ? SG_FL_CAP : 1];      // FILTER: per-wave lists of passing elements
     __shared__ int fl_n[FILTER ? kBlock / 64 : 1][FILTER ? SG_FL_CAP : 1];
     __shared__ float fl_v[FILTER ? kBlock / 64 : 1][FILTER ? SG_FL_CAP : 1];
@@ -495,14 +486,10 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
             const int f = tid + 256 * i;
-#if JMAC_SG_PIPE
             // zeroing as a bit mask (exact, and no select the compiler could turn into a branch: the slab body stays ONE basic block)
             const unsigned keep = k0 + 4 * (f & 3) < d ? 0xffffffffu : 0u;
             const float4 x = make_float4(__uint_as_float(__float_as_uint(v[i].x) & keep), __uint_as_float(__float_as_uint(v[i].y) & keep),
                                          __uint_as_float(__float_as_uint(v[i].z) & keep), __uint_as_float(__float_as_uint(v[i].w) & keep));
-#else
-            const float4 x = k0 + 4 * (f & 3) < d ? v[i] : f4zero();
-#endif
             *reinterpret_cast<float4*>(S + (f & 3) * PLANE + (f >> 2) * 4) = x;      // plane index = kq = 2q + h
         }
     };
@@ -543,9 +530,12 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
             for (int j = 0; j < SG_WJ; ++j)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-        // Software pipeline, one barrier per slab.  At the top of slab kt: fragment set 0 holds (kt, q=0), the staging
-        // registers hold slab kt+1 (loads in flight).  The q=0 MFMAs cover the q=1 fragment reads and the LDS stores of
-        // slab kt+1; the q=1 MFMAs cover the first fragment reads of slab kt+1 and the global loads of slab kt+2.
+        // Software pipeline, one barrier per slab.  At the top of slab kt: fragment set 0 holds (kt, q=0), the staging registers
+        // hold slab kt+1 (loads in flight).  One slab is ONE basic block (round 6): no zeroing select, no loop-carried branch --
+        // HAS1 = slab kt+1 exists (its staged rows go to LDS, its first fragments are read behind the barrier), HAS2 = slab kt+2
+        // exists (requested); the steady state (both) runs in the loop, the last two slabs are peeled -- and inside it the LDS and
+        // memory operations are spread between the MFMAs (sched_group_barrier): one operation behind each MFMA instead of a burst
+        // behind sixteen of them (ablation and A/B: profiles/r6_simgemm_ablation.txt; +3 % over the burst form).
         sstore(As[0], ra, 0);
         sstore(Bs[0], rb, 0);
         if (nk > 1 && !SG_NO_LOAD) {
@@ -555,13 +545,10 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
         __syncthreads();
         frags(0, 0, af0, bf0);
         if (SG_MFMA_ONLY) frags(0, 1, af1, bf1);
-#if JMAC_SG_PIPE
-        // One slab as ONE basic block: HAS1 = slab kt+1 exists (its staged rows go to LDS, its first fragments are read behind the
-        // barrier), HAS2 = slab kt+2 exists (requested).  The steady state (both) runs in the loop, the last two slabs are peeled.
         auto slab_body = [&](const int kt, auto has1, auto has2) {
-            constexpr bool HAS1 = decltype(has1)::value, HAS2 = decltype(has2)::value;
+            constexpr bool HAS1 = decltype(has1)::value && !SG_MFMA_ONLY, HAS2 = decltype(has2)::value && !SG_MFMA_ONLY && !SG_NO_LOAD;
             const int cur = kt & 1;
-            frags(cur, 1, af1, bf1);
+            if (!SG_MFMA_ONLY) frags(cur, 1, af1, bf1);
             mfma16(af0, bf0);
             if constexpr (HAS1) {
                 sstore(As[cur ^ 1], ra, (kt + 1) * SG_K);
@@ -571,34 +558,32 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
                     gload(Bm, ldb, n0, N, (kt + 2) * SG_K, rb);
                 }
             }
-#if JMAC_SG_PIPE == 2
-            // 2 + WJ fragment reads, 8 WJ MFMAs, then per staged float4 one LDS store and (HAS2) one global load: one memory
-            // operation between two MFMAs instead of a burst behind sixteen of them
+            if constexpr (!SG_MFMA_ONLY) {
+                // 2 + WJ fragment reads, 8 WJ MFMAs, then per staged float4 one LDS store and (HAS2) one global load
 #pragma unroll
-            for (int i = 0; i < 2 + SG_WJ; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 8 * SG_WJ - (2 + SG_WJ) - (HAS1 ? 2 + SG_LB : 0) - (HAS2 ? 2 + SG_LB : 0), 0);
-            if constexpr (HAS1) {
-#pragma unroll
-                for (int i = 0; i < 2 + SG_LB; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                for (int i = 0; i < 2 + SG_WJ; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-            }
-            if constexpr (HAS2) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 8 * SG_WJ - (2 + SG_WJ) - (HAS1 ? 2 + SG_LB : 0) - (HAS2 ? 2 + SG_LB : 0), 0);
+                if constexpr (HAS1) {
 #pragma unroll
-                for (int i = 0; i < 2 + SG_LB; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    for (int i = 0; i < 2 + SG_LB; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
                 }
+                if constexpr (HAS2) {
+#pragma unroll
+                    for (int i = 0; i < 2 + SG_LB; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                }
+                __syncthreads();
             }
-#endif
-            __syncthreads();
             if constexpr (HAS1) frags(cur ^ 1, 0, af0, bf0);
             mfma16(af1, bf1);
-#if JMAC_SG_PIPE == 2
             if constexpr (HAS1) {
 #pragma unroll
                 for (int i = 0; i < 2 + SG_WJ; ++i) {
@@ -606,7 +591,6 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
             }
-#endif
         };
         {
             int kt = 0;
@@ -617,36 +601,6 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
             }
             slab_body(kt, std::false_type{}, std::false_type{});
         }
-#else
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-#if JMAC_SG_PRIO
-            if (kt == nk / 4) __builtin_amdgcn_s_setprio(1);
-            else if (kt == nk / 2) __builtin_amdgcn_s_setprio(2);
-            else if (kt == (3 * nk) / 4) __builtin_amdgcn_s_setprio(3);
-#endif
-            if (!SG_MFMA_ONLY) frags(cur, 1, af1, bf1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma16(af0, bf0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < nk && !SG_MFMA_ONLY) {
-                sstore(As[cur ^ 1], ra, (kt + 1) * SG_K);
-                sstore(Bs[cur ^ 1], rb, (kt + 1) * SG_K);
-                if (kt + 2 < nk && !SG_NO_LOAD) {
-                    gload(A, lda, m0, M, (kt + 2) * SG_K, ra);
-                    gload(Bm, ldb, n0, N, (kt + 2) * SG_K, rb);
-                }
-            }
-            if (!SG_MFMA_ONLY) __syncthreads();
-            if (kt + 1 < nk && !SG_MFMA_ONLY) frags(cur ^ 1, 0, af0, bf0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma16(af1, bf1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#endif
-#if JMAC_SG_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         if (SG_MFMA_ONLY) __syncthreads();               // (the next tile's first sstore must not race this tile's first fragment reads)
         // the next tile's first slab is requested BEFORE this tile's 64 KB of results are stored: the stores and the
         // loads overlap, and no wave reads LDS any more (the last fragment reads precede the last barrier)
@@ -719,13 +673,7 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
                         if (acc[i][j][reg] == 123456.789f) cbase[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg];
                 } else if (full) {
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-#if JMAC_SG_NT
-                        __builtin_nontemporal_store(acc[i][j][reg], cbase + (int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc);
-#else
-                        cbase[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg];
-#endif
-                    }
+                    for (int reg = 0; reg < 16; ++reg) cbase[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg];
                 } else {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
@@ -740,6 +688,223 @@ __global__ __launch_bounds__(kBlock, JMAC_SG_OCC) void sim_gemm_kernel(const flo
         tn = ntn;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same product with the operand slabs DMA'd straight into LDS (global_load_lds_dwordx4), 32 k per slab (round 6 experiment,
+// JMAC_SG_GLDS).  What the ablation of the register-staged kernel above left on the table (profiles/r6_simgemm_ablation.txt):
+// its loads touch 16 half cache lines per wave instruction, every staged float4 costs a 13-cycle ds_write_b128 on the LDS data
+// path, and there is one barrier per 16 k.  Here one wave instruction fetches 8 FULL 128-byte lines (8 rows x 32 k) into 1 KB of
+// LDS, nothing is staged in registers, and there is one barrier per 32 k.
+//   LDS image of an operand slab: [128 rows][8 slots of 16 B]; slot = kq ^ ((row >> 1) & 7), kq = the float4 index inside the
+//   row's 32 k.  The LDS destination of a DMA is lane-linear (wave base + 16 lane), so the swizzle is applied to the SOURCE address
+//   (lane l of a DMA fetches row 8c + l/8, float4 kq = (l & 7) ^ ((row >> 1) & 7)) and again on the fragment read: a ds_read_b128
+//   lane group (16 rows of one parity pattern, MI355X_MICROARCH.md "LDS") then touches 64 distinct banks.
+//   Contraction order per output element: group g of 8 k, step s: k = {8g + s, 8g + 4 + s} -- the order of sim_gemm_kernel, so
+//   the results are bit-identical to it (and to cand_select_kernel's recomputation).
+//   Pipeline: the (tile, slab) sequence of a block is flat: while slab t is multiplied, slab t+1 -- of this tile or slab 0 of the
+//   block's next tile -- is in flight into the other buffer; one raw s_barrier per slab, behind a counted vmcnt wait (the C stores
+//   of a finished tile stay in flight across it: vmcnt completes in order, the DMAs were issued first).
+// ------------------------------------------------------------------------------------------------
+#ifndef JMAC_SG_GLDS
+#define JMAC_SG_GLDS 0              // 1: tools/r6_simgemm_ablation.sh variant "glds" (closed: 104 vs 103 TF/s of the kernel above)
+#endif
+#if JMAC_SG_GLDS
+constexpr int GL_K = 32;                       // k per slab
+constexpr int GL_OP = SG_T * GL_K;             // floats per operand slab (16 KB)
+__device__ __attribute__((aligned(16))) float sg_zero16[4] = {0.f, 0.f, 0.f, 0.f};      // source of the float4s past d
+
+typedef void __attribute__((address_space(3))) * gl_dst_t;
+// One LDS-DMA: lane l's 16 bytes at gsrc -> LDS byte address lds_dst + 16 l (lds_dst wave-uniform, in an SGPR).  Inline asm, so
+// the compiler neither counts it in its own s_waitcnt bookkeeping nor drains it (vmcnt(0)) before the next ds_read: the kernel
+// counts vmcnt by hand (cdna_hip_programming.md section 5, "Pipelining across barriers").  M0 is written and restored in the
+// same statement.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(gl_dst_t)(const_cast<void*>(p));
+}
+// s_waitcnt immediates (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8])
+constexpr int gl_waitcnt(int vm, int lgkm) { return (vm & 0xf) | ((vm >> 4) << 14) | (0x7 << 4) | ((lgkm & 0xf) << 8); }
+
+__global__ __launch_bounds__(kBlock, 2) void sim_gemm_glds_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
+                                                                int64_t ldb, int M, int N, int d, float* __restrict__ C, int64_t ldc,
+                                                                int tiles_m, int tiles_n, int super_order, int n_ids,
+                                                                const float* __restrict__ zero16) {
+    __shared__ __attribute__((aligned(1024))) float Ls[2][2][GL_OP];          // [buffer][A | B][row * 32 + slot * 4]: 64 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    auto tile_of = [&](int id, int& tm, int& tn) -> bool {
+        if (super_order) {
+            const int sup_n = (tiles_n + SG_SUPER - 1) / SG_SUPER, sup_m = (tiles_m + SG_SUPER - 1) / SG_SUPER;
+            const int per = SG_SUPER * SG_SUPER;
+            const int xcd = id & 7, local = id >> 3;
+            const int sup = (local / per) * 8 + xcd, within = local % per;
+            if (sup >= sup_m * sup_n) return false;
+            tm = (sup / sup_n) * SG_SUPER + within / SG_SUPER;
+            tn = (sup % sup_n) * SG_SUPER + within % SG_SUPER;
+            return tm < tiles_m && tn < tiles_n;
+        }
+        tm = id / tiles_n;
+        tn = id % tiles_n;
+        return true;
+    };
+    auto next_tile = [&](int id, int& tm, int& tn) -> int {
+        while (id < n_ids && !tile_of(id, tm, tn)) id += gridDim.x;
+        return id < n_ids ? id : n_ids;
+    };
+    // DMA side: instruction i of a wave fills rows 8 (4 i + wave) .. + 7 of the slab; the lane's row inside them and its float4
+    const int rr = lane >> 3;
+    const int kq_src = (lane & 7) ^ ((((wave & 1) << 2) | (rr >> 1)) & 7);   // ((row >> 1) & 7 with row = 32 i + 8 wave + rr)
+    const float* pa[4];
+    const float* pb[4];
+    auto set_rows = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (4 * i + wave) * 8 + rr;
+            pa[i] = A + (int64_t)min(m0 + row, M - 1) * lda + 4 * kq_src;
+            pb[i] = Bm + (int64_t)min(n0 + row, N - 1) * ldb + 4 * kq_src;
+        }
+    };
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(&Ls[0][0][0]) + wave * 8 * GL_K * 4);     // wave's first DMA target
+    auto issue = [&](int buf, int k0) {
+        // float4s past d (only in a row's last slab, d % 32 != 0) come from 16 zero bytes: an integer select on the ADDRESS
+        const uint64_t keep = k0 + 4 * kq_src < d ? ~0ull : 0ull, zero = (uint64_t)(uintptr_t)zero16 & ~keep;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t sa = ((uint64_t)(uintptr_t)(pa[i] + k0) & keep) | zero;
+            const uint64_t sb = ((uint64_t)(uintptr_t)(pb[i] + k0) & keep) | zero;
+            const unsigned dst = lds0 + (unsigned)((buf * 2 * GL_OP + 4 * i * 8 * GL_K) * 4);
+            glds16(reinterpret_cast<const void*>(sa), dst);
+            glds16(reinterpret_cast<const void*>(sb), dst + GL_OP * 4);
+        }
+    };
+    // fragment side
+    const int r = lane & 31, h = lane >> 5;
+    const int sw = (r >> 1) & 7;
+    const int arow = (wm * 64 + r) * GL_K, brow = (wn * 64 + r) * GL_K;      // + 32 GL_K for the second 32-row sub-tile
+    auto frags = [&](int buf, int g, float4 (&af)[2], float4 (&bf)[2]) {
+        const int slot = (((2 * g + h) ^ sw) & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            af[i] = *reinterpret_cast<const float4*>(&Ls[buf][0][arow + i * 32 * GL_K + slot]);
+            bf[i] = *reinterpret_cast<const float4*>(&Ls[buf][1][brow + i * 32 * GL_K + slot]);
+        }
+    };
+    f32x16 acc[2][2];
+    auto mfma16 = [&](const float4 (&af)[2], const float4 (&bf)[2]) {
+#define JMAC_GL_STEP(c)                                                                                   \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0].c, bf[0].c, acc[0][0], 0, 0, 0);          \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0].c, bf[1].c, acc[0][1], 0, 0, 0);          \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1].c, bf[0].c, acc[1][0], 0, 0, 0);          \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1].c, bf[1].c, acc[1][1], 0, 0, 0);
+        JMAC_GL_STEP(x)
+        JMAC_GL_STEP(y)
+        JMAC_GL_STEP(z)
+        JMAC_GL_STEP(w)
+#undef JMAC_GL_STEP
+    };
+    const int nk = (d + GL_K - 1) / GL_K;
+    int tm, tn;
+    int id = next_tile(blockIdx.x, tm, tn);
+    if (id >= n_ids) return;
+    set_rows(tm * SG_T, tn * SG_T);
+    issue(0, 0);
+    int buf = 0;
+    __builtin_amdgcn_s_waitcnt(gl_waitcnt(0, 0));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float4 af[2][2], bf[2][2];
+    while (id < n_ids) {
+        const int m0 = tm * SG_T, n0 = tn * SG_T;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+        int ntm = 0, ntn = 0;
+        const int nid = next_tile(id + gridDim.x, ntm, ntn);
+        // every slab but the tile's last: the tile's next slab goes into the other buffer (every wave has passed the barrier behind
+        // its last fragment read of that buffer), four groups of 8 k are multiplied with alternating fragment sets
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            issue(buf ^ 1, (kt + 1) * GL_K);
+            frags(buf, 0, af[0], bf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            // group g's 16 MFMAs carry group g+1's four fragment reads between them (one read behind each of the first four)
+#define JMAC_GL_OVERLAP()                                                                  \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                             \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                         \
+            }                                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                            \
+            __builtin_amdgcn_sched_barrier(0);
+            frags(buf, 1, af[1], bf[1]);
+            mfma16(af[0], bf[0]);
+            JMAC_GL_OVERLAP()
+            frags(buf, 2, af[0], bf[0]);
+            mfma16(af[1], bf[1]);
+            JMAC_GL_OVERLAP()
+            frags(buf, 3, af[1], bf[1]);
+            mfma16(af[0], bf[0]);
+            JMAC_GL_OVERLAP()
+#undef JMAC_GL_OVERLAP
+            mfma16(af[1], bf[1]);
+            __builtin_amdgcn_s_waitcnt(gl_waitcnt(0, 0));      // the wave's own DMAs of the next slab have landed
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");                     // no fragment read of the next slab moves above the barrier
+            buf ^= 1;
+        }
+        // the last slab (d % 32 != 0: fewer groups): slab 0 of the block's NEXT tile is requested first
+        if (nid < n_ids) {
+            set_rows(ntm * SG_T, ntn * SG_T);
+            issue(buf ^ 1, 0);
+        }
+        {
+            const int ng = (d - (nk - 1) * GL_K + 7) >> 3;
+            frags(buf, 0, af[0], bf[0]);
+            for (int g = 0; g < ng; ++g) {
+                mfma16(af[0], bf[0]);
+                if (g + 1 < ng) frags(buf, g + 1, af[0], bf[0]);
+            }
+        }
+        {
+            // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+            const bool full = m0 + SG_T <= M && n0 + SG_T <= N;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float* cbase = C + (int64_t)(m0 + wm * 64 + i * 32 + 4 * h) * ldc + (n0 + wn * 64 + j * 32 + r);
+                    if (full) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) cbase[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg];
+                    } else {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int64_t m = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                            const int64_t n = n0 + wn * 64 + j * 32 + r;
+                            if (m < M && n < N) C[m * ldc + n] = acc[i][j][reg];
+                        }
+                    }
+                }
+        }
+        // the 8 DMAs of the next tile's first slab were issued before the (up to 64) stores: vmcnt retires in order
+        __builtin_amdgcn_s_waitcnt(gl_waitcnt(63, 0));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        buf ^= 1;
+        id = nid;
+        tm = ntm;
+        tn = ntn;
+    }
+}
+
+#endif  // JMAC_SG_GLDS
 
 // ------------------------------------------------------------------------------------------------
 // row top-k: one block per row.  Order: value descending, ties -> lower index first.
@@ -1384,37 +1549,94 @@ __global__ __launch_bounds__(kBlock) void csls_rank_kernel(const float* __restri
     }
 }
 
-int launch_sim(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t d, float* C, int64_t ldc,
-               hipStream_t st, const SimFilter* flt = nullptr) {
-    if (M == 0 || N == 0) return 0;
-    const int tiles_m = (int)((M + SG_T - 1) / SG_T), tiles_n = (int)((N + SG_TN - 1) / SG_TN);
-    const int64_t sup = (int64_t)((tiles_m + SG_SUPER - 1) / SG_SUPER) * ((tiles_n + SG_SUPER_N - 1) / SG_SUPER_N);
-    const int super_order = sup >= 64 ? 1 : 0;                          // >= 8 super-tiles per XCD: the tail imbalance is small
-    const int64_t n_ids = super_order ? (sup + 7) / 8 * 8 * SG_SUPER * SG_SUPER_N : (int64_t)tiles_m * tiles_n;
-    if (n_ids >= INT32_MAX) return JMAC_ERANGE;
-    if (d % 4) return JMAC_EDIM;
-    // persistent: as many blocks as are resident at once (occupancy query: 3 per CU with 80 + 64 accumulation VGPRs and
-    // 33 KB of LDS), rounded down to a multiple of 8 so that a block's tile ids stay on its XCD
-    static int resident_of[64] = {0};                                   // per device: CU counts may differ between devices
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+// One shape's launch geometry with WJ column sub-tiles per wave: tiles, the XCD-aware id space and the blocks resident at once.
+template <int WJ>
+struct SimGeom {
+    int tiles_m, tiles_n, super_order;
+    int64_t n_ids, tiles;
+    SimGeom(int64_t M, int64_t N) {
+        tiles_m = (int)((M + SG_T - 1) / SG_T);
+        tiles_n = (int)((N + SgTile<WJ>::TN - 1) / SgTile<WJ>::TN);
+        const int64_t sup = (int64_t)((tiles_m + SG_SUPER - 1) / SG_SUPER) * ((tiles_n + SgTile<WJ>::SUPER_N - 1) / SgTile<WJ>::SUPER_N);
+        super_order = sup >= 64 ? 1 : 0;                                  // >= 8 super-tiles per XCD: the tail imbalance is small
+        tiles = (int64_t)tiles_m * tiles_n;
+        n_ids = super_order ? (sup + 7) / 8 * 8 * SG_SUPER * SgTile<WJ>::SUPER_N : tiles;
+    }
+};
+
+// persistent grids: as many blocks as are resident at once (occupancy query: 3 per CU for the 128 x 128 tile -- 64 accumulation
+// VGPRs, 33 KB of LDS -- and 2 for 128 x 256), rounded down to a multiple of 8 so that a block's tile ids stay on its XCD
+template <bool FILTER, int WJ>
+int sim_resident(int dev) {
+    static int resident_of[64] = {0};                                     // per device: CU counts may differ between devices
     int& resident = resident_of[dev >= 0 && dev < 64 ? dev : 0];
     if (resident == 0 || dev >= 64) {
-        int cus = 256, occ = 3;
+        int cus = 256, occ = SgTile<WJ>::OCC;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(sim_gemm_kernel<false>), kBlock, 0) != hipSuccess || occ < 1)
-            occ = 3;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(sim_gemm_kernel<FILTER, WJ>), kBlock, 0) != hipSuccess || occ < 1)
+            occ = SgTile<WJ>::OCC;
         resident = (cus * occ) / 8 * 8;
         if (resident < 8) resident = 8;
     }
-    const unsigned grid = (unsigned)(n_ids < resident ? n_ids : resident);
-    if (flt)
-        hipLaunchKernelGGL(sim_gemm_kernel<true>, dim3(grid), dim3(kBlock), 0, st, A, lda, B, ldb, (int)M, (int)N, (int)d, C, ldc,
-                           tiles_m, tiles_n, super_order, (int)n_ids, *flt);
-    else
-        hipLaunchKernelGGL(sim_gemm_kernel<false>, dim3(grid), dim3(kBlock), 0, st, A, lda, B, ldb, (int)M, (int)N, (int)d, C, ldc,
-                           tiles_m, tiles_n, super_order, (int)n_ids, SimFilter{});
+    return resident;
+}
+
+template <bool FILTER, int WJ>
+int launch_sim_wj(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t d, float* C, int64_t ldc,
+                  hipStream_t st, const SimFilter* flt, int dev) {
+    const SimGeom<WJ> g(M, N);
+    if (g.n_ids >= INT32_MAX) return JMAC_ERANGE;
+    const int resident = sim_resident<FILTER, WJ>(dev);
+    const unsigned grid = (unsigned)(g.n_ids < resident ? g.n_ids : resident);
+    hipLaunchKernelGGL((sim_gemm_kernel<FILTER, WJ>), dim3(grid), dim3(kBlock), 0, st, A, lda, B, ldb, (int)M, (int)N, (int)d, C, ldc,
+                       g.tiles_m, g.tiles_n, g.super_order, (int)g.n_ids, flt ? *flt : SimFilter{});
     return (int)hipGetLastError();
+}
+
+int launch_sim(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t d, float* C, int64_t ldc,
+               hipStream_t st, const SimFilter* flt = nullptr) {
+    if (M == 0 || N == 0) return 0;
+    if (d % 4) return JMAC_EDIM;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+#if JMAC_SG_GLDS
+    if (!flt) {                                                           // closed experiment: the LDS-DMA form of the plain product
+        const SimGeom<2> g(M, N);
+        if (g.n_ids >= INT32_MAX) return JMAC_ERANGE;
+        static const float* zero_of[64] = {nullptr};
+        const float*& zero16 = zero_of[dev >= 0 && dev < 64 ? dev : 0];
+        if (zero16 == nullptr || dev >= 64) {
+            void* p = nullptr;
+            if (hipGetSymbolAddress(&p, HIP_SYMBOL(sg_zero16)) != hipSuccess) return (int)hipGetLastError();
+            zero16 = static_cast<const float*>(p);
+        }
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int res2 = (cus * 2) / 8 * 8;
+        hipLaunchKernelGGL(sim_gemm_glds_kernel, dim3((unsigned)(g.n_ids < res2 ? g.n_ids : res2)), dim3(kBlock), 0, st, A, lda, B, ldb, (int)M,
+                           (int)N, (int)d, C, ldc, g.tiles_m, g.tiles_n, g.super_order, (int)g.n_ids, zero16);
+        return (int)hipGetLastError();
+    }
+#endif
+    // Which tile?  Both give the same bits.  A round of resident blocks is (resident blocks) x (tile area) of matrix-pipe work, and
+    // the wide tile does a given amount of it ~3.5 % faster (fewer barriers and operand bytes per flop) -- but its rounds are coarser.
+    // Take it when its quantised makespan, rounds x resident x area, is no larger than the narrow tile's (measured, config-5 shapes:
+    // 12 000^2 and 3 000 x 30 000 tie on that count and gain 3.4 / 3.5 %; 10 500^2 needs 7 168 against 6 912 units and loses 4 %).
+#if defined(JMAC_SG_FORCE_WJ)
+    const bool wide = JMAC_SG_FORCE_WJ == 4;
+#else
+    const SimGeom<2> g2(M, N);
+    const SimGeom<4> g4(M, N);
+    const int64_t r2 = flt ? sim_resident<true, 2>(dev) : sim_resident<false, 2>(dev);
+    const int64_t r4 = flt ? sim_resident<true, 4>(dev) : sim_resident<false, 4>(dev);
+    const int64_t cost2 = (g2.tiles + r2 - 1) / r2 * r2, cost4 = (g4.tiles + r4 - 1) / r4 * r4 * 2;
+    const bool wide = g4.tiles >= r4 && cost4 <= cost2;
+#endif
+    if (wide)
+        return flt ? launch_sim_wj<true, 4>(A, lda, B, ldb, M, N, d, C, ldc, st, flt, dev)
+                   : launch_sim_wj<false, 4>(A, lda, B, ldb, M, N, d, C, ldc, st, flt, dev);
+    return flt ? launch_sim_wj<true, 2>(A, lda, B, ldb, M, N, d, C, ldc, st, flt, dev)
+               : launch_sim_wj<false, 2>(A, lda, B, ldb, M, N, d, C, ldc, st, flt, dev);
 }
 
 int launch_topk(const float* S, int64_t lds, int64_t L, int64_t N, int32_t k, float* val, int32_t* idx, hipStream_t st) {

@@ -1,12 +1,16 @@
 #!/bin/bash
 # round 6: where does the similarity GEMM's matrix-pipe idle time go?  Ablation / experiment builds of sim_gemm_kernel
-# (score.hip: JMAC_SG_ABLATE bits, JMAC_SG_PRIO, JMAC_SG_NT, JMAC_SG_OCC), timed on the config-5 shapes beside the library's
+# (score.hip: JMAC_SG_ABLATE bits, JMAC_SG_FORCE_WJ, JMAC_SG_GLDS), timed on the config-5 shapes beside the library's
 # fp32 NT GEMM (torch.mm -> hipBLASLt / rocBLAS), plus one PMC pass (MFMA busy, GRBM_GUI_ACTIVE) per build.
 #   build (dev container, repo root):  bash tools/r6_simgemm_ablation.sh build     -> build/variants/jmac_<name>.so (travel with gpurun)
 #   run   (GPU box, repo root):        bash tools/r6_simgemm_ablation.sh run [pmc] -> gpurun_out/r6_simgemm_ablation.txt
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$R"
-VARIANTS=${VARIANTS:-"base: nostore:-DJMAC_SG_ABLATE=1 noload:-DJMAC_SG_ABLATE=2 nostore_noload:-DJMAC_SG_ABLATE=3 mfma_only:-DJMAC_SG_ABLATE=7 mfma_only_io:-DJMAC_SG_ABLATE=4 prio:-DJMAC_SG_PRIO=1 nt:-DJMAC_SG_NT=1 prio_nt:-DJMAC_SG_PRIO=1,-DJMAC_SG_NT=1 occ2:-DJMAC_SG_OCC=2"}
+# variants: the product build ("auto": launch_sim picks the tile per shape), each tile forced, the ablations of the 128 x 128 form
+# (JMAC_SG_ABLATE bits: 1 no C store, 2 no global loads after the first slab, 4 no LDS traffic / barriers in the K loop), the closed
+# LDS-DMA form.  Round-6 history (profiles/r6_simgemm_ablation.txt) also holds the builds that were measured and removed: the
+# round-5 loop ("burst": sixteen MFMAs, then all LDS / memory operations), s_setprio ramps, non-temporal C stores, launch bounds 2.
+VARIANTS=${VARIANTS:-"auto: wj2:-DJMAC_SG_FORCE_WJ=2 wj4:-DJMAC_SG_FORCE_WJ=4 nostore:-DJMAC_SG_FORCE_WJ=2,-DJMAC_SG_ABLATE=1 noload:-DJMAC_SG_FORCE_WJ=2,-DJMAC_SG_ABLATE=2 nostore_noload:-DJMAC_SG_FORCE_WJ=2,-DJMAC_SG_ABLATE=3 mfma_only:-DJMAC_SG_FORCE_WJ=2,-DJMAC_SG_ABLATE=7 mfma_only_io:-DJMAC_SG_FORCE_WJ=2,-DJMAC_SG_ABLATE=4 glds:-DJMAC_SG_GLDS=1"}
 if [ "$1" = "build" ]; then
   make -s -C jmac_amd/csrc >/dev/null || exit 1
   mkdir -p build/variants
