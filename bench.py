@@ -1183,11 +1183,14 @@ def union_train_step(a, device, m, kgs):
         out[key] = {"bound": "hbm", "algorithmic_bytes_per_layer_call": nbytes, "avg_ms_per_layer_call": ms, "in_step_event_ms": ev_ms,
                     "in_step_rocprof_ms": ms_in, "source": ksrc, "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    if a.dim == 300:
-        parts = [pmc_traffic("union_train", k, ("r6",)) for k in ("rel_attn_bwd_dst_kernel", "rel_attn_bwd_gather_kernel", "bwd_finalize_kernel")]
-        if "roofline_bwd" in out and all(p is not None for p in parts):
-            out["roofline_bwd"]["traffic_per_step"] = float(sum(parts))
-            out["roofline_bwd"]["traffic_over_algorithmic"] = float(sum(parts)) / (calls * bb)
+    if a.dim == 300 and "roofline_bwd" in out:
+        # HBM-side bytes of the three backward launches on this very graph (the real five-KG union, E = 197 604) from the committed
+        # PMC passes (tools/union_agg_probe.py under rocprofv3 --pmc: one layer call, back to back)
+        parts = [pmc_traffic("union", k) for k in ("rel_attn_bwd_dst_kernel", "rel_attn_bwd_gather_kernel", "bwd_finalize_kernel")]
+        if all(p is not None for p in parts):
+            out["roofline_bwd"]["traffic"] = float(sum(parts))
+            out["roofline_bwd"]["traffic_over_algorithmic"] = float(sum(parts)) / bb
+            out["roofline_bwd"]["traffic_source"] = "%s (committed rocprofv3 --pmc passes; not collected by this run)" % pmc_source("union")
     return out
 
 

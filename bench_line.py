@@ -27,6 +27,7 @@ HIGHLIGHTS = (("ms_per_step_torch_adam", ("ms_per_step_torch_adam",)),
               ("pair.ms_per_step", ("pair", "ms_per_step")),
               ("union.train_ms_per_step", ("union", "train_mode", "ms_per_step")),
               ("union.bwd_frac_hbm", ("union", "train_mode", "roofline_bwd", "frac")),
+              ("union.bwd_traffic_over_algorithmic", ("union", "train_mode", "roofline_bwd", "traffic_over_algorithmic")),
               ("synth.fwd_frac_hbm", ("synth", "fwd_frac_hbm")),
               ("synth.bwd_frac_hbm", ("synth", "bwd_frac_hbm")),
               ("synth.fwd_bf16_frac_hbm", ("synth", "fwd_bf16_frac_hbm")),

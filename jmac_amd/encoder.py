@@ -334,6 +334,11 @@ _TRACKERS = None      # list while an encoder node's forward runs: the num_batch
 # epilogues) instead of autograd adding two [N, d] tensors afterwards.  Only a buffer one of this library's loss ops has just
 # allocated and marked (jmac_amd.losses: ``_jmac_fresh_grad``) is written in place; any other incoming gradient (a sum the engine
 # formed, a user's tensor) is left alone and returned beside the node's own, as before.
+# Restriction: the buffer taken over is the gradient of the node's layer-0 OUTPUT.  Whoever else holds that very tensor
+# -- ``torch.autograd.grad(loss, [comp0])``, ``comp0.retain_grad()``, a tensor hook on it -- sees loss gradient + the node's input
+# gradient after this backward ran.  ``loss.backward()`` (the training loop, train.py:358) has no such observer; a caller that
+# inspects the layer-0 output's gradient sets ``encoder.INPLACE_GRADS = False`` (the sum is then formed out of place).  A backward
+# that is itself recorded (create_graph=True) never takes a buffer over.
 INPLACE_GRADS = True
 INPLACE_COUNT = 0         # tests: how many incoming gradient buffers a backward took over
 
@@ -341,7 +346,8 @@ INPLACE_COUNT = 0         # tests: how many incoming gradient buffers a backward
 def _take_grad(g, shape):
     """``g`` if this backward may accumulate onto it in place, else None."""
     global INPLACE_COUNT
-    if (INPLACE_GRADS and g is not None and getattr(g, "_jmac_fresh_grad", False) and g.dtype == torch.float32 and g.is_contiguous()
+    if (INPLACE_GRADS and not torch.is_grad_enabled() and g is not None and getattr(g, "_jmac_fresh_grad", False)
+            and g.dtype == torch.float32 and g.is_contiguous()
             and tuple(g.shape) == tuple(shape)):
         g._jmac_fresh_grad = False
         INPLACE_COUNT += 1

@@ -113,9 +113,9 @@ def _pair_index(i1: torch.Tensor, i2: torch.Tensor, off1: int, off2: int, same: 
     rowptr = None
     if n1 + n2 > 0:                                            # sorted positions are ordered by (table, row): a CSR pointer over them
         tkey = row if same else torch.where(side, row + n1, row)
-        rowptr = torch.zeros(n1 + n2 + 1, dtype=torch.int64, device=rec.device)
-        rowptr[1:] = torch.cumsum(torch.bincount(tkey, minlength=n1 + n2), 0)
-        rowptr = rowptr.to(torch.int32)
+        # tkey is non-decreasing (the sort key): the pointer is a search, with no host read (torch.bincount reads its maximum
+        # back, which would abort a stream capture that meets an unseen pair -- ADVICE r5)
+        rowptr = torch.searchsorted(tkey, torch.arange(n1 + n2 + 1, dtype=tkey.dtype, device=rec.device)).to(torch.int32)
     rec = (rec, rowptr)
     if not torch.cuda.is_current_stream_capturing():
         if int(row.max()) >= (1 << 29):

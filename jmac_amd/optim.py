@@ -4,7 +4,9 @@ as ONE launch over all parameter tensors: ``jmac_adam_step_f32`` (csrc/optim.hip
 Drop-in for ``torch.optim.Adam`` / ``torch.optim.AdamW`` on fp32 HIP parameters with dense gradients: same constructor arguments and
 defaults, same update, same ``state_dict`` layout (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter, so a checkpoint written by
 either loads into the other).  The step count is a device tensor, so a step captured in a hipGraph replays correctly (torch needs
-``capturable=True`` for that); ``amsgrad`` is not offered.  Why it exists: torch's fused multi-tensor kernel gives each 65 536-element
+``capturable=True`` for that); ``amsgrad`` is not offered.  ``lr``, the betas, ``eps`` and ``weight_decay`` are HOST numbers passed as
+kernel arguments: a captured step replays the values it was captured with, so a learning-rate schedule needs a re-capture after
+every change (torch's capturable Adam takes a tensor ``lr`` instead; the reference never schedules: train.py:406-407).  Why it exists: torch's fused multi-tensor kernel gives each 65 536-element
 chunk to one workgroup, 125 workgroups for the 6.3 M parameters of the DBP-5L model -- under half of the MI355X's 256 CUs.
 """
 from __future__ import annotations
@@ -121,8 +123,14 @@ class Adam(torch.optim.Optimizer):
         """torch.optim.Adam's layout.  ``step`` leaves as one host tensor per parameter (torch's own default form): the shared device
         count of this class must not reach an optimizer that increments every parameter's ``step`` in place."""
         sd = super().state_dict()
-        sd["state"] = {k: {**v, "step": v["step"].detach().to("cpu", copy=True)} if "step" in v else dict(v)
-                       for k, v in sd["state"].items()}
+        host = {}                                               # one blocking copy per DISTINCT counter (the parameters of a group share one)
+
+        def to_host(t):
+            key = (t.data_ptr(), t.device)
+            if key not in host:
+                host[key] = t.detach().to("cpu", copy=True)
+            return host[key].clone()
+        sd["state"] = {k: {**v, "step": to_host(v["step"])} if "step" in v else dict(v) for k, v in sd["state"].items()}
         return sd
 
     @torch.no_grad()
