@@ -273,3 +273,20 @@ def test_phased_backward_equals_one_call_bitwise(n, e, slabs):
         assert torch.equal(piece, want[1][slabs[c]:slabs[c + 1]]), c
         assert bool(torch.isnan(bp.dQZ[slabs[c + 1]:]).all())          # a slab call writes its own rows only
     assert torch.equal(bp.dQZ, want[1])
+
+
+def test_world8_rehearsal_on_one_gpu_small_scale():
+    """bench_dist.rehearse_world (round 6): rank 0's share of a weak-scaled graph at world 8 in ONE process -- sources uniform over a
+    table eight times the rank's rows, filled locally, no collective -- at 2 % of config 4's size.  The checks bench.py runs on the
+    19 GB table before it reports `sharded.rehearsal_world8`: softmax normalisation through every split-segment merge, the
+    backward's conservation laws, slab-pipelined forward == one-piece forward, phased backward == one-call backward bit for bit."""
+    import argparse
+    import bench_dist
+    a = argparse.Namespace(dim=300, synth_scale=0.02)
+    r = bench_dist.rehearse_world(a, torch.device("cuda"), world=8, chunks=4, check=True)
+    assert r["world"] == 8 and r["table_rows"] == 8 * r["local_rows"] and r["local_edges"] == 400_000
+    c = r["checks"]
+    assert c["ok"], c
+    assert c["phased_equals_one_call_bitwise"] and c["pipelined_ok"] and c["softmax_normalisation_ok"] and c["conservation_ok"]
+    assert r["pipelined"]["chunks"] == 4 and len(r["phased_bwd"]["slab_ms"]) == 4
+    assert 0.0 < r["phased_bwd"]["pass_b_share"] < 1.0

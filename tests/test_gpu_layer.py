@@ -132,7 +132,7 @@ def _check_random_layer(n, nr, d, e, hub, chunk, mode, seed, lay_seed, strict):
     flips = _kink_flips(lay, {k: v.detach() for k, v in p.items()}, Xc.detach(), Rc.detach(), ei, et, Xg.detach(), Rg.detach(),
                         captured)
     if strict:
-        assert flips == 0, flips                                     # seed chosen flip-free (tools/flip_probe.py)
+        assert flips == 0, flips                                     # seed chosen flip-free (tools/closed/flip_probe.py)
     assert flips <= 3, flips                                         # a handful at most out of e*d pre-activations
     grtol = RTOL if flips == 0 else 5e-2                             # see _kink_flips (one flip moved grad w_att by 1.4 %)
     assert_close(Xg.grad, Xc.grad, grtol, 1e-6, "grad_X")
@@ -161,7 +161,7 @@ def test_layer_matches_oracle_random(n, nr, d, e, hub, chunk, mode):
 def test_layer_gradients_at_1e4_on_flip_free_seeds(n, nr, d, e, hub, chunk, seed):
     """The BASELINE dims (d=300, and the reference's default d=256) with NO tolerance escape: these seeds have no attention
     pre-activation (and no pre-activation of the relation transform's own LeakyReLU) whose sign differs between the fp32
-    tables the layer node gathered and the float64 oracle (tools/flip_probe.py scanned seeds 100-139 on the round-3 node:
+    tables the layer node gathered and the float64 oracle (tools/closed/flip_probe.py scanned seeds 100-139 on the round-3 node:
     0 flips for 100-104 at d=300 and for 101-106 at d=256), so forward and every gradient must meet 1e-4 outright."""
     _check_random_layer(n, nr, d, e, hub, chunk, 1, seed=seed, lay_seed=seed, strict=True)
 

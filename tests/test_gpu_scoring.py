@@ -346,6 +346,30 @@ def test_sim_topk_fused_running_topk_is_bit_identical_to_two_step_form(L, N, d, 
     assert int(lib().jmac_sim_topk_workspace_bytes(L, N, k)) < (0.3 if N >= 20000 else 0.6) * L * N * 4
 
 
+def test_sim_gemm_both_tiles_give_the_same_bits():
+    """Round 6: launch_sim picks the 128 x 256 tile (a wave owns 64 x 128) when its quantised makespan is no larger than the
+    128 x 128 tile's, else the narrow one; the contraction order per output element is the same, so WHICH one ran must not be
+    visible.  A 4 096 x 8 192 product takes the wide tile (1 024 wide tiles = 2 rounds of 512 against 3 rounds of 768 narrow
+    ones); the same product asked for in 128-row blocks has 32 wide tiles per call -- fewer than the resident blocks -- and takes
+    the narrow one.  Ragged edges on both sides, d = 300 (a row's last 16-k slab is zero-filled past k = 300), and the fused
+    top-k (FILTER epilogue of both tiles) against the two-step form on the same shape."""
+    from jmac_amd import scoring
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    M, N, d = 4096 + 37, 8192 + 101, 300
+    a = torch.nn.functional.normalize(torch.randn(M, d, device="cuda", generator=gen))
+    b = torch.nn.functional.normalize(torch.randn(N, d, device="cuda", generator=gen))
+    whole = scoring.sim_matrix(a, b)
+    blocks = torch.cat([scoring.sim_matrix(a[i:i + 128].contiguous(), b) for i in range(0, M, 128)])
+    assert torch.equal(whole, blocks)
+    ref = a[:64].double() @ b.double().t()
+    assert float((whole[:64].double() - ref).abs().max()) < 2e-6
+    idx, val = scoring.sim_topk(a, b, 25, return_values=True)                # L = 4 133: the wide FILTER tile
+    val2, idx2 = _two_step_topk(a, b, 25)
+    assert torch.equal(idx, idx2) and torch.equal(val, val2)
+    idx3, val3 = scoring.sim_topk(a[:130].contiguous(), b, 25, return_values=True)       # L = 130: the narrow one
+    assert torch.equal(idx3, idx2[:130]) and torch.equal(val3, val2[:130])
+
+
 def test_sim_topk_fused_overflowing_rows_recompute_exactly():
     """Mass ties push more than the list capacity over a row's threshold: those rows recompute their scores with the product's
     own MFMA sequence and must still return the two-step answer (ties -> lower index first)."""
