@@ -520,8 +520,26 @@ __global__ __launch_bounds__(kBlock, SgTile<WJ>::OCC) void sim_gemm_kernel(const
     int tm, tn;
     int id = next_tile(blockIdx.x, tm, tn);
     if (id >= n_ids) return;
+    // A tile's first slab: staged rows -> LDS buffer 0, slab 1 requested, the first fragments read.  Called for the block's first
+    // tile here and for every further tile at the END of the loop body, behind the previous tile's epilogue: a separate instance
+    // of the code, so that its wait for the slab's loads is counted on that path alone -- the loads were issued BEFORE the epilogue's
+    // 64 stores and vmcnt retires in order, so the stores stay in flight (vmcnt(63)).  With the prologue at the loop's top the
+    // kernel-entry path (nothing but four loads pending) and the back edge merged into vmcnt(3): every tile began by waiting for
+    // the previous tile's stores to be acknowledged (round 6: the "nostore" ablation's 6 %).
+    auto tile_prologue = [&](const int m0, const int n0) {
+        sstore(As[0], ra, 0);
+        sstore(Bs[0], rb, 0);
+        if (nk > 1 && !SG_NO_LOAD) {
+            gload(A, lda, m0, M, SG_K, ra);
+            gload(Bm, ldb, n0, N, SG_K, rb);
+        }
+        __syncthreads();
+        frags(0, 0, af0, bf0);
+        if (SG_MFMA_ONLY) frags(0, 1, af1, bf1);
+    };
     gload(A, lda, tm * SG_T, M, 0, ra);
     gload(Bm, ldb, tn * SG_TN, N, 0, rb);
+    tile_prologue(tm * SG_T, tn * SG_TN);
     while (id < n_ids) {
         const int m0 = tm * SG_T, n0 = tn * SG_TN;
 #pragma unroll
@@ -536,15 +554,6 @@ __global__ __launch_bounds__(kBlock, SgTile<WJ>::OCC) void sim_gemm_kernel(const
         // exists (requested); the steady state (both) runs in the loop, the last two slabs are peeled -- and inside it the LDS and
         // memory operations are spread between the MFMAs (sched_group_barrier): one operation behind each MFMA instead of a burst
         // behind sixteen of them (ablation and A/B: profiles/r6_simgemm_ablation.txt; +3 % over the burst form).
-        sstore(As[0], ra, 0);
-        sstore(Bs[0], rb, 0);
-        if (nk > 1 && !SG_NO_LOAD) {
-            gload(A, lda, m0, M, SG_K, ra);
-            gload(Bm, ldb, n0, N, SG_K, rb);
-        }
-        __syncthreads();
-        frags(0, 0, af0, bf0);
-        if (SG_MFMA_ONLY) frags(0, 1, af1, bf1);
         auto slab_body = [&](const int kt, auto has1, auto has2) {
             constexpr bool HAS1 = decltype(has1)::value && !SG_MFMA_ONLY, HAS2 = decltype(has2)::value && !SG_MFMA_ONLY && !SG_NO_LOAD;
             const int cur = kt & 1;
@@ -661,31 +670,43 @@ __global__ __launch_bounds__(kBlock, SgTile<WJ>::OCC) void sim_gemm_kernel(const
                     }
                 }
             flush();
-        } else
+        } else if (SG_NO_STORE || full) {
+            // interior tile: 64 unconditional stores per wave, then (its own instance: see tile_prologue) the next tile's first slab
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < SG_WJ; ++j) {
-                float* cbase = C + (int64_t)(m0 + wm * 64 + i * 32 + 4 * h) * ldc + (n0 + wn * 32 * SG_WJ + j * 32 + r);
-                if (SG_NO_STORE) {                         // ablation: nothing leaves the CU, the accumulators stay live
+                for (int j = 0; j < SG_WJ; ++j) {
+                    float* cbase = C + (int64_t)(m0 + wm * 64 + i * 32 + 4 * h) * ldc + (n0 + wn * 32 * SG_WJ + j * 32 + r);
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg)
-                        if (acc[i][j][reg] == 123456.789f) cbase[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg];
-                } else if (full) {
+                    for (int reg = 0; reg < 16; ++reg) {
+                        if (SG_NO_STORE) {                 // ablation: nothing leaves the CU, the accumulators stay live
+                            if (acc[i][j][reg] == 123456.789f) cbase[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg];
+                        } else {
+                            cbase[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg];
+                        }
+                    }
+                }
+            if (nid < n_ids) tile_prologue(ntm * SG_T, ntn * SG_TN);
+            id = nid;
+            tm = ntm;
+            tn = ntn;
+            continue;
+        } else {
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) cbase[(int64_t)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg];
-                } else {
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < SG_WJ; ++j)
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int64_t m = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                         const int64_t n = n0 + wn * 32 * SG_WJ + j * 32 + r;
                         if (m < M && n < N) C[m * ldc + n] = acc[i][j][reg];
                     }
-                }
-            }
+        }
         id = nid;
         tm = ntm;
         tn = ntn;
+        if (id < n_ids) tile_prologue(tm * SG_T, tn * SG_TN);     // (no wave reads LDS any more: see above)
     }
 }
 
