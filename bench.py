@@ -1525,8 +1525,7 @@ def main():
         # efficiency of this value has to be computed against.
         import torch.distributed as dist
         from bench_dist import run_sharded
-        sa = argparse.Namespace(**vars(a))
-        sa.steps, sa.warmup = max(3, min(a.steps, 10)), 2
+        sa = argparse.Namespace(**vars(a))                  # the line's value: EXACTLY --steps timed steps after --warmup untimed ones
         line = run_sharded(sa, rank, world, device)
         if rank == 0:
             complete_sharded_line(line, a)
