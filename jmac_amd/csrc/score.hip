@@ -26,6 +26,10 @@ constexpr int L1_T = 64, L1_K = 16, L1_LD = L1_T + 4;
 
 // acc + |a - b| in two full-rate VALU ops (v_sub_f32, v_add_f32 with the |.| source modifier).  Left to the
 // compiler, fabsf() becomes v_and_b32 and the adds are SLP-packed into half-rate v_pk_add_f32: 3 issue slots.
+// (Round 6, tools/r6_l1_probe.py: with -fno-slp-vectorize the compiler's own form keeps the |.| modifier and has none of the
+// hazard s_nops hipcc puts between dependent asm statements -- one per sub/add pair here -- but it hoists a slab's 32 fragment
+// reads: 165 VGPRs against 56, three waves per SIMD, and the tile kernels run 8-60 % SLOWER; at eight waves per SIMD the nops
+// cost nothing, another wave issues in their slot.)
 __device__ __forceinline__ float add_absdiff(float acc, float a, float b) {
     float d, r;
     asm("v_sub_f32_e32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
