@@ -84,15 +84,20 @@ def train_alignment_component(model: JMAC, opt, ei1, et1, ei2, et2, feeddict):
 
 
 @torch.no_grad()
-def evaluate_completion(model: JMAC, kg: KnowledgeGraph, ei, et, args, split="val", filtered=True, fused=True):
-    """CompletionEvaluator.test (src/validate.py:22-80) with the encoder run once instead of once per batch."""
+def evaluate_completion(model: JMAC, kg: KnowledgeGraph, ei, et, args, split="val", filtered=True, fused=True, eval_batch=None):
+    """CompletionEvaluator.test (src/validate.py:22-80) with the encoder run once instead of once per batch.
+    The reference scores 1 000 queries at a time (``args.batch_size``) because it materialises their [B, N] distance matrix.  The
+    fused path has no matrix and a query's rank does not depend on what else is in its call, so it takes ``eval_batch`` queries
+    per call -- default: up to 16 384, i.e. a whole DBP-5L split at once (the per-call query preparation and the last partial
+    round of tiles are paid once); the materialised path keeps the reference's batches."""
     model.eval()
     data = {"val": kg.val_data, "test": kg.test_data, "train": kg.train_data}[split]
     eb, rb = [kg.entity_id_base, kg.upper_entity_base], [kg.relation_id_base, kg.upper_relation_base]
     cached = model.forward_base(ei, et, eb, rb)
     ranks = []
-    for s in range(0, len(data), args.batch_size):
-        b = data[s:s + args.batch_size]
+    step = int(eval_batch or (16384 if fused else args.batch_size))
+    for s in range(0, len(data), step):
+        b = data[s:s + step]
         h, r, t = b[:, 0].tolist(), b[:, 1].tolist(), b[:, 2].tolist()
         fp = fi = None
         if filtered:
