@@ -33,6 +33,7 @@ HIGHLIGHTS = (("ms_per_step_torch_adam", ("ms_per_step_torch_adam",)),
               ("synth.fwd_bf16_frac_hbm", ("synth", "fwd_bf16_frac_hbm")),
               ("sim.mfma_frac_of_f32_peak", ("sim", "mfma_frac_of_f32_peak")),
               ("scoring.scored_triples_per_s", ("scoring", "scored_triples_per_s")),
+              ("scoring.whole_split_triples_per_s", ("scoring", "whole_split", "scored_triples_per_s")),
               ("sharded.ms_per_step", ("sharded", "ms_per_step")),
               ("sharded.rehearsal_world8.agg_ms", ("sharded", "rehearsal_world8", "step_ms")),
               ("sharded.speedup8_rehearsed", ("sharded", "scaling_model", "predicted", "8", "speedup_vs_1")),
