@@ -386,13 +386,13 @@ __global__ __launch_bounds__(kBlock) void link_rank_tile_kernel(LinkRankArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------
-// similarity GEMM  C = A * B^T  on the fp32-input MFMA (32x32x2), 128x128 tile per 4-wave block, K staged 16 deep
+// similarity GEMM  C = A * B^T  on the fp32-input MFMA (32x32x2), 128x128 or 128x256 tile per 4-wave block, K staged 16 deep
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Tile: 128 rows x (64 WJ) columns per 4-wave block, wave grid 2 x 2, a wave owns 64 x (32 WJ).  WJ = 2: the 128 x 128 tile of
 // rounds 1-5 (64 accumulator registers, 3 blocks per CU); WJ = 4: 128 x 256 (128 accumulator registers, 2 blocks per CU): per flop
-// a quarter fewer operand bytes through L2 and LDS and half as many barriers (round 6: +4..6 % where the tile count divides the
-// resident blocks as well, profiles/r6_simgemm_ablation.txt).  launch_sim picks per shape.  The contraction order per output
+// a quarter fewer operand bytes through L2 and LDS and half as many barriers (round 6: +3.5 % where its rounds of resident blocks are
+// no coarser, profiles/r6_simgemm_ablation.txt).  launch_sim picks per shape.  The contraction order per output
 // element is the same for both (planes k = 8q + 4h + s), so the results are bit-identical whichever runs.
 constexpr int SG_T = 128, SG_K = 16;
 constexpr int SG_PLANE = SG_T * 4 + 8;      // floats per (sub-slab q, k-half h) plane; +8: the 4 planes a wave store
