@@ -349,13 +349,13 @@ def test_sim_topk_fused_running_topk_is_bit_identical_to_two_step_form(L, N, d, 
 def test_sim_gemm_both_tiles_give_the_same_bits():
     """Round 6: launch_sim picks the 128 x 256 tile (a wave owns 64 x 128) when its quantised makespan is no larger than the
     128 x 128 tile's, else the narrow one; the contraction order per output element is the same, so WHICH one ran must not be
-    visible.  A 4 096 x 8 192 product takes the wide tile (1 024 wide tiles = 2 rounds of 512 against 3 rounds of 768 narrow
-    ones); the same product asked for in 128-row blocks has 32 wide tiles per call -- fewer than the resident blocks -- and takes
-    the narrow one.  Ragged edges on both sides, d = 300 (a row's last 16-k slab is zero-filled past k = 300), and the fused
+    visible.  A 4 059 x 8 091 product takes the wide tile (32 x 32 = 1 024 wide tiles = 2 rounds of the 512 resident blocks
+    against 3 rounds of 768 for the 2 048 narrow ones, on the 256 CUs of an MI355X); the same product asked for in 128-row blocks
+    has 32 wide tiles per call -- fewer than the resident blocks -- and takes the narrow one.  Ragged edges on both sides, d = 300 (a row's last 16-k slab is zero-filled past k = 300), and the fused
     top-k (FILTER epilogue of both tiles) against the two-step form on the same shape."""
     from jmac_amd import scoring
     gen = torch.Generator(device="cuda").manual_seed(77)
-    M, N, d = 4096 + 37, 8192 + 101, 300
+    M, N, d = 4096 - 37, 8192 - 101, 300
     a = torch.nn.functional.normalize(torch.randn(M, d, device="cuda", generator=gen))
     b = torch.nn.functional.normalize(torch.randn(N, d, device="cuda", generator=gen))
     whole = scoring.sim_matrix(a, b)
@@ -363,11 +363,31 @@ def test_sim_gemm_both_tiles_give_the_same_bits():
     assert torch.equal(whole, blocks)
     ref = a[:64].double() @ b.double().t()
     assert float((whole[:64].double() - ref).abs().max()) < 2e-6
-    idx, val = scoring.sim_topk(a, b, 25, return_values=True)                # L = 4 133: the wide FILTER tile
-    val2, idx2 = _two_step_topk(a, b, 25)
+    # the fused top-k: jmac_sim_topk_f32 samples the first 2 048 columns and runs the FILTER product over the other 8 142 --
+    # 32 x 32 wide tiles again (against 32 x 64 narrow ones): the wide FILTER tile; 130 query rows: the narrow one
+    b2 = torch.nn.functional.normalize(torch.randn(10240 - 50, d, device="cuda", generator=gen))
+    idx, val = scoring.sim_topk(a, b2, 25, return_values=True)
+    val2, idx2 = _two_step_topk(a, b2, 25)
     assert torch.equal(idx, idx2) and torch.equal(val, val2)
-    idx3, val3 = scoring.sim_topk(a[:130].contiguous(), b, 25, return_values=True)       # L = 130: the narrow one
+    idx3, val3 = scoring.sim_topk(a[:130].contiguous(), b2, 25, return_values=True)
     assert torch.equal(idx3, idx2[:130]) and torch.equal(val3, val2[:130])
+
+
+@pytest.mark.parametrize("d", [4, 20, 304])
+def test_sim_gemm_wide_tile_operand_and_accumulator_maps(d):
+    """The 128 x 256 tile's LDS planes, fragment reads and C/D map on exact integers (asymmetric B, ragged edges on both sides);
+    d = 4: one 16-k slab, mostly zero-filled; d = 20: two slabs, the second with one live float4; d = 304: 19 full slabs."""
+    from jmac_amd import scoring
+    gen = torch.Generator().manual_seed(d)
+    # 32 x 32 = 1 024 wide tiles = 2 rounds of the 512 resident blocks (2 x 512 x 2 = 2 048 units) against 32 x 64 = 2 048 narrow
+    # tiles = 3 rounds of 768 (2 304): launch_sim takes WJ = 4 (256 CUs: MI355X); both edges ragged
+    M, N = 4096 - 5, 8192 - 3
+    ai = torch.randint(-3, 4, (M, d), generator=gen).float()
+    bi = (torch.arange(N).view(-1, 1) % 5 + torch.arange(d).view(1, -1) % 3).float()
+    got = scoring.sim_matrix(ai.cuda(), bi.cuda())
+    assert torch.equal(got.cpu(), ai @ bi.t())
+    blocks = torch.cat([scoring.sim_matrix(ai[i:i + 256].cuda(), bi.cuda()) for i in range(0, M, 256)])     # narrow tile
+    assert torch.equal(got, blocks)
 
 
 def test_sim_topk_fused_overflowing_rows_recompute_exactly():
