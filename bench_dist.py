@@ -190,11 +190,16 @@ def run_sharded(a, rank, world, device):
             # north_star's 8-GPU configuration (a 10x graph, strong-scaled: 2M entities / 200M triples) from THIS run's per-row and
             # per-edge rates -- the graph itself is run by `--scaling strong --synth-scale 10`
             m = scaling_model(el / a.steps * 1e3, fms, bms, len(layers), 2_000_000, 200_000_000, d, 1, True,
-                              wire_bytes=2 if wire is not None else 4, chunks=sg.chunks, run_rows=n_loc, run_edges=e_loc)
+                              wire_bytes=2 if wire is not None else 4, chunks=sg.chunks, run_rows=n_loc, run_edges=e_loc,
+                              rehearsal=committed_strong_rehearsal(d))
             m["assumptions"]["kind"] = ("strong, 2M entities / 200M triples; extrapolated from the measured per-row / per-edge rates of "
                                         "this run's %d-entity / %d-triple rank" % (n_loc, e_loc))
             del m["measured_here"]
             m["memory_GB_one_gpu"] = step_memory_gb(2_000_000, 200_000_000, d, len(layers))
+            if "carried_over" in m:
+                m["assumptions"]["aggregation_at_W"] = ("rank 0's share of THIS graph at world 1 / 2 / 4 / 8 measured on one GPU (bench_dist.py "
+                                                        "--rehearse-strong -> %s, committed; not collected by this run); the rest of the "
+                                                        "step carried over from this run per row" % STRONG_REHEARSAL_FILE)
             line["scaling_model_strong_10x"] = m
             # the other reading of "a 10x graph": 10M entities / 200M triples.  It does not fit ONE GPU (the base of a strong-scaling
             # ratio), which is why the 2M-entity graph is the one that is run; the model for it is printed beside it
@@ -364,6 +369,56 @@ def rehearse_world(a, device, world=8, chunks=4, check=True):
     return res
 
 
+def rehearse_strong(a, device, worlds=(8, 4, 2, 1), scale=10.0):
+    """ONE process, no collective: rank 0's share of the STRONG-scaled graph -- north_star's "10x synthetic graph", 2M entities /
+    200M triples at scale 10 (the graph `bench.py --gpus N --scaling strong --synth-scale 10` partitions) -- at each world size:
+    n_glob / W local destinations, e_glob / W edges whose sources are uniform over the WHOLE n_glob-row [Q|Z] table (the same
+    4.8 GB table at every W, filled locally).  Times the one-piece forward and the one-call backward of the aggregation (HIP
+    events, median of 3): what `scaling_model_strong_10x` used to extrapolate from the weak run's per-edge rate (1M rows / 20M
+    edges gathering from a 1M-row table) is measured on the shapes a rank really has, the N = 1 base included."""
+    from jmac_amd import ops, synth
+    from jmac_amd.dist import ShardedGraph
+    d, nr, slope = a.dim, 1000, 0.05
+    n_glob, e_glob = int(200_000 * scale), int(20_000_000 * scale)
+    gen = torch.Generator(device=device).manual_seed(78)
+    QZ = torch.empty(n_glob, 2 * d, device=device)
+    for r0 in range(0, n_glob, 1 << 20):
+        QZ[r0:r0 + (1 << 20)].normal_(0.0, 0.3, generator=gen)
+    RR = torch.randn(nr + 1, 2 * d, device=device, generator=gen) * 0.3
+    av = torch.randn(d, device=device, generator=gen) * 0.1
+    out = {"what": "rank 0's share of the strong-scaled %d-entity / %d-triple graph at each world size in one process: sources uniform "
+                   "over the whole %d-row [Q|Z] table (%.1f GB), table filled locally, no collective"
+                   % (n_glob, e_glob, n_glob, n_glob * 2 * d * 4 / 1e9), "global_entities": n_glob, "global_triples": e_glob, "worlds": {}}
+    for W in worlds:
+        t0 = time.perf_counter()
+        ei, et, n_loc, e_loc = _strong_graph(0, W, n_glob, e_glob, nr)
+        bounds = np.arange(W + 1, dtype=np.int64) * n_loc
+        sg = ShardedGraph(ei, et, bounds, 0, already_local=True, chunks=1)
+        del ei, et
+        g = sg.rel_graph(device, nr + 1)
+        g.ensure_backward_views()
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - t0
+        P = torch.randn(n_loc, d, device=device, generator=gen) * 0.3
+        G = torch.randn(n_loc, d, device=device, generator=gen)
+        fw = lambda: ops.rel_attn_split_fwd_raw(P, QZ, RR, av, g, slope, 0.5, nr, sg.self_off)
+        o, m, l = fw()
+        fwd_ms = _ms(fw, n=3)
+        bwd_ms = _ms(lambda: ops.rel_attn_split_bwd_raw(P, QZ, RR, av, g, slope, 0.5, nr, sg.self_off, o, m, l, G), n=3)
+        fb, bb = synth.fwd_algorithmic_bytes(n_loc, e_loc, d), synth.bwd_algorithmic_bytes(n_loc, e_loc, d)
+        out["worlds"][str(W)] = {"local_rows": n_loc, "local_edges": e_loc, "table_rows": n_glob, "fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
+                                 "fwd_frac_hbm": fb / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bwd_frac_hbm": bb / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "max_in_degree": int((g.rowptr[1:] - g.rowptr[:-1]).max()), "graph_build_s": build_s}
+        del sg, g, P, G, o, m, l
+        torch.cuda.empty_cache()
+    out["max_memory_GB"] = torch.cuda.max_memory_allocated() / 1e9
+    w = out["worlds"]
+    if "1" in w:
+        for W in w:
+            w[W]["aggregation_speedup_vs_1"] = (w["1"]["fwd_ms"] + w["1"]["bwd_ms"]) / (w[W]["fwd_ms"] + w[W]["bwd_ms"])
+    return out
+
+
 XGMI_LINK_GBS, XGMI_EFF = 153.0, 0.8     # one xGMI link per peer pair (MI355X: 7 links x ~153 GB/s per GPU), sustained fraction assumed
 PASS_B_SHARE = 0.4                       # assumed share of the aggregation backward that is pass B (by source: what a reduce-scatter of
                                          # d[Q|Z] slabs can hide behind); ja-size kernel times: A 28 us, B || C 27 us, merges 11 us
@@ -388,6 +443,22 @@ def step_memory_gb(n, e, d, n_layers, hbm_gb=288.0):
                     "partial-row buffers of the split segments come on top"}
 
 
+STRONG_REHEARSAL_FILE = "profiles/r6_rehearse_strong.json"
+
+
+def committed_strong_rehearsal(d):
+    """rehearse_strong()'s per-world figures for the 2M-entity / 200M-triple graph from the committed run, or None."""
+    import json
+    import os
+    try:
+        doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), STRONG_REHEARSAL_FILE)))
+        if doc.get("global_entities") != 2_000_000 or doc.get("global_triples") != 200_000_000 or d != 300:
+            return None
+        return {int(W): v for W, v in doc["worlds"].items()}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def scaling_model(step_ms, agg_fwd_ms, agg_bwd_ms, n_layers, n_glob, e_glob, d, world, strong, wire_bytes=4, chunks=1,
                   run_rows=None, run_edges=None, rehearsal=None):
     """What this run's own measurements predict for 2 / 4 / 8 GPUs -- an explicit model, NOT a measurement (no multi-GPU node has
@@ -408,7 +479,10 @@ def scaling_model(step_ms, agg_fwd_ms, agg_bwd_ms, n_layers, n_glob, e_glob, d, 
     backward, the pipelined form's extra cost and pass B's share of the backward at W are THOSE measurements instead of the
     world-1 figures carried over; the figures carried over stay beside them (``carried_over``) so that the change is visible."""
     n_run, e_run = (run_rows or n_glob / world), (run_edges or e_glob / world)
-    reh = {int(k): v for k, v in (rehearsal or {}).items()} if not strong else {}
+    # {W: rehearse_world(W)} (weak) or rehearse_strong()["worlds"] (strong, the graph it was measured on only)
+    reh = {int(k): v for k, v in (rehearsal or {}).items()}
+    if reh and strong != ("fwd_ms" in next(iter(reh.values()))):
+        reh = {}                                                # a weak rehearsal says nothing about a strong model and vice versa
     out = {"assumptions": {"xgmi_link_GBps": XGMI_LINK_GBS, "sustained_fraction": XGMI_EFF, "overlap": "none beyond the measured step",
                            "wire_bytes_per_element": wire_bytes, "kind": "strong" if strong else "weak"},
            "measured_here": {"world": world, "step_ms": step_ms, "aggregation_ms": n_layers * (agg_fwd_ms + agg_bwd_ms),
@@ -446,7 +520,11 @@ def _predict(step_ms, agg_fwd_ms, agg_bwd_ms, n_layers, n_glob, e_glob, d, stron
         n_tot, e_tot = (n_glob, e_glob) if strong else (n_run * W, e_run * W)
         n_w, e_w = n_tot / W, e_tot / W
         r = reh.get(W)
-        if r is not None:                                       # measured on this rank's world-W shapes
+        if r is not None and "fwd_ms" in r:                     # rehearse_strong: the aggregation alone, measured on this rank's shapes
+            fwd_w, bwd_w = r["fwd_ms"], r["bwd_ms"]
+            over = 7.5 * (0.5 * n_w / 1e6 + 0.5 * e_w / 2e7) if chunks == 1 else 0.0
+            pass_b, bwd_extra = PASS_B_SHARE * bwd_w, 0.0
+        elif r is not None:                                     # rehearse_world: measured on this rank's world-W shapes
             fwd_w, bwd_w = r["one_piece_fwd_ms"], r["one_call_bwd_ms"]
             over = r["pipelined"]["extra_over_one_piece_ms"] if chunks == 1 else 0.0
             pass_b = r["phased_bwd"]["pass_b_share"] * r["phased_bwd"]["total_ms"]
@@ -502,10 +580,15 @@ def main():
     ap.add_argument("--synth-scale", type=float, default=1.0)
     ap.add_argument("--dim", type=int, default=300)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--rehearse-strong", action="store_true",
+                    help="instead: rank 0's share of the strong-scaled 2M / 200M graph at world 8, 4, 2, 1 (aggregation forward / backward)")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench_dist.py needs an MI355X (no CPU fallback for the product path)")
-    res = rehearse_world(a, torch.device("cuda", 0), a.rehearse_world, a.pipeline_chunks, check=not a.no_check)
+    if a.rehearse_strong:
+        res = rehearse_strong(a, torch.device("cuda", 0), scale=10.0 * a.synth_scale)
+    else:
+        res = rehearse_world(a, torch.device("cuda", 0), a.rehearse_world, a.pipeline_chunks, check=not a.no_check)
     print(json.dumps(res), flush=True)
 
 

@@ -75,3 +75,25 @@ def test_scaling_model_takes_the_rehearsed_aggregation_where_it_was_measured():
     s_new = bench_dist.scaling_model(step, f1, b1, 2, 2_000_000, 200_000_000, 300, 1, True, run_rows=1_000_000, run_edges=20_000_000,
                                      rehearsal=reh)
     assert s_new["predicted"] == s_old["predicted"] and "carried_over" not in s_new
+
+
+def test_strong_model_takes_the_strong_rehearsal_and_only_that():
+    """rehearse_strong(): the aggregation of rank 0's share of the 2M / 200M graph at world 1, 2, 4, 8, measured on one GPU.  The
+    strong model's compute term becomes those figures + the run's non-aggregation time per row; a weak rehearsal is ignored by a
+    strong model and a strong one by a weak model."""
+    import bench_dist
+    strong = {W: {"fwd_ms": 120.0 / W + 1.0, "bwd_ms": 230.0 / W + 2.0, "local_rows": 2_000_000 // W, "local_edges": 200_000_000 // W}
+              for W in (1, 2, 4, 8)}
+    step, f1, b1 = 108.0, 10.9, 20.2
+    kw = dict(run_rows=1_000_000, run_edges=20_000_000)
+    old = bench_dist.scaling_model(step, f1, b1, 2, 2_000_000, 200_000_000, 300, 1, True, **kw)
+    new = bench_dist.scaling_model(step, f1, b1, 2, 2_000_000, 200_000_000, 300, 1, True, rehearsal=strong, **kw)
+    other = step - 2 * (f1 + b1)
+    for W in (1, 2, 4, 8):
+        want = 2 * (strong[W]["fwd_ms"] + strong[W]["bwd_ms"]) + other * (2_000_000 / W) / 1_000_000
+        assert abs(new["predicted"][str(W)]["compute_ms"] - want) < 1e-9
+        assert new["predicted"][str(W)]["exchange_ms"] == old["predicted"][str(W)]["exchange_ms"]
+    assert new["carried_over"]["predicted"] == old["predicted"]
+    weak_model = bench_dist.scaling_model(step, f1, b1, 2, 1_000_000, 20_000_000, 300, 1, False, rehearsal=strong)
+    assert "carried_over" not in weak_model
+    assert weak_model["predicted"] == bench_dist.scaling_model(step, f1, b1, 2, 1_000_000, 20_000_000, 300, 1, False)["predicted"]
