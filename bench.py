@@ -114,6 +114,9 @@ def parse():
     ap.add_argument("--no-torch-adam-leg", action="store_true",
                     help="skip the second timing of the headline step with torch.optim.Adam (ms_per_step_torch_adam)")
     ap.add_argument("--no-synth", action="store_true")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the union / pair side sections as well (with --no-synth: the headline step, layer, scoring, sim only -- "
+                         "what tests/test_gpu_entry.py runs to check the line's contract)")
     ap.add_argument("--no-rehearsal", action="store_true", help="skip the one-GPU rehearsal of a rank's world-2/4/8 shapes (sharded.rehearsal_world*)")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the library GEMM heuristics as they are")
     ap.add_argument("--torch-adam", action="store_true", help="step torch.optim.Adam(fused, capturable) instead of jmac_amd.optim.Adam")
@@ -1654,12 +1657,13 @@ def main():
     except Exception as ex:                          # pragma: no cover
         line["sim"] = {"error": str(ex)}
     lap("layer_scoring_sim")
-    try:
-        line["union"] = union_bench(a, device, cpu=cpu_on)
-    except Exception as ex:                          # pragma: no cover
-        line["union"] = {"error": str(ex)}
-    lap("union")
-    if a.data == "real":
+    if not a.no_side:
+        try:
+            line["union"] = union_bench(a, device, cpu=cpu_on)
+        except Exception as ex:                          # pragma: no cover
+            line["union"] = {"error": str(ex)}
+        lap("union")
+    if a.data == "real" and not a.no_side:
         try:
             line["pair"] = pair_bench(a, device, rank, ms, cpu=cpu_on)
         except SystemExit:
