@@ -344,9 +344,12 @@ def rehearse_world(a, device, world=8, chunks=4, check=True):
         torch.cuda.synchronize()
         return bp, [evs[i].elapsed_time(evs[i + 1]) for i in range(C + 2)]
     phased()
-    runs = [phased() for _ in range(3)]
-    tms = np.median(np.array([t for _, t in runs]), axis=0)
-    bp = runs[-1][0]
+    times, bp = [], None
+    for _ in range(3):
+        bp = None                                              # one d[Q|Z] table (21.6 GB at world 8) alive at a time
+        bp, t = phased()
+        times.append(t)
+    tms = np.median(np.array(times), axis=0)
     res["phased_bwd"] = {"begin_ms": float(tms[0]), "slab_ms": [float(x) for x in tms[1:C + 1]], "own_rows_slab_ms": float(tms[C + 1]),
                          "total_ms": float(tms.sum()), "pass_b_share": float(tms[1:].sum() / tms.sum()),
                          "extra_over_one_call_ms": float(tms.sum()) - res["one_call_bwd_ms"]}
@@ -364,7 +367,7 @@ def rehearse_world(a, device, world=8, chunks=4, check=True):
         res["checks"] = checks
         del dPc, dTc, dRRc, dac
     res["max_memory_GB"] = torch.cuda.max_memory_allocated() / 1e9
-    del table, bp, runs, pre, out, P, G
+    del table, bp, pre, out, P, G
     torch.cuda.empty_cache()
     return res
 
