@@ -303,3 +303,41 @@ def test_pair_cosine_mean_fwd_bwd(N1, N2, d, L, same):
     bg2 = ag2 if same else e2.to(dev).requires_grad_(True)
     (losses.pair_cosine_distance(ag2, i1.to(dev), bg2, i2.to(dev)).mean() * 0.3).sum().backward()
     assert_close(ag.grad, ag2.grad, 1e-6, 1e-9, "rows form (scalar gradient) vs the vector form")
+
+
+def test_pair_cosine_with_an_index_pair_first_seen_inside_a_capture():
+    """the incidence record of an index pair that a stream capture meets for the first time is sorted INSIDE the
+    capture -- with no host read on the way (the row pointer used to come from torch.bincount, which reads its maximum back and
+    aborted the capture).  The replayed graph's loss and gradient equal the eager ones on the same tensors."""
+    from jmac_amd import losses
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    e = (torch.randn(500, 300, device="cuda", generator=gen)).requires_grad_(True)
+    i1 = torch.randint(0, 500, (777,), device="cuda", generator=gen)
+    i2 = torch.randint(0, 500, (777,), device="cuda", generator=gen)
+    static_loss = torch.zeros(1, device="cuda")
+    static_grad = torch.zeros_like(e)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):                                          # warm-up on OTHER index tensors: the capture's pair stays unseen
+        w1, w2 = i1.clone(), i2.clone()
+        for _ in range(2):
+            (g,) = torch.autograd.grad(losses.pair_cosine_mean(e, w1, e, w2), [e])
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss = losses.pair_cosine_mean(e, i1, e, i2)                    # (i1, i2): first seen here
+        (g,) = torch.autograd.grad(loss, [e])
+        static_loss.copy_(loss.reshape(1))
+        static_grad.copy_(g)
+    graph.replay()
+    torch.cuda.synchronize()
+    want = losses.pair_cosine_mean(e, i1, e, i2)
+    (gw,) = torch.autograd.grad(want, [e])
+    assert torch.equal(static_loss, want.reshape(1).detach())
+    assert torch.equal(static_grad, gw)
+    e64 = e.detach().double().cpu().requires_grad_(True)
+    ref = orc.pair_cosine_distance(e64, i1.cpu(), e64, i2.cpu()).mean()
+    ref.backward()
+    assert_close(static_loss, ref.detach().reshape(1), 1e-5, what="loss")
+    assert_close(static_grad, e64.grad, 1e-5, what="d e")
