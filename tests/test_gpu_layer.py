@@ -277,3 +277,59 @@ def test_split_tables_fewer_source_rows_than_destinations_no_loop(n_dst, n_src, 
     assert_close(QZg.grad, PQZ.grad[:n_src, d:], gtol, 1e-9, "dQZ")
     assert_close(Rg.grad, R64.grad, gtol, 1e-9, "dRR")
     assert_close(ag.grad, a64.grad, gtol, 1e-9, "da")
+
+
+@pytest.mark.parametrize("kind", ["no_edges", "star", "duplicates_and_self_edges", "two_nodes_one_edge", "one_relation_everywhere"])
+@pytest.mark.parametrize("d", [300, 64])
+def test_layer_on_degenerate_graphs(kind, d):
+    """Graphs at the edge of what the schedules see (empty segments, single-edge segments, duplicate edges):
+    no edge at all (every segment empty: the layer is tanh(BN((X - r_loop'') W_gcn / 2))), every edge into ONE destination from
+    every other node (one split segment, all others empty), the same edge repeated and edges from a node to itself (the reference
+    counts each occurrence: message_passing.py:24-28 index on positions, not on pairs), two nodes joined by one edge, and one
+    relation id on every edge (one hot row of [Rq|Rz]).  Forward and every gradient against the float64 oracle."""
+    from jmac_amd.layer import RelationAwareLayer
+    rng = np.random.default_rng(len(kind) + d)
+    n, nr = (2, 3) if kind == "two_nodes_one_edge" else (97, 6)
+    if kind == "no_edges":
+        ei, et = np.zeros((2, 0), np.int64), np.zeros(0, np.int64)
+    elif kind == "star":
+        src = np.arange(1, n)
+        ei, et = np.stack([np.zeros_like(src), src]), rng.integers(0, nr, n - 1)
+    elif kind == "duplicates_and_self_edges":
+        base = np.stack([rng.integers(0, n, 40), rng.integers(0, n, 40)])
+        loops = np.stack([np.arange(10), np.arange(10)])
+        ei = np.concatenate([base, base, base[:, :7], loops, loops[:, :3]], axis=1)
+        et = np.concatenate([rng.integers(0, nr, 40)] * 2 + [rng.integers(0, nr, 7), rng.integers(0, nr, 10), rng.integers(0, nr, 3)])
+    elif kind == "two_nodes_one_edge":
+        ei, et = np.array([[1], [0]]), np.array([2])
+    else:
+        ei, et = np.stack([rng.integers(0, n, 500), rng.integers(0, n, 500)]), np.full(500, 4)
+    ei, et = torch.from_numpy(ei.astype(np.int64)), torch.from_numpy(et.astype(np.int64))
+    gen = torch.Generator().manual_seed(d + n)
+    X = torch.randn(n, d, generator=gen) * (4 / np.sqrt(d))
+    R = torch.randn(nr, d, generator=gen) * (4 / np.sqrt(d))
+    G = torch.randn(n, d, generator=gen)
+    torch.manual_seed(d)
+    lay = RelationAwareLayer(d, d, rel_dim=d, act=torch.tanh, args=make_args())
+    f64 = torch.float64
+    p = {k: v.detach().clone().to(f64).requires_grad_(True) for k, v in lay.named_parameters()}
+    Xc, Rc = X.clone().to(f64).requires_grad_(True), R.clone().to(f64).requires_grad_(True)
+    ref = orc.layer_forward(p, Xc, Rc, ei, et, 0.05, "sub", "leaky_relu", True, torch.zeros(d, dtype=f64), torch.ones(d, dtype=f64))
+    (ref * G.to(f64)).sum().backward()
+    lay = lay.cuda()
+    Xg, Rg = X.cuda().requires_grad_(True), R.cuda().requires_grad_(True)
+    out = lay(Xg, Rg, ei.cuda(), et.cuda())
+    (out * G.cuda()).sum().backward()
+    assert torch.isfinite(out).all()
+    # two rows under train-mode BatchNorm: the normalised values are +-1 whatever the inputs, the gradients through the statistics
+    # are differences of nearly equal numbers -- forward only there
+    assert_close(out, ref, RTOL, 1e-6, "out")
+    if kind != "two_nodes_one_edge":
+        assert_close(Xg.grad, Xc.grad, 5e-2, 1e-6, "grad_X")           # (tolerance of the random-graph test when a kink flips)
+        assert_close(Rg.grad, Rc.grad, 5e-2, 1e-6, "grad_R")
+        # gradients that are mathematically zero (no edge: nothing reaches the relation transforms but the loop row, whose constant
+        # shift per column train-mode BatchNorm removes) come out as rounding noise on both sides: absolute floor from the scale
+        gscale = max(float(v.grad.abs().max()) for v in p.values() if v.grad is not None)
+        for name, prm in lay.named_parameters():
+            if name != "loop_rel":
+                assert_close(prm.grad, p[name].grad, 5e-2, 1e-5 * gscale + 1e-6, "grad " + name)
