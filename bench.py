@@ -1062,7 +1062,7 @@ def pair_bench(a, device, rank, ms_single, cpu=True):
            "exec": mode, "ms_per_step": ms, "edges_per_s": e_all / (ms * 1e-3), "edges_counted_per_step": e_all,
            "batched": "one launch set on the block-diagonal union of the two graphs, per-KG BatchNorm statistics "
                       "(JMAC.forward_stacked)",
-           "ms_single_kg_step": ms_single, "ratio_to_single_kg_step": ms / ms_single if ms_single else None,
+           "ms_single_kg_step": ms_single,        # (another step: forward_base's three layers on ONE KG -- not a like-for-like ratio)
            "parity": parity}
     del w
     try:
